@@ -1,0 +1,299 @@
+"""gnxraytracer_amd -- MI355X-native wavefront path-tracing core (host-side Python mirror).
+
+This package is a thin ctypes layer over ``libgnxr.so`` (HIP kernels + C ABI, ``include/gnxr.h``).
+Names follow the reference's authoring layer so that tests read like the reference's own scene
+set-up (ui/ModelList.cpp, ui/MaterialList.cpp, ui/RenderThread.cpp:46-187):
+
+    b = SceneBuilder()
+    white = b.MatteMaterial((0.91, 0.91, 0.91), sigma=60)
+    ...
+    b.AddCornell(red, blue, white); b.AddAreaLight(white)
+    scene = Scene(b)                                   # Scene(make_shared<BVHAccel>(prims, 1), lights)
+    img, stats = PathIntegrator(8, rrThreshold=1.0).Render(scene, 256, 256, spp=64)
+
+There is NO CPU fallback: every compute call goes through the HIP library and raises
+``GnxrError`` if it (or a GPU) is missing.  The CPU restatement under ``oracle/`` is test
+infrastructure and is never imported from here.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi
+from ._abi import (Camera, Hit, Light, Material, Medium, Ray, RenderParams, SceneDesc, Stats)  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgnxr.so")
+
+
+class GnxrError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libgnxr.so (built by ``__graft_entry__.build()``); fail loudly when absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GnxrError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        _lib = _abi.bind(C.CDLL(LIB_PATH))
+        if _lib.gnxr_abi_version() != _abi.GNXR_ABI_VERSION:
+            raise GnxrError("libgnxr.so ABI version mismatch")
+    return _lib
+
+
+def _check(rc):
+    if rc < 0:
+        raise GnxrError(f"gnxr error {rc}: {lib().gnxr_last_error().decode(errors='replace')}")
+    return rc
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def init(device_id=0):
+    _check(lib().gnxr_init(int(device_id)))
+
+
+class SceneBuilder:
+    """Mirror of the scene-authoring free functions in ui/ModelList.cpp / ui/MaterialList.cpp."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        _check(lib().gnxr_builder_create(C.byref(self._h)))
+        self.hdr_path = None
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.gnxr_builder_destroy(self._h)
+            self._h = None
+
+    # ---- materials (return a material index) ----
+    def MatteMaterial(self, kd, sigma=60.0):          # ui/RenderThread.cpp:79-99
+        return _check(lib().gnxr_builder_matte(self._h, _f3(kd), float(sigma)))
+
+    def MirrorMaterial(self, kr):                     # ui/RenderThread.cpp:102
+        return _check(lib().gnxr_builder_mirror(self._h, _f3(kr)))
+
+    def getPurplePlasticMaterial(self):               # ui/MaterialList.cpp:48-56
+        return _check(lib().gnxr_builder_purple_plastic(self._h))
+
+    def getYelloMetalMaterial(self):                  # ui/MaterialList.cpp:58-69
+        return _check(lib().gnxr_builder_yellow_metal(self._h))
+
+    def getWhiteGlassMaterial(self):                  # ui/MaterialList.cpp:71-83
+        return _check(lib().gnxr_builder_white_glass(self._h))
+
+    def add_material(self, **kw):
+        m = Material()
+        m.has_bump = 1
+        for k, v in kw.items():
+            if isinstance(v, (tuple, list, np.ndarray)):
+                setattr(m, k, (C.c_float * len(v))(*[float(x) for x in v]))
+            else:
+                setattr(m, k, v)
+        return _check(lib().gnxr_builder_add_material(self._h, C.byref(m)))
+
+    def DisneyMaterial(self, color, metallic=0.0, eta=1.5, roughness=0.5, specularTint=0.0, anisotropic=0.0, sheen=0.0,
+                       sheenTint=0.5, clearcoat=0.0, clearcoatGloss=1.0, specTrans=0.0, thin=False, flatness=0.0,
+                       diffTrans=1.0):                 # materials/DisneyMaterial.h:21-36
+        return self.add_material(type=_abi.MAT_DISNEY, kd=color, eta=(eta, 0, 0), disney_metallic=metallic,
+                                 disney_roughness=roughness, disney_spec_tint=specularTint,
+                                 disney_anisotropic=anisotropic, disney_sheen=sheen, disney_sheen_tint=sheenTint,
+                                 disney_clearcoat=clearcoat, disney_clearcoat_gloss=clearcoatGloss,
+                                 disney_spec_trans=specTrans, disney_thin=int(thin), disney_flatness=flatness,
+                                 disney_diff_trans=diffTrans)
+
+    # ---- geometry / lights ----
+    def AddModel(self, path, material):               # ui/ModelList.cpp:47-69
+        return _check(lib().gnxr_builder_add_model_3d(self._h, os.fsencode(path), int(material)))
+
+    def AddCornell(self, material1, material2, material3):   # ui/ModelList.cpp:71-118
+        return _check(lib().gnxr_builder_add_cornell(self._h, int(material1), int(material2), int(material3)))
+
+    def AddFloor(self, material):                     # ui/ModelList.cpp:20-45
+        return _check(lib().gnxr_builder_add_floor(self._h, int(material)))
+
+    def AddAreaLight(self, material):                 # ui/ModelList.cpp:120-147
+        return _check(lib().gnxr_builder_add_area_light(self._h, int(material)))
+
+    def AddSkyLight(self):                            # ui/ModelList.cpp:163-170
+        return _check(lib().gnxr_builder_add_sky_light(self._h))
+
+    def AddInfLight(self, hdr_path):                  # ui/ModelList.cpp:172-179
+        self.hdr_path = str(hdr_path)
+        return _check(lib().gnxr_builder_add_inf_light(self._h, os.fsencode(hdr_path)))
+
+    def AddInfLightData(self, rgb, light_to_world=None, power=(1.0, 1.0, 1.0)):
+        rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+        h, w = rgb.shape[:2]
+        m = None
+        if light_to_world is not None:
+            m = np.ascontiguousarray(light_to_world, dtype=np.float32).reshape(16).ctypes.data_as(C.POINTER(C.c_float))
+        return _check(lib().gnxr_builder_add_inf_light_data(self._h, rgb.ctypes.data_as(C.POINTER(C.c_float)), w, h, m,
+                                                            _f3(power)))
+
+    def add_mesh(self, vertices, indices, material, object_to_world=None, medium_inside=-1, medium_outside=-1):
+        v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
+        i = np.ascontiguousarray(indices, dtype=np.int32).reshape(-1, 3)
+        m = None
+        if object_to_world is not None:
+            m = np.ascontiguousarray(object_to_world, dtype=np.float32).reshape(16).ctypes.data_as(C.POINTER(C.c_float))
+        return _check(lib().gnxr_builder_add_mesh(self._h, v.ctypes.data_as(C.POINTER(C.c_float)), len(v),
+                                                  i.ctypes.data_as(C.POINTER(C.c_int32)), len(i), m, int(material),
+                                                  int(medium_inside), int(medium_outside)))
+
+    def add_medium(self, medium, density=None):
+        d = None
+        if density is not None:
+            density = np.ascontiguousarray(density, dtype=np.float32)
+            d = density.ctypes.data_as(C.POINTER(C.c_float))
+        return _check(lib().gnxr_builder_add_medium(self._h, C.byref(medium), d))
+
+    def set_camera(self, eye=(0, 0, 5), look=(0, 0, 0), up=(0, 1, 0), fov=90.0, lens_radius=0.0, focal_distance=3.0):
+        cam = Camera(_f3(eye), _f3(look), _f3(up), fov, lens_radius, focal_distance)
+        _check(lib().gnxr_builder_set_camera(self._h, C.byref(cam)))
+
+    def desc(self):
+        """gnxr_scene_desc pointing into builder-owned memory (valid until the next builder call)."""
+        d = SceneDesc()
+        _check(lib().gnxr_builder_desc(self._h, C.byref(d)))
+        return d
+
+
+def write_synthetic_3d(path, target_triangles=100000, seed=1):
+    """Deterministic stand-in for the absent Resources/dragon.3d (`.MISSING_LARGE_BLOBS`)."""
+    _check(lib().gnxr_write_synthetic_3d(os.fsencode(path), int(target_triangles), int(seed)))
+
+
+class Scene:
+    """Device-resident scene: replaces `Scene(make_shared<BVHAccel>(prims, 1), lights)` (RenderThread.cpp:155)."""
+
+    def __init__(self, builder_or_desc):
+        self._h = C.c_void_p()
+        self._keep = builder_or_desc
+        d = builder_or_desc.desc() if isinstance(builder_or_desc, SceneBuilder) else builder_or_desc
+        _check(lib().gnxr_scene_create(C.byref(d), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.gnxr_scene_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def info(self):
+        n, dmax, nv = C.c_int32(), C.c_int32(), C.c_int32()
+        _check(lib().gnxr_scene_info(self._h, C.byref(n), C.byref(dmax), C.byref(nv)))
+        return {"bvh_nodes": n.value, "bvh_max_depth": dmax.value, "light_voxels": nv.value}
+
+    # Aggregate seam: Scene::Intersect / IntersectP, batched
+    def Intersect(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        hits = np.zeros(len(rays), dtype=HIT_DTYPE)
+        _check(lib().gnxr_trace_closest(self._h, rays.ctypes.data_as(C.POINTER(Ray)), len(rays),
+                                        hits.ctypes.data_as(C.POINTER(Hit))))
+        return hits
+
+    def IntersectP(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
+        occ = np.zeros(len(rays), dtype=np.uint8)
+        _check(lib().gnxr_trace_any(self._h, rays.ctypes.data_as(C.POINTER(Ray)), len(rays),
+                                    occ.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return occ
+
+
+HIT_DTYPE = np.dtype([("prim", np.int32), ("t", np.float32), ("b0", np.float32), ("b1", np.float32), ("b2", np.float32),
+                      ("n", np.float32, 3)])
+
+
+def make_rays(o, d, tmax=np.inf):
+    o = np.asarray(o, dtype=np.float32).reshape(-1, 3)
+    d = np.asarray(d, dtype=np.float32).reshape(-1, 3)
+    r = np.zeros((len(o), 8), dtype=np.float32)
+    r[:, 0:3] = o
+    r[:, 3] = tmax
+    r[:, 4:7] = d
+    return r
+
+
+def stats_dict(s):
+    return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+
+class PathIntegrator:
+    """Mirror of pbr::PathIntegrator(maxDepth, camera, sampler, bounds, fb, rrThreshold, strategy)
+    (integrators/PathIntegrator.cpp:20-29); camera and sampler are implied by the scene and (W, H, spp)."""
+    integrator = _abi.INTEGRATOR_PATH
+
+    def __init__(self, maxDepth=5, rrThreshold=1.0, lightSampleStrategy="spatial"):
+        self.maxDepth = int(maxDepth)
+        self.rrThreshold = float(rrThreshold)
+        self.strategy = {"spatial": _abi.LIGHTS_SPATIAL, "uniform": _abi.LIGHTS_UNIFORM,
+                         "power": _abi.LIGHTS_POWER}.get(lightSampleStrategy, _abi.LIGHTS_SPATIAL)
+
+    def params(self, width, height, spp, spp_begin=0, spp_end=0, shard_index=0, shard_count=1, shard_rows=1,
+               samples_per_pass=0):
+        return RenderParams(width, height, spp, spp_begin, spp_end, self.maxDepth, self.rrThreshold, self.integrator,
+                            self.strategy, shard_index, shard_count, shard_rows, samples_per_pass, 0)
+
+    def Render(self, scene, width, height, spp, **kw):
+        """Integrator::Render: returns (float32 image [H, W, 4], stats dict)."""
+        p = self.params(width, height, spp, **kw)
+        img = np.zeros((height, width, 4), dtype=np.float32)
+        st = Stats()
+        _check(lib().gnxr_render(scene._h, C.byref(p), img.ctypes.data_as(C.POINTER(C.c_float)), C.byref(st)))
+        return img, stats_dict(st)
+
+    def RenderDevice(self, scene, d_ptr, width, height, spp, stream=None, **kw):
+        p = self.params(width, height, spp, **kw)
+        st = Stats()
+        _check(lib().gnxr_render_device(scene._h, C.byref(p), C.c_void_p(int(d_ptr)),
+                                        C.c_void_p(int(stream) if stream else None), C.byref(st)))
+        return stats_dict(st)
+
+
+class VolPathIntegrator(PathIntegrator):
+    integrator = _abi.INTEGRATOR_VOLPATH
+
+
+def sample_halton(width, height, px, py, s, dim):
+    px = np.ascontiguousarray(px, dtype=np.int32)
+    py = np.ascontiguousarray(py, dtype=np.int32)
+    s = np.ascontiguousarray(s, dtype=np.int64)
+    dim = np.ascontiguousarray(dim, dtype=np.int32)
+    out = np.zeros(len(px), dtype=np.float32)
+    _check(lib().gnxr_sample_halton(width, height, px.ctypes.data_as(C.POINTER(C.c_int32)),
+                                    py.ctypes.data_as(C.POINTER(C.c_int32)), s.ctypes.data_as(C.POINTER(C.c_int64)),
+                                    dim.ctypes.data_as(C.POINTER(C.c_int32)), len(px),
+                                    out.ctypes.data_as(C.POINTER(C.c_float))))
+    return out
+
+
+def camera_rays(camera, width, height, px, py, s):
+    px = np.ascontiguousarray(px, dtype=np.int32)
+    py = np.ascontiguousarray(py, dtype=np.int32)
+    s = np.ascontiguousarray(s, dtype=np.int64)
+    o = np.zeros((len(px), 3), dtype=np.float32)
+    d = np.zeros((len(px), 3), dtype=np.float32)
+    _check(lib().gnxr_camera_rays(C.byref(camera), width, height, px.ctypes.data_as(C.POINTER(C.c_int32)),
+                                  py.ctypes.data_as(C.POINTER(C.c_int32)), s.ctypes.data_as(C.POINTER(C.c_int64)),
+                                  len(px), o.ctypes.data_as(C.POINTER(C.c_float)),
+                                  d.ctypes.data_as(C.POINTER(C.c_float))))
+    return o, d
+
+
+def framebuffer_update(running_mean, frame, frame_count):
+    """FrameBuffer::update_f_u_c (ui/FrameBuffer.h:127-149): running mean + 1-exp(-4x) tone map to RGBA8."""
+    h, w = frame.shape[:2]
+    rgba8 = np.zeros((h, w, 4), dtype=np.uint8)
+    _check(lib().gnxr_framebuffer_update(running_mean.ctypes.data_as(C.POINTER(C.c_float)),
+                                         np.ascontiguousarray(frame, dtype=np.float32).ctypes.data_as(C.POINTER(C.c_float)),
+                                         w, h, int(frame_count), rgba8.ctypes.data_as(C.POINTER(C.c_uint8))))
+    return rgba8

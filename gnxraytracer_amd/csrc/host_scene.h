@@ -1,0 +1,78 @@
+// host_scene.h -- host side of libgnxr: scene authoring (mirror of ui/ModelList.cpp and
+// ui/MaterialList.cpp) and the scene compiler that flattens a gnxr_scene_desc into device tables.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/gnxr.h"
+#include "gnxr_device_types.h"
+#include "host_math.h"
+
+namespace gnxr {
+
+void set_error(const char *fmt, ...);
+const char *get_error();
+
+// ---------------- authoring ----------------
+struct Builder {
+    std::vector<float> vertices;   // world space
+    std::vector<int32_t> indices, tri_material, tri_light, tri_med_in, tri_med_out;
+    std::vector<gnxr_material> materials;
+    std::vector<gnxr_light> lights;
+    std::vector<gnxr_medium> media;
+    std::vector<float> grid_density;
+    std::vector<float> env_rgb;
+    int env_w = 0, env_h = 0;
+    gnxr_camera camera;
+    int camera_medium = -1;
+    Builder();
+    int add_mesh(const float *verts, int nv, const int32_t *idx, int nt, const Xf &o2w, int material, int med_in, int med_out);
+    void fill_desc(gnxr_scene_desc *d) const;
+};
+
+bool read_model_3d(const char *path, std::vector<float> *verts, std::vector<int32_t> *idx);  // shape/plyRead.h:19-48
+bool write_synthetic_3d(const char *path, int target_tris, uint32_t seed);
+bool read_rgbe(const char *path, std::vector<float> *rgb, int *w, int *h);  // what stbi_loadf returns for a .hdr
+
+// ---------------- compiled scene (host copies of the device tables) ----------------
+struct CompiledScene {
+    // geometry
+    std::vector<DNode> nodes;
+    std::vector<DTri> tris;              // leaf order
+    std::vector<int32_t> leaf_of_prim;   // authoring index -> leaf index
+    int bvh_max_depth = 0;
+    Box3 world_bound;
+    // shading
+    std::vector<DMaterial> materials;
+    std::vector<DLight> lights;
+    std::vector<int32_t> infinite_lights;
+    // sampler
+    std::vector<uint16_t> perms;
+    std::vector<int32_t> primes, prime_sums;
+    std::vector<uint32_t> prime_magic;   // 2 words per prime: multiplier, shift (exact u32 division)
+    // env light
+    bool has_env = false;
+    DEnv env;
+    std::vector<float> env_texels;       // Lmap level 0, rgb
+    std::vector<float> env_cond_func, env_cond_cdf, env_cond_int;   // Distribution2D conditional rows
+    std::vector<float> env_marg_func, env_marg_cdf;
+    // media
+    std::vector<gnxr_medium> media;
+    std::vector<float> grid_density;
+    // camera description (matrices depend on the render resolution)
+    gnxr_camera camera;
+    int camera_medium = -1;
+    // copy of the description for the light grid builder
+    std::vector<gnxr_light> desc_lights;
+};
+
+bool compile_scene(const gnxr_scene_desc *d, CompiledScene *out);
+DCamera make_camera(const gnxr_camera &c, int W, int H, int medium);      // camera/Perspective.cpp:114-135, core/Camera.h:54-75
+DHalton make_halton(int W, int H);                                          // samplers/HaltonSampler.cpp:33-60
+// light-selection table: dense restatement of core/LightDistribution.cpp (uniform / power / spatial)
+void build_light_grid(const CompiledScene &cs, int strategy, DLightGrid *grid, std::vector<float> *table);
+
+// host restatements used by probes and the light grid
+float host_radical_inverse(const CompiledScene &cs, int baseIndex, uint64_t a);
+
+}  // namespace gnxr

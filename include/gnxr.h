@@ -1,0 +1,295 @@
+/*
+ * gnxr.h -- C ABI of the MI355X wavefront path-tracing core (libgnxr.so).
+ *
+ * This is the drop-in boundary for the reference's render hot path.  The reference
+ * (zhouxuguang/GNXRayTracer) has no FFI of its own; its two seams are C++ virtuals:
+ *
+ *   - Integrator seam : pbr::Integrator::Render(const Scene&, double& timeConsume)
+ *                       core/Integrator.h:17-23, called from ui/RenderThread.cpp:175
+ *   - Aggregate seam  : pbr::Primitive::Intersect / IntersectP
+ *                       core/Primitive.h:13-27, reached via core/Scene.h:32-35
+ *
+ * A live pbr::Scene cannot be flattened from outside (all members private), so the
+ * scene crosses the boundary where it is *authored* (ui/ModelList.cpp, ui/MaterialList.cpp,
+ * ui/RenderThread.cpp:46-187) as plain arrays: gnxr_scene_desc below.
+ *
+ * Conventions: extern "C", plain pointers and sizes, no C++/torch types.  The caller owns
+ * every input and output buffer; the library copies what it needs at gnxr_scene_create and
+ * owns the device memory behind the opaque handle.  Every entry point returns 0 on success
+ * and a negative gnxr_status on failure; gnxr_last_error() returns a thread-local message.
+ * Nothing throws across the boundary (the reference builds with exceptions disabled on
+ * Apple, CMakeLists.txt:252-253).  There is NO CPU fallback: without a HIP device every
+ * compute entry point fails with GNXR_ERR_NO_DEVICE.
+ */
+#ifndef GNXR_H
+#define GNXR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNXR_ABI_VERSION 1
+
+typedef enum gnxr_status {
+    GNXR_OK = 0,
+    GNXR_ERR_INVALID = -1,    /* bad argument / inconsistent description            */
+    GNXR_ERR_NO_DEVICE = -2,  /* no HIP device or HIP runtime error                   */
+    GNXR_ERR_OOM = -3,        /* host or device allocation failed                     */
+    GNXR_ERR_UNSUPPORTED = -4,/* feature present in the description but not built    */
+    GNXR_ERR_IO = -5          /* file could not be read / written                     */
+} gnxr_status;
+
+/* ---- materials: materials/{Matte,Mirror,Glass,Metal,Plastic,Disney}Material.cpp ---- */
+typedef enum gnxr_material_type {
+    GNXR_MAT_NONE = 0,     /* null material: medium boundary, PathIntegrator.cpp:121-126 */
+    GNXR_MAT_MATTE = 1,    /* MatteMaterial.cpp:14-32   (Lambert / OrenNayar)            */
+    GNXR_MAT_MIRROR = 2,   /* MirrorMaterial.cpp:13-24                                   */
+    GNXR_MAT_GLASS = 3,    /* GlassMaterial.cpp:14-61                                    */
+    GNXR_MAT_METAL = 4,    /* MetalMaterial.cpp:28-49                                    */
+    GNXR_MAT_PLASTIC = 5,  /* PlasticMaterial.cpp:15-41                                  */
+    GNXR_MAT_DISNEY = 6    /* DisneyMaterial.cpp:467-581 (BSSRDF branch out of scope)    */
+} gnxr_material_type;
+
+/* All textures on the path are ConstantTexture (textures/ConstantTexture.h:13-23), so a
+ * material is a POD of constants.  Field use per type:
+ *   MATTE  : kd, sigma (degrees)
+ *   MIRROR : kr
+ *   GLASS  : kr, kt, eta[0] (index), urough, vrough, remap_roughness
+ *   METAL  : eta (rgb), k (rgb), urough, vrough, remap_roughness
+ *   PLASTIC: kd, ks, urough (roughness), remap_roughness
+ *   DISNEY : kd (color), eta[0], and the disney_* block (DisneyMaterial.h:21-36)
+ * bump: every reference material carries a non-null ConstantTexture<float>(0) bump map
+ * (ui/RenderThread.cpp:90, ui/MaterialList.cpp:44,54,67,80) so Material::Bump
+ * (core/Material.cpp:16-52) runs on every hit; has_bump=1 reproduces that.            */
+typedef struct gnxr_material {
+    int32_t type;
+    int32_t has_bump;
+    int32_t remap_roughness;
+    int32_t disney_thin;
+    float kd[3];
+    float ks[3];
+    float kr[3];
+    float kt[3];
+    float eta[3];
+    float k[3];
+    float sigma;
+    float urough;
+    float vrough;
+    float disney_metallic;
+    float disney_spec_trans;
+    float disney_spec_tint;
+    float disney_sheen;
+    float disney_sheen_tint;
+    float disney_clearcoat;
+    float disney_clearcoat_gloss;
+    float disney_anisotropic;
+    float disney_roughness;
+    float disney_flatness;
+    float disney_diff_trans;
+    float disney_scatter_distance[3];
+    float _pad[1];
+} gnxr_material;
+
+/* ---- lights: lights/{DiffuseAreaLight,InfiniteAreaLight,SkyBoxLight}.cpp ---------- */
+typedef enum gnxr_light_type {
+    GNXR_LIGHT_AREA_TRI = 1, /* one DiffuseAreaLight per emissive triangle, ModelList.cpp:140-146 */
+    GNXR_LIGHT_INFINITE = 2, /* InfiniteAreaLight.cpp:12-132, uses desc.env_*                    */
+    GNXR_LIGHT_SKYBOX = 3    /* SkyBoxLight.cpp:43-85 with a failed image load (gradient)        */
+} gnxr_light_type;
+
+typedef struct gnxr_light {
+    int32_t type;
+    int32_t tri;        /* AREA_TRI: index into desc triangles (authoring order)          */
+    int32_t two_sided;  /* kept for fidelity; has no effect (DiffuseAreaLight.h:24 quirk) */
+    int32_t _pad;
+    float le[3];        /* AREA_TRI: Lemit ; INFINITE: power scale L                      */
+    float radius;       /* SKYBOX: sphere radius                                          */
+    float center[3];    /* SKYBOX: sphere centre                                          */
+    float _pad2;
+    float light_to_world[16]; /* INFINITE: row-major 4x4 (LightToWorld, ModelList.cpp:174) */
+} gnxr_light;
+
+/* ---- camera: camera/Perspective.cpp:114-135 (fov 90, lens 0 in the reference) ------ */
+typedef struct gnxr_camera {
+    float eye[3];
+    float look[3];
+    float up[3];
+    float fov_deg;
+    float lens_radius;
+    float focal_distance;
+} gnxr_camera;
+
+/* ---- media: media/{Homogeneous,GridDensity}Medium.cpp (VolPath, config 5) ---------- */
+typedef enum gnxr_medium_type { GNXR_MEDIUM_HOMOGENEOUS = 1, GNXR_MEDIUM_GRID = 2 } gnxr_medium_type;
+
+typedef struct gnxr_medium {
+    int32_t type;
+    int32_t nx, ny, nz;        /* GRID: density grid resolution                            */
+    float sigma_a[3];
+    float sigma_s[3];
+    float g;
+    float _pad;
+    float medium_to_world[16]; /* GRID: row-major 4x4                                      */
+    int64_t density_offset;    /* GRID: first float of this grid in desc.grid_density      */
+} gnxr_medium;
+
+/* ---- scene description: what ModelList.cpp / RenderThread.cpp author --------------- */
+typedef struct gnxr_scene_desc {
+    int32_t abi_version;        /* GNXR_ABI_VERSION */
+    int32_t n_vertices;
+    int32_t n_triangles;
+    int32_t n_materials;
+    int32_t n_lights;
+    int32_t n_media;
+    int32_t env_width;          /* INFINITE light: lat-long radiance map (RGB fp32), 0 if none */
+    int32_t env_height;
+    const float *vertices;      /* n_vertices * 3, WORLD space (TriangleMesh ctor, Triangle.cpp:27-31) */
+    const int32_t *indices;     /* n_triangles * 3; triangle order == reference prims order  */
+    const int32_t *tri_material;/* n_triangles; index into materials, -1 == null material    */
+    const int32_t *tri_light;   /* n_triangles; index into lights (AREA_TRI) or -1           */
+    const int32_t *tri_medium_inside;  /* n_triangles or NULL; -1 == none (MediumInterface)  */
+    const int32_t *tri_medium_outside; /* n_triangles or NULL                                */
+    const gnxr_material *materials;
+    const gnxr_light *lights;   /* order == scene.lights order (light selection index)       */
+    const gnxr_medium *media;
+    const float *grid_density;
+    const float *env_rgb;       /* env_width*env_height*3, row-major, as decoded from .hdr   */
+    gnxr_camera camera;
+    int32_t camera_medium;      /* medium the camera sits in, -1 == none                     */
+    int32_t _pad;
+} gnxr_scene_desc;
+
+typedef enum gnxr_integrator {
+    GNXR_INTEGRATOR_PATH = 0,    /* integrators/PathIntegrator.cpp:62-208   */
+    GNXR_INTEGRATOR_VOLPATH = 1, /* integrators/VolPathIntegrator.cpp:24-159 */
+    GNXR_INTEGRATOR_WHITTED = 2  /* integrators/WhittedIntegrator.cpp:14-68 */
+} gnxr_integrator;
+
+typedef enum gnxr_light_strategy {
+    GNXR_LIGHTS_SPATIAL = 0, /* core/LightDistribution.cpp:70-274 */
+    GNXR_LIGHTS_UNIFORM = 1,
+    GNXR_LIGHTS_POWER = 2
+} gnxr_light_strategy;
+
+/* Render parameters.  A render covers samples [spp_begin, spp_end) of a HaltonSampler(spp)
+ * (samplers/HaltonSampler.cpp:33-60) for the image rows this shard owns:
+ * row y belongs to the shard iff (y / shard_rows) % shard_count == shard_index.
+ * shard_count=1 renders the whole image.                                                  */
+typedef struct gnxr_render_params {
+    int32_t width, height;
+    int32_t spp;                /* HaltonSampler samplesPerPixel; divisor of the box average */
+    int32_t spp_begin, spp_end; /* sample range rendered by this call; 0,spp == all          */
+    int32_t max_depth;          /* PathIntegrator maxDepth                                   */
+    float rr_threshold;         /* PathIntegrator rrThreshold                                */
+    int32_t integrator;         /* gnxr_integrator                                           */
+    int32_t light_strategy;     /* gnxr_light_strategy                                       */
+    int32_t shard_index, shard_count, shard_rows;
+    int32_t samples_per_pass;   /* 0 = auto; samples of one pixel in flight per pass         */
+    int32_t _pad;
+} gnxr_render_params;
+
+typedef struct gnxr_stats {
+    uint64_t rays_closest;      /* Scene::Intersect calls  (core/Scene.cpp:11-17)            */
+    uint64_t rays_any;          /* Scene::IntersectP calls (core/Scene.cpp:19-24)            */
+    uint64_t camera_samples;
+    uint64_t nodes_visited;     /* filled only when GNXR_STATS_TRAVERSAL is requested        */
+    uint64_t tris_tested;
+    double seconds_render;      /* kernel pipeline, excludes scene build/upload              */
+    double seconds_trace;       /* sum of HIP-event time of the traversal kernels            */
+    double seconds_total;
+    uint32_t kernel_launches;
+    uint32_t passes;
+} gnxr_stats;
+
+typedef struct gnxr_ray { float o[3]; float tmax; float d[3]; float _pad; } gnxr_ray;
+typedef struct gnxr_hit {
+    int32_t prim;               /* triangle index (authoring order) or -1                    */
+    float t, b0, b1, b2;
+    float n[3];                 /* geometric normal as set by Triangle::Intersect            */
+} gnxr_hit;
+
+typedef struct gnxr_scene gnxr_scene;
+
+/* -- lifecycle ---------------------------------------------------------------------- */
+int gnxr_abi_version(void);
+int gnxr_init(int device_id);          /* binds the calling process to one HIP device    */
+void gnxr_shutdown(void);
+const char *gnxr_last_error(void);
+
+/* -- scene (replaces `Scene(make_shared<BVHAccel>(prims,1), lights)`, RenderThread.cpp:155) */
+int gnxr_scene_create(const gnxr_scene_desc *desc, gnxr_scene **out);
+void gnxr_scene_destroy(gnxr_scene *scene);
+int gnxr_scene_info(const gnxr_scene *scene, int32_t *n_bvh_nodes, int32_t *bvh_max_depth,
+                    int32_t *n_light_voxels);
+
+/* -- Integrator seam (replaces integrator->Render(*worldScene, frameTime), RenderThread.cpp:175).
+ * rgba_out: width*height*4 fp32, row-major, pixel (x,y) at (x + y*width)*4, the layout of
+ * FrameBuffer::fbuffer (ui/FrameBuffer.h:136); A is written as 1.  With shard_count>1 only
+ * the shard's rows are written.                                                          */
+int gnxr_render(gnxr_scene *scene, const gnxr_render_params *params, float *rgba_out,
+                gnxr_stats *stats);
+/* Same, output stays in device memory (d_rgba_out is a HIP device pointer, e.g. the data_ptr
+ * of a torch tensor) and the work is enqueued on `hip_stream` (a hipStream_t, may be NULL). */
+int gnxr_render_device(gnxr_scene *scene, const gnxr_render_params *params, void *d_rgba_out,
+                       void *hip_stream, gnxr_stats *stats);
+
+/* -- Aggregate seam (replaces Scene::Intersect / Scene::IntersectP), batched ------------ */
+int gnxr_trace_closest(gnxr_scene *scene, const gnxr_ray *rays, int64_t n, gnxr_hit *hits);
+int gnxr_trace_any(gnxr_scene *scene, const gnxr_ray *rays, int64_t n, uint8_t *occluded);
+
+/* -- sampler / camera probes (bit-exactness test hooks) --------------------------------- */
+/* HaltonSampler(spp, [0,width)x[0,height)) value of dimension dim[i] for sample s[i] of pixel
+ * (px[i],py[i]) -- GetIndexForSample + SampleDimension, HaltonSampler.cpp:63-94.            */
+int gnxr_sample_halton(int32_t width, int32_t height, const int32_t *px, const int32_t *py,
+                       const int64_t *s, const int32_t *dim, int64_t n, float *out);
+/* Camera rays (Perspective.cpp:62-112 + Integrator.cpp:277-283): for sample s of pixel (px,py)
+ * writes origin[3], direction[3] per ray.                                                    */
+int gnxr_camera_rays(const gnxr_camera *cam, int32_t width, int32_t height, const int32_t *px,
+                     const int32_t *py, const int64_t *s, int64_t n, float *o_out, float *d_out);
+
+/* -- output stage (FrameBuffer::update_f_u_c, ui/FrameBuffer.h:127-149) ------------------ */
+/* Folds one Render() result into the running mean of `frame_count` previous frames and
+ * tone-maps 1-exp(-x/0.25) to RGBA8 (A=255).  Device-side; host pointers in and out.        */
+int gnxr_framebuffer_update(float *running_mean_rgba, const float *frame_rgba, int32_t width,
+                            int32_t height, int32_t frame_count, uint8_t *rgba8_out);
+
+/* -- host-side scene authoring (mirror of ui/ModelList.cpp, ui/MaterialList.cpp) -------- */
+typedef struct gnxr_builder gnxr_builder;
+int gnxr_builder_create(gnxr_builder **out);
+void gnxr_builder_destroy(gnxr_builder *b);
+/* material factories return a material index */
+int gnxr_builder_add_material(gnxr_builder *b, const gnxr_material *m);
+int gnxr_builder_matte(gnxr_builder *b, const float kd[3], float sigma_deg);          /* RenderThread.cpp:79-99 */
+int gnxr_builder_mirror(gnxr_builder *b, const float kr[3]);                          /* RenderThread.cpp:102   */
+int gnxr_builder_purple_plastic(gnxr_builder *b);                                     /* MaterialList.cpp:48-56 */
+int gnxr_builder_yellow_metal(gnxr_builder *b);                                       /* MaterialList.cpp:58-69 */
+int gnxr_builder_white_glass(gnxr_builder *b);                                        /* MaterialList.cpp:71-83 */
+/* geometry: each returns the index of the first triangle added, or <0 */
+int gnxr_builder_add_mesh(gnxr_builder *b, const float *vertices, int32_t n_vertices,
+                          const int32_t *indices, int32_t n_triangles, const float *object_to_world16,
+                          int32_t material, int32_t medium_inside, int32_t medium_outside);
+int gnxr_builder_add_model_3d(gnxr_builder *b, const char *path, int32_t material);   /* ModelList.cpp:47-69, plyRead.h:19-48 */
+int gnxr_builder_add_cornell(gnxr_builder *b, int32_t material1, int32_t material2,
+                             int32_t material3);                                      /* ModelList.cpp:71-118 */
+int gnxr_builder_add_floor(gnxr_builder *b, int32_t material);                        /* ModelList.cpp:20-45  */
+int gnxr_builder_add_area_light(gnxr_builder *b, int32_t material);                   /* ModelList.cpp:120-147 */
+int gnxr_builder_add_sky_light(gnxr_builder *b);                                      /* ModelList.cpp:163-170 */
+int gnxr_builder_add_inf_light(gnxr_builder *b, const char *hdr_path);                /* ModelList.cpp:172-179 */
+int gnxr_builder_add_inf_light_data(gnxr_builder *b, const float *rgb, int32_t w, int32_t h,
+                                    const float *light_to_world16, const float power[3]);
+int gnxr_builder_add_medium(gnxr_builder *b, const gnxr_medium *m, const float *density);
+int gnxr_builder_set_camera(gnxr_builder *b, const gnxr_camera *cam);                 /* RenderThread.cpp:60-68 */
+/* The returned description points into builder-owned memory, valid until the next builder
+ * call or gnxr_builder_destroy.                                                            */
+int gnxr_builder_desc(gnxr_builder *b, gnxr_scene_desc *out);
+
+/* Deterministic synthetic stand-in for the absent Resources/dragon.3d (.MISSING_LARGE_BLOBS:1):
+ * writes a `.3d` text file in the format plyRead.h:19-48 parses.                           */
+int gnxr_write_synthetic_3d(const char *path, int32_t target_triangles, uint32_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNXR_H */

@@ -1,0 +1,241 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see o_math.h header).
+//
+// o_envlight.h: CPU restatement of the infinite lights:
+//   InfiniteAreaLight ctor / Le / Sample_Li / Pdf_Li / Power   lights/InfiniteAreaLight.cpp:12-132
+//   MIPMap ctor (Lanczos resample to pow2, pyramid) / Lookup / triangle / Texel   core/MIPMap.h:41-256
+//   Lanczos                                                    core/Texture.cpp:152-161
+//   SkyBoxLight::Le / Sample_Li (image load failed)            lights/SkyBoxLight.cpp:43-85
+#pragma once
+#include "o_scene.h"
+
+namespace gnxo {
+
+inline Float Lanczos(Float x, Float tau = 2) {
+    x = std::abs(x);
+    if (x < 1e-5f) return 1;
+    if (x > 1.f) return 0;
+    x *= Pi;
+    Float s = std::sin(x * tau) / (x * tau);
+    Float lanczos = std::sin(x) / x;
+    return s * lanczos;
+}
+inline bool IsPowerOf2(int v) { return v && !(v & (v - 1)); }
+inline int RoundUpPow2(int v) { v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1; }
+inline int Log2Int(uint32_t v) { return 31 - __builtin_clz(v); }
+inline Float Log2(Float x) { const Float invLog2 = 1.442695040888963387004650940071; return std::log(x) * invLog2; }
+inline int ModI(int a, int b) { int r = a - (a / b) * b; return (r < 0) ? r + b : r; }
+
+// MIPMap<RGBSpectrum> with doTrilinear=false, wrapMode=Repeat (the only instantiation on the path)
+struct MIPMapRGB {
+    int resX = 0, resY = 0;
+    std::vector<std::vector<Spec>> pyramid;
+    std::vector<int> lw, lh;
+    struct ResampleWeight { int firstTexel; Float weight[4]; };
+    static std::vector<ResampleWeight> resampleWeights(int oldRes, int newRes) {
+        std::vector<ResampleWeight> wt(newRes);
+        Float filterwidth = 2.f;
+        for (int i = 0; i < newRes; ++i) {
+            Float center = (i + .5f) * oldRes / newRes;
+            wt[i].firstTexel = std::floor((center - filterwidth) + 0.5f);
+            for (int j = 0; j < 4; ++j) {
+                Float pos = wt[i].firstTexel + j + .5f;
+                wt[i].weight[j] = Lanczos((pos - center) / filterwidth);
+            }
+            Float invSumWts = 1 / (wt[i].weight[0] + wt[i].weight[1] + wt[i].weight[2] + wt[i].weight[3]);
+            for (int j = 0; j < 4; ++j) wt[i].weight[j] *= invSumWts;
+        }
+        return wt;
+    }
+    void Build(int rx, int ry, const Spec *img) {
+        resX = rx; resY = ry;
+        std::vector<Spec> resampled;
+        if (!IsPowerOf2(resX) || !IsPowerOf2(resY)) {
+            int px = RoundUpPow2(resX), py = RoundUpPow2(resY);
+            std::vector<ResampleWeight> sWeights = resampleWeights(resX, px);
+            resampled.assign((size_t)px * py, Spec(0.f));
+            for (int64_t t = 0; t < resY; ++t)
+                for (int s = 0; s < px; ++s) {
+                    resampled[t * px + s] = Spec(0.f);
+                    for (int j = 0; j < 4; ++j) {
+                        int origS = sWeights[s].firstTexel + j;
+                        origS = ModI(origS, resX);
+                        if (origS >= 0 && origS < resX) resampled[t * px + s] += sWeights[s].weight[j] * img[t * resX + origS];
+                    }
+                }
+            std::vector<ResampleWeight> tWeights = resampleWeights(resY, py);
+            std::vector<Spec> workData(py);
+            for (int64_t s = 0; s < px; ++s) {
+                for (int t = 0; t < py; ++t) {
+                    workData[t] = Spec(0.f);
+                    for (int j = 0; j < 4; ++j) {
+                        int offset = tWeights[t].firstTexel + j;
+                        offset = ModI(offset, resY);
+                        if (offset >= 0 && offset < resY) workData[t] += tWeights[t].weight[j] * resampled[offset * px + s];
+                    }
+                }
+                for (int t = 0; t < py; ++t) resampled[t * px + s] = workData[t].Clamp(0.f, Infinity);
+            }
+            resX = px; resY = py;
+        }
+        int nLevels = 1 + Log2Int(std::max(resX, resY));
+        pyramid.resize(nLevels); lw.resize(nLevels); lh.resize(nLevels);
+        lw[0] = resX; lh[0] = resY;
+        if (!resampled.empty()) pyramid[0] = resampled;
+        else pyramid[0].assign(img, img + (size_t)resX * resY);
+        for (int i = 1; i < nLevels; ++i) {
+            int sRes = std::max(1, lw[i - 1] / 2), tRes = std::max(1, lh[i - 1] / 2);
+            lw[i] = sRes; lh[i] = tRes;
+            pyramid[i].resize((size_t)sRes * tRes);
+            for (int t = 0; t < tRes; t++)
+                for (int s = 0; s < sRes; ++s)
+                    pyramid[i][t * sRes + s] = .25f * (Texel(i - 1, 2 * s, 2 * t) + Texel(i - 1, 2 * s + 1, 2 * t) +
+                                                       Texel(i - 1, 2 * s, 2 * t + 1) + Texel(i - 1, 2 * s + 1, 2 * t + 1));
+        }
+    }
+    int Levels() const { return (int)pyramid.size(); }
+    const Spec &Texel(int level, int s, int t) const {
+        s = ModI(s, lw[level]); t = ModI(t, lh[level]);
+        return pyramid[level][(size_t)t * lw[level] + s];
+    }
+    Spec triangle(int level, const P2 &st) const {
+        level = Clamp(level, 0, Levels() - 1);
+        Float s = st.x * lw[level] - 0.5f;
+        Float t = st.y * lh[level] - 0.5f;
+        int s0 = std::floor(s), t0 = std::floor(t);
+        Float ds = s - s0, dt = t - t0;
+        return (1 - ds) * (1 - dt) * Texel(level, s0, t0) + (1 - ds) * dt * Texel(level, s0, t0 + 1) +
+               ds * (1 - dt) * Texel(level, s0 + 1, t0) + ds * dt * Texel(level, s0 + 1, t0 + 1);
+    }
+    Spec Lookup(const P2 &st, Float width = 0.f) const {
+        Float level = Levels() - 1 + Log2(std::max(width, (Float)1e-8));
+        if (level < 0) return triangle(0, st);
+        else if (level >= Levels() - 1) return Texel(Levels() - 1, 0, 0);
+        else {
+            int iLevel = std::floor(level);
+            Float delta = level - iLevel;
+            return Lerp(delta, triangle(iLevel, st), triangle(iLevel + 1, st));
+        }
+    }
+};
+
+}  // namespace gnxo
+
+#include "o_lightsample.h"
+
+namespace gnxo {
+
+struct InfiniteAreaLight {
+    M44 lightToWorld, worldToLight;
+    MIPMapRGB Lmap;
+    Distribution2D distribution;
+    V3 worldCenter;
+    Float worldRadius = 0;
+    // InfiniteAreaLight.cpp:12-82.  env_rgb is the decoded .hdr (what stbi_loadf returns); texels =
+    // (L*rgb)^1.5 (`r * Sqrt(r)`, :41).
+    InfiniteAreaLight(const gnxr_light &l, const float *rgb, int w, int h) {
+        lightToWorld = M44::FromRowMajor(l.light_to_world);
+        worldToLight = Inverse(lightToWorld);
+        std::vector<Spec> texels;
+        int rx = w, ry = h;
+        if (rgb && w > 0 && h > 0) {
+            texels.resize((size_t)w * h);
+            for (int j = 0; j < h; j++)
+                for (int i = 0; i < w; i++) {
+                    Spec r;
+                    r[0] = l.le[0] * rgb[(i + j * w) * 3 + 0];
+                    r[1] = l.le[1] * rgb[(i + j * w) * 3 + 1];
+                    r[2] = l.le[2] * rgb[(i + j * w) * 3 + 2];
+                    texels[i + j * w] = r * Sqrt(r);
+                }
+        } else {
+            rx = ry = 1;
+            texels.assign(1, Spec(l.le[0], l.le[1], l.le[2]));
+        }
+        Lmap.Build(rx, ry, texels.data());
+        int width = 2 * Lmap.resX, height = 2 * Lmap.resY;
+        std::vector<Float> img((size_t)width * height);
+        float fwidth = 0.5f / std::min(width, height);
+        for (int v = 0; v < height; v++) {
+            Float vp = (v + .5f) / (Float)height;
+            Float sinTheta = std::sin(Pi * (v + .5f) / height);
+            for (int u = 0; u < width; ++u) {
+                Float up = (u + .5f) / (Float)width;
+                img[u + v * width] = Lmap.Lookup(P2(up, vp), fwidth).y();
+                img[u + v * width] *= sinTheta;
+            }
+        }
+        distribution = Distribution2D(img.data(), width, height);
+    }
+    // InfiniteAreaLight.h:23-26, Geometry.h:770-773
+    void Preprocess(const Bounds3 &wb) {
+        worldCenter = (wb.pMin + wb.pMax) / 2;
+        bool inside = worldCenter.x >= wb.pMin.x && worldCenter.x <= wb.pMax.x && worldCenter.y >= wb.pMin.y &&
+                      worldCenter.y <= wb.pMax.y && worldCenter.z >= wb.pMin.z && worldCenter.z <= wb.pMax.z;
+        worldRadius = inside ? (worldCenter - wb.pMax).Length() : 0;
+    }
+    Spec Power() const { return Pi * worldRadius * worldRadius * Lmap.Lookup(P2(.5f, .5f), .5f); }
+    Spec Le(const Ray &ray) const {
+        V3 w = Normalize(XVector(worldToLight, ray.d));
+        P2 st(SphericalPhi(w) * Inv2Pi, SphericalTheta(w) * InvPi);
+        return Lmap.Lookup(st);
+    }
+    LightSample Sample_Li(const Interaction &ref, const P2 &u) const {
+        LightSample s;
+        Float mapPdf;
+        P2 uv = distribution.SampleContinuous(u, &mapPdf);
+        if (mapPdf == 0) { s.Li = Spec(0.f); s.pdf = 0; return s; }  // *pdf left untouched (0) in the reference
+        Float theta = uv.y * Pi, phi = uv.x * 2 * Pi;
+        Float cosTheta = std::cos(theta), sinTheta = std::sin(theta);
+        Float sinPhi = std::sin(phi), cosPhi = std::cos(phi);
+        s.wi = XVector(lightToWorld, V3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta));
+        s.pdf = mapPdf / (2 * Pi * Pi * sinTheta);
+        if (sinTheta == 0) s.pdf = 0;
+        s.p1 = Interaction();
+        s.p1.p = ref.p + s.wi * (2 * worldRadius);
+        s.Li = Lmap.Lookup(uv);
+        return s;
+    }
+    Float Pdf_Li(const Interaction &, const V3 &w) const {
+        V3 wi = XVector(worldToLight, w);
+        Float theta = SphericalTheta(wi), phi = SphericalPhi(wi);
+        Float sinTheta = std::sin(theta);
+        if (sinTheta == 0) return 0;
+        return distribution.Pdf(P2(phi * Inv2Pi, theta * InvPi)) / (2 * Pi * Pi * sinTheta);
+    }
+};
+
+// SkyBoxLight::Le with data == nullptr, SkyBoxLight.cpp:55-85.  The double/float mix follows the source.
+inline Spec SkyBoxLe(const gnxr_light &l, const Ray &ray) {
+    V3 worldCenter(l.center[0], l.center[1], l.center[2]);
+    float worldRadius = l.radius;
+    V3 oc = ray.o - worldCenter;
+    float a = Dot(ray.d, ray.d);
+    float b = 2.0 * Dot(oc, ray.d);
+    float c = Dot(oc, oc) - worldRadius * worldRadius;
+    float discriminant = b * b - 4 * a * c;
+    float t;
+    if (discriminant < 0) return Spec(0.f);
+    t = (-b + ::sqrt((double)discriminant)) / (2.0 * a);  // unqualified sqrt -> double
+    V3 hitPos = ray.o + t * ray.d;
+    V3 hitPos_temp = hitPos - worldCenter;
+    Spec Col;
+    Col[0] = (hitPos_temp.x + worldRadius) / (2.f * worldRadius);
+    Col[1] = (hitPos_temp.y + worldRadius) / (2.f * worldRadius);
+    Col[2] = (hitPos_temp.z + worldRadius) / (2.f * worldRadius);
+    return Col;
+}
+// SkyBoxLight::Sample_Li, SkyBoxLight.cpp:43-53 (no image: value 0, pdf 1/4pi; LightToWorld = identity)
+inline LightSample SkyBoxSample_Li(const gnxr_light &l, const Interaction &ref, const P2 &u) {
+    LightSample s;
+    float theta = u.y * Pi, phi = u.x * 2 * Pi;
+    float cosTheta = std::cos(theta), sinTheta = std::sin(theta);
+    float sinPhi = std::sin(phi), cosPhi = std::cos(phi);
+    s.wi = V3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
+    s.pdf = 1.f / (4 * Pi);
+    s.p1 = Interaction();
+    s.p1.p = ref.p + s.wi * (2 * l.radius);
+    s.Li = Spec(0.f);
+    return s;
+}
+
+}  // namespace gnxo

@@ -1,0 +1,505 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see o_math.h header).
+//
+// o_scene.h: CPU restatement of the geometric side of the hot path:
+//   BVHAccel build (SAH) / flatten / Intersect / IntersectP   accelerator/BVHAccel.cpp:147-189,201-367,628-729
+//   Triangle::Intersect / IntersectP / Sample / Area           shape/Triangle.cpp:71-303,305-453,455-492
+//   GeometricPrimitive::Intersect                              core/Primitive.cpp:32-46
+//   SurfaceInteraction ctor / SetShadingGeometry               core/Interaction.cpp:8-54
+//   Interaction::SpawnRay / SpawnRayTo                         core/Interaction.h:33-53
+//   Shape::Sample(ref,u,pdf) / Pdf(ref,wi)                     core/Shape.cpp:21-53
+//   PerspectiveCamera::GenerateRayDifferential                 camera/Perspective.cpp:62-135
+#pragma once
+#include <atomic>
+#include <vector>
+
+#include "../include/gnxr.h"
+#include "o_sampler.h"
+
+namespace gnxo {
+
+// What the integrators need from Interaction / SurfaceInteraction (core/Interaction.h).
+struct Interaction {
+    V3 p, pError, wo, n;
+    int mediumInside = -1, mediumOutside = -1;  // MediumInterface
+    bool IsSurfaceInteraction() const { return n != V3(); }
+    int GetMedium(const V3 &w) const { return Dot(w, n) > 0 ? mediumOutside : mediumInside; }
+    // Interaction.h:33-37
+    Ray SpawnRay(const V3 &d) const {
+        V3 o = OffsetRayOrigin(p, pError, n, d);
+        return Ray(o, d, Infinity, GetMedium(d));
+    }
+    // Interaction.h:39-44
+    Ray SpawnRayTo(const V3 &p2) const {
+        V3 origin = OffsetRayOrigin(p, pError, n, p2 - p);
+        V3 d = p2 - p;
+        return Ray(origin, d, 1 - ShadowEpsilon, GetMedium(d));
+    }
+    // Interaction.h:46-53
+    Ray SpawnRayTo(const Interaction &it) const {
+        V3 origin = OffsetRayOrigin(p, pError, n, it.p - p);
+        V3 target = OffsetRayOrigin(it.p, it.pError, it.n, origin - it.p);
+        V3 d = target - origin;
+        return Ray(origin, d, 1 - ShadowEpsilon, GetMedium(d));
+    }
+};
+
+struct SurfaceInteraction : Interaction {
+    P2 uv;
+    V3 dpdu, dpdv;
+    V3 sn, sdpdu, sdpdv;  // shading.n / dpdu / dpdv
+    int prim = -1;         // triangle index in AUTHORING order (desc order)
+    Float b0 = 0, b1 = 0, b2 = 0, t = 0;
+    // Interaction.cpp:36-54 (dndu/dndv are zero on this path)
+    void SetShadingGeometry(const V3 &dpdus, const V3 &dpdvs, bool orientationIsAuthoritative) {
+        sn = Normalize(Cross(dpdus, dpdvs));
+        if (orientationIsAuthoritative) n = Faceforward(n, sn);
+        else sn = Faceforward(sn, n);
+        sdpdu = dpdus;
+        sdpdv = dpdvs;
+    }
+};
+
+struct LinearBVHNode {  // BVHAccel.cpp:54-65
+    Bounds3 bounds;
+    int offset;  // primitivesOffset (leaf) / secondChildOffset (interior)
+    uint16_t nPrimitives;
+    uint8_t axis;
+    uint8_t pad;
+};
+
+struct TraversalCounters {
+    std::atomic<uint64_t> nIntersect{0}, nIntersectP{0}, nNodes{0}, nTris{0};
+};
+
+struct Scene {
+    std::vector<V3> verts;
+    std::vector<int> indices;      // authoring order
+    std::vector<int> triMaterial, triLight, triMedIn, triMedOut;
+    std::vector<gnxr_material> materials;
+    std::vector<gnxr_light> lights;
+    std::vector<gnxr_medium> media;
+    std::vector<float> gridDensity;
+    std::vector<float> envRgb;
+    int envW = 0, envH = 0;
+    gnxr_camera camera;
+    int cameraMedium = -1;
+    // BVH
+    std::vector<LinearBVHNode> nodes;
+    std::vector<int> orderedPrims;  // BVH leaf order -> authoring index (primitives.swap(orderedPrims), BVHAccel.cpp:171)
+    int bvhMaxDepth = 0;
+    mutable TraversalCounters counters;
+    bool countTraversal = false;
+
+    int nTriangles() const { return (int)indices.size() / 3; }
+    void Tri(int i, V3 *p0, V3 *p1, V3 *p2) const {
+        *p0 = verts[indices[3 * i]]; *p1 = verts[indices[3 * i + 1]]; *p2 = verts[indices[3 * i + 2]];
+    }
+    Bounds3 TriBound(int i) const {  // Triangle::WorldBound, Triangle.cpp:62-69
+        V3 p0, p1, p2; Tri(i, &p0, &p1, &p2);
+        return Union(Bounds3(p0, p1), p2);
+    }
+    Bounds3 WorldBound() const { return nodes.empty() ? Bounds3() : nodes[0].bounds; }
+
+    void Load(const gnxr_scene_desc *d) {
+        verts.resize(d->n_vertices);
+        for (int i = 0; i < d->n_vertices; ++i) verts[i] = V3(d->vertices[3 * i], d->vertices[3 * i + 1], d->vertices[3 * i + 2]);
+        indices.assign(d->indices, d->indices + 3 * (size_t)d->n_triangles);
+        triMaterial.assign(d->tri_material, d->tri_material + d->n_triangles);
+        triLight.assign(d->tri_light, d->tri_light + d->n_triangles);
+        if (d->tri_medium_inside) triMedIn.assign(d->tri_medium_inside, d->tri_medium_inside + d->n_triangles);
+        else triMedIn.assign(d->n_triangles, -1);
+        if (d->tri_medium_outside) triMedOut.assign(d->tri_medium_outside, d->tri_medium_outside + d->n_triangles);
+        else triMedOut.assign(d->n_triangles, -1);
+        materials.assign(d->materials, d->materials + d->n_materials);
+        lights.assign(d->lights, d->lights + d->n_lights);
+        if (d->n_media) media.assign(d->media, d->media + d->n_media);
+        if (d->grid_density && d->n_media) {
+            int64_t total = 0;
+            for (auto &m : media) if (m.type == GNXR_MEDIUM_GRID) total = std::max<int64_t>(total, m.density_offset + (int64_t)m.nx * m.ny * m.nz);
+            gridDensity.assign(d->grid_density, d->grid_density + total);
+        }
+        envW = d->env_width; envH = d->env_height;
+        if (envW && envH) envRgb.assign(d->env_rgb, d->env_rgb + (size_t)envW * envH * 3);
+        camera = d->camera;
+        cameraMedium = d->camera_medium;
+        BuildBVH();
+    }
+
+    // ---------------- BVH build: BVHAccel.cpp:147-189, 201-367 (SAH, maxPrimsInNode = 1) -----------
+    struct PrimInfo { size_t primitiveNumber; Bounds3 bounds; V3 centroid; };
+    struct BuildNode { Bounds3 bounds; BuildNode *children[2]; int splitAxis, firstPrimOffset, nPrimitives; };
+    std::vector<BuildNode *> buildPool;
+    BuildNode *NewNode() { buildPool.push_back(new BuildNode()); return buildPool.back(); }
+
+    BuildNode *recursiveBuild(std::vector<PrimInfo> &primitiveInfo, int start, int end, int *totalNodes) {
+        const int maxPrimsInNode = 1;
+        BuildNode *node = NewNode();
+        (*totalNodes)++;
+        Bounds3 bounds;
+        for (int i = start; i < end; ++i) bounds = Union(bounds, primitiveInfo[i].bounds);
+        int nPrimitives = end - start;
+        auto makeLeaf = [&]() {
+            int firstPrimOffset = (int)orderedPrims.size();
+            for (int i = start; i < end; ++i) orderedPrims.push_back((int)primitiveInfo[i].primitiveNumber);
+            node->firstPrimOffset = firstPrimOffset; node->nPrimitives = nPrimitives; node->bounds = bounds;
+            node->children[0] = node->children[1] = nullptr;
+            return node;
+        };
+        if (nPrimitives == 1) return makeLeaf();
+        Bounds3 centroidBounds;
+        for (int i = start; i < end; ++i) centroidBounds = Union(centroidBounds, primitiveInfo[i].centroid);
+        int dim = centroidBounds.MaximumExtent();
+        int mid = (start + end) / 2;
+        if (centroidBounds.pMax[dim] == centroidBounds.pMin[dim]) return makeLeaf();
+        if (nPrimitives <= 2) {
+            mid = (start + end) / 2;
+            std::nth_element(&primitiveInfo[start], &primitiveInfo[mid], &primitiveInfo[end - 1] + 1,
+                             [dim](const PrimInfo &a, const PrimInfo &b) { return a.centroid[dim] < b.centroid[dim]; });
+        } else {
+            constexpr int nBuckets = 12;
+            struct BucketInfo { int count = 0; Bounds3 bounds; };
+            BucketInfo buckets[nBuckets];
+            for (int i = start; i < end; ++i) {
+                int b = nBuckets * centroidBounds.Offset(primitiveInfo[i].centroid)[dim];
+                if (b == nBuckets) b = nBuckets - 1;
+                buckets[b].count++;
+                buckets[b].bounds = Union(buckets[b].bounds, primitiveInfo[i].bounds);
+            }
+            Float cost[nBuckets - 1];
+            for (int i = 0; i < nBuckets - 1; ++i) {
+                Bounds3 b0, b1;
+                int count0 = 0, count1 = 0;
+                for (int j = 0; j <= i; ++j) { b0 = Union(b0, buckets[j].bounds); count0 += buckets[j].count; }
+                for (int j = i + 1; j < nBuckets; ++j) { b1 = Union(b1, buckets[j].bounds); count1 += buckets[j].count; }
+                cost[i] = 1 + (count0 * b0.SurfaceArea() + count1 * b1.SurfaceArea()) / bounds.SurfaceArea();
+            }
+            Float minCost = cost[0];
+            int minCostSplitBucket = 0;
+            for (int i = 1; i < nBuckets - 1; ++i)
+                if (cost[i] < minCost) { minCost = cost[i]; minCostSplitBucket = i; }
+            Float leafCost = nPrimitives;
+            if (nPrimitives > maxPrimsInNode || minCost < leafCost) {
+                PrimInfo *pmid = std::partition(&primitiveInfo[start], &primitiveInfo[end - 1] + 1, [=](const PrimInfo &pi) {
+                    int b = nBuckets * centroidBounds.Offset(pi.centroid)[dim];
+                    if (b == nBuckets) b = nBuckets - 1;
+                    return b <= minCostSplitBucket;
+                });
+                mid = (int)(pmid - &primitiveInfo[0]);
+            } else
+                return makeLeaf();
+        }
+        // `node->InitInterior(dim, recursiveBuild(left), recursiveBuild(right))` (BVHAccel.cpp:359-363): g++
+        // evaluates call arguments right to left, so the reference builds the RIGHT subtree first and
+        // orderedPrims fills from there.  Node (DFS) order is unaffected.
+        BuildNode *c1 = recursiveBuild(primitiveInfo, mid, end, totalNodes);
+        BuildNode *c0 = recursiveBuild(primitiveInfo, start, mid, totalNodes);
+        node->children[0] = c0; node->children[1] = c1;
+        node->bounds = Union(c0->bounds, c1->bounds);
+        node->splitAxis = dim; node->nPrimitives = 0;
+        return node;
+    }
+    // BVHAccel.cpp:628-646
+    int flatten(BuildNode *node, int *offset, int depth) {
+        bvhMaxDepth = std::max(bvhMaxDepth, depth);
+        LinearBVHNode *ln = &nodes[*offset];
+        ln->bounds = node->bounds;
+        int myOffset = (*offset)++;
+        if (node->nPrimitives > 0) {
+            ln->offset = node->firstPrimOffset;
+            ln->nPrimitives = (uint16_t)node->nPrimitives;
+            ln->axis = 0;
+        } else {
+            ln->axis = (uint8_t)node->splitAxis;
+            ln->nPrimitives = 0;
+            flatten(node->children[0], offset, depth + 1);
+            ln->offset = flatten(node->children[1], offset, depth + 1);
+        }
+        ln->pad = 0;
+        return myOffset;
+    }
+    void BuildBVH() {
+        nodes.clear(); orderedPrims.clear(); bvhMaxDepth = 0;
+        int n = nTriangles();
+        if (n == 0) return;
+        std::vector<PrimInfo> info(n);
+        for (int i = 0; i < n; ++i) {
+            Bounds3 b = TriBound(i);
+            info[i].primitiveNumber = i;
+            info[i].bounds = b;
+            info[i].centroid = .5f * b.pMin + .5f * b.pMax;  // BVHAccel.cpp:16
+        }
+        int totalNodes = 0;
+        orderedPrims.reserve(n);
+        BuildNode *root = recursiveBuild(info, 0, n, &totalNodes);
+        nodes.resize(totalNodes);
+        int offset = 0;
+        flatten(root, &offset, 0);
+        for (BuildNode *b : buildPool) delete b;
+        buildPool.clear();
+    }
+
+    // ---------------- Triangle::Intersect, Triangle.cpp:71-303 + GeometricPrimitive::Intersect -------------
+    // `authoringIndex` selects the triangle; on a hit ray.tMax is shrunk (Primitive.cpp:36).
+    bool TriIntersect(int tri, const Ray &ray, SurfaceInteraction *isect) const {
+        V3 p0, p1, p2; Tri(tri, &p0, &p1, &p2);
+        V3 p0t = p0 - ray.o, p1t = p1 - ray.o, p2t = p2 - ray.o;
+        int kz = MaxDimension(Abs(ray.d));
+        int kx = kz + 1; if (kx == 3) kx = 0;
+        int ky = kx + 1; if (ky == 3) ky = 0;
+        V3 d = Permute(ray.d, kx, ky, kz);
+        p0t = Permute(p0t, kx, ky, kz); p1t = Permute(p1t, kx, ky, kz); p2t = Permute(p2t, kx, ky, kz);
+        Float Sx = -d.x / d.z, Sy = -d.y / d.z, Sz = 1.f / d.z;
+        p0t.x += Sx * p0t.z; p0t.y += Sy * p0t.z;
+        p1t.x += Sx * p1t.z; p1t.y += Sy * p1t.z;
+        p2t.x += Sx * p2t.z; p2t.y += Sy * p2t.z;
+        Float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+        Float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+        Float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+        if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {
+            double p2txp1ty = (double)p2t.x * (double)p1t.y;
+            double p2typ1tx = (double)p2t.y * (double)p1t.x;
+            e0 = (float)(p2typ1tx - p2txp1ty);
+            double p0txp2ty = (double)p0t.x * (double)p2t.y;
+            double p0typ2tx = (double)p0t.y * (double)p2t.x;
+            e1 = (float)(p0typ2tx - p0txp2ty);
+            double p1txp0ty = (double)p1t.x * (double)p0t.y;
+            double p1typ0tx = (double)p1t.y * (double)p0t.x;
+            e2 = (float)(p1typ0tx - p1txp0ty);
+        }
+        if ((e0 < 0 || e1 < 0 || e2 < 0) && (e0 > 0 || e1 > 0 || e2 > 0)) return false;
+        Float det = e0 + e1 + e2;
+        if (det == 0) return false;
+        p0t.z *= Sz; p1t.z *= Sz; p2t.z *= Sz;
+        Float tScaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+        if (det < 0 && (tScaled >= 0 || tScaled < ray.tMax * det)) return false;
+        else if (det > 0 && (tScaled <= 0 || tScaled > ray.tMax * det)) return false;
+        Float invDet = 1 / det;
+        Float b0 = e0 * invDet, b1 = e1 * invDet, b2 = e2 * invDet;
+        Float t = tScaled * invDet;
+        float maxZt = MaxComponent(Abs(V3(p0t.z, p1t.z, p2t.z)));
+        float deltaZ = gamma(3) * maxZt;
+        float maxXt = MaxComponent(Abs(V3(p0t.x, p1t.x, p2t.x)));
+        float maxYt = MaxComponent(Abs(V3(p0t.y, p1t.y, p2t.y)));
+        float deltaX = gamma(5) * (maxXt + maxZt);
+        float deltaY = gamma(5) * (maxYt + maxZt);
+        float deltaE = 2 * (gamma(2) * maxXt * maxYt + deltaY * maxXt + deltaX * maxYt);
+        float maxE = MaxComponent(Abs(V3(e0, e1, e2)));
+        float deltaT = 3 * (gamma(3) * maxE * maxZt + deltaE * maxZt + deltaZ * maxE) * std::abs(invDet);
+        if (t <= deltaT) return false;
+        if (!isect) { return true; }  // IntersectP stops here (Triangle.cpp:305-453 has no alpha mask on this path)
+
+        // partial derivatives with the default UVs (0,0),(1,0),(1,1), Triangle.h:60-74
+        V3 dpdu, dpdv;
+        P2 uv[3] = {P2(0, 0), P2(1, 0), P2(1, 1)};
+        Float duv02[2] = {uv[0].x - uv[2].x, uv[0].y - uv[2].y}, duv12[2] = {uv[1].x - uv[2].x, uv[1].y - uv[2].y};
+        V3 dp02 = p0 - p2, dp12 = p1 - p2;
+        Float determinant = duv02[0] * duv12[1] - duv02[1] * duv12[0];
+        bool degenerateUV = std::abs(determinant) < 1e-8;
+        if (!degenerateUV) {
+            Float invdet = 1 / determinant;
+            dpdu = (duv12[1] * dp02 - duv02[1] * dp12) * invdet;
+            dpdv = (-duv12[0] * dp02 + duv02[0] * dp12) * invdet;
+        }
+        if (degenerateUV || Cross(dpdu, dpdv).LengthSquared() == 0) {
+            V3 ng = Cross(p2 - p0, p1 - p0);
+            if (ng.LengthSquared() == 0) return false;
+            CoordinateSystem(Normalize(ng), &dpdu, &dpdv);
+        }
+        float xAbsSum = (std::abs(b0 * p0.x) + std::abs(b1 * p1.x) + std::abs(b2 * p2.x));
+        float yAbsSum = (std::abs(b0 * p0.y) + std::abs(b1 * p1.y) + std::abs(b2 * p2.y));
+        float zAbsSum = (std::abs(b0 * p0.z) + std::abs(b1 * p1.z) + std::abs(b2 * p2.z));
+        V3 pError = gamma(7) * V3(xAbsSum, yAbsSum, zAbsSum);
+        P2 uvHit(b0 * uv[0].x + b1 * uv[1].x + b2 * uv[2].x, b0 * uv[0].y + b1 * uv[1].y + b2 * uv[2].y);
+        V3 pHit = b0 * p0 + b1 * p1 + b2 * p2;
+
+        // SurfaceInteraction ctor, Interaction.cpp:8-34 (n from Cross(dpdu,dpdv) is overridden just below)
+        SurfaceInteraction si;
+        si.p = pHit; si.pError = pError; si.uv = uvHit; si.wo = Normalize(-ray.d);
+        si.dpdu = dpdu; si.dpdv = dpdv; si.sdpdu = dpdu; si.sdpdv = dpdv;
+        // Triangle.cpp:223-226 (no reverseOrientation / handedness swap on this path)
+        si.n = si.sn = Normalize(Cross(dp02, dp12));
+        si.p = b0 * p0 + b1 * p1 + b2 * p2;
+        si.prim = tri; si.b0 = b0; si.b1 = b1; si.b2 = b2; si.t = t;
+        // GeometricPrimitive::Intersect, Primitive.cpp:32-46
+        ray.tMax = t;
+        int mi = triMedIn[tri], mo = triMedOut[tri];
+        if (mi != mo) { si.mediumInside = mi; si.mediumOutside = mo; }  // IsMediumTransition
+        else { si.mediumInside = si.mediumOutside = ray.medium; }
+        *isect = si;
+        return true;
+    }
+
+    // BVHAccel::Intersect, BVHAccel.cpp:653-691
+    bool Intersect(const Ray &ray, SurfaceInteraction *isect) const {
+        counters.nIntersect.fetch_add(1, std::memory_order_relaxed);
+        if (nodes.empty()) return false;
+        bool hit = false;
+        V3 invDir(1 / ray.d.x, 1 / ray.d.y, 1 / ray.d.z);
+        int dirIsNeg[3] = {invDir.x < 0, invDir.y < 0, invDir.z < 0};
+        int toVisitOffset = 0, currentNodeIndex = 0;
+        int nodesToVisit[64];
+        uint64_t nn = 0, nt = 0;
+        while (true) {
+            const LinearBVHNode *node = &nodes[currentNodeIndex];
+            ++nn;
+            if (SlabTest(node->bounds, ray, invDir, dirIsNeg)) {
+                if (node->nPrimitives > 0) {
+                    for (int i = 0; i < node->nPrimitives; ++i) {
+                        ++nt;
+                        if (TriIntersect(orderedPrims[node->offset + i], ray, isect)) hit = true;
+                    }
+                    if (toVisitOffset == 0) break;
+                    currentNodeIndex = nodesToVisit[--toVisitOffset];
+                } else {
+                    if (dirIsNeg[node->axis]) {
+                        nodesToVisit[toVisitOffset++] = currentNodeIndex + 1;
+                        currentNodeIndex = node->offset;
+                    } else {
+                        nodesToVisit[toVisitOffset++] = node->offset;
+                        currentNodeIndex = currentNodeIndex + 1;
+                    }
+                }
+            } else {
+                if (toVisitOffset == 0) break;
+                currentNodeIndex = nodesToVisit[--toVisitOffset];
+            }
+        }
+        if (countTraversal) { counters.nNodes.fetch_add(nn, std::memory_order_relaxed); counters.nTris.fetch_add(nt, std::memory_order_relaxed); }
+        return hit;
+    }
+    // BVHAccel::IntersectP, BVHAccel.cpp:693-729
+    bool IntersectP(const Ray &ray) const {
+        counters.nIntersectP.fetch_add(1, std::memory_order_relaxed);
+        if (nodes.empty()) return false;
+        V3 invDir(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
+        int dirIsNeg[3] = {invDir.x < 0, invDir.y < 0, invDir.z < 0};
+        int nodesToVisit[64];
+        int toVisitOffset = 0, currentNodeIndex = 0;
+        uint64_t nn = 0, nt = 0;
+        bool result = false;
+        while (true) {
+            const LinearBVHNode *node = &nodes[currentNodeIndex];
+            ++nn;
+            if (SlabTest(node->bounds, ray, invDir, dirIsNeg)) {
+                if (node->nPrimitives > 0) {
+                    bool any = false;
+                    for (int i = 0; i < node->nPrimitives; ++i) {
+                        ++nt;
+                        if (TriIntersect(orderedPrims[node->offset + i], ray, nullptr)) { any = true; break; }
+                    }
+                    if (any) { result = true; break; }
+                    if (toVisitOffset == 0) break;
+                    currentNodeIndex = nodesToVisit[--toVisitOffset];
+                } else {
+                    if (dirIsNeg[node->axis]) {
+                        nodesToVisit[toVisitOffset++] = currentNodeIndex + 1;
+                        currentNodeIndex = node->offset;
+                    } else {
+                        nodesToVisit[toVisitOffset++] = node->offset;
+                        currentNodeIndex = currentNodeIndex + 1;
+                    }
+                }
+            } else {
+                if (toVisitOffset == 0) break;
+                currentNodeIndex = nodesToVisit[--toVisitOffset];
+            }
+        }
+        if (countTraversal) { counters.nNodes.fetch_add(nn, std::memory_order_relaxed); counters.nTris.fetch_add(nt, std::memory_order_relaxed); }
+        return result;
+    }
+
+    // Triangle::Area, Triangle.cpp:455-462
+    Float TriArea(int tri) const {
+        V3 p0, p1, p2; Tri(tri, &p0, &p1, &p2);
+        return 0.5 * Cross(p1 - p0, p2 - p0).Length();
+    }
+    // Triangle::Sample(u,pdf), Triangle.cpp:464-492
+    Interaction TriSample(int tri, const P2 &u, Float *pdf) const {
+        P2 b = UniformSampleTriangle(u);
+        V3 p0, p1, p2; Tri(tri, &p0, &p1, &p2);
+        Interaction it;
+        it.p = b.x * p0 + b.y * p1 + (1 - b.x - b.y) * p2;
+        it.n = Normalize(Cross(p1 - p0, p2 - p0));
+        V3 pAbsSum = Abs(b.x * p0) + Abs(b.y * p1) + Abs((1 - b.x - b.y) * p2);
+        it.pError = gamma(6) * V3(pAbsSum.x, pAbsSum.y, pAbsSum.z);
+        *pdf = 1 / TriArea(tri);
+        return it;
+    }
+    // Shape::Sample(ref,u,pdf), Shape.cpp:21-35
+    Interaction ShapeSample(int tri, const Interaction &ref, const P2 &u, Float *pdf) const {
+        Interaction intr = TriSample(tri, u, pdf);
+        V3 wi = intr.p - ref.p;
+        if (wi.LengthSquared() == 0) *pdf = 0;
+        else {
+            wi = Normalize(wi);
+            *pdf *= DistanceSquared(ref.p, intr.p) / AbsDot(intr.n, -wi);
+            if (std::isinf(*pdf)) *pdf = 0.f;
+        }
+        return intr;
+    }
+    // Shape::Pdf(ref,wi), Shape.cpp:37-53: re-intersects the single light triangle
+    Float ShapePdf(int tri, const Interaction &ref, const V3 &wi) const {
+        Ray ray = ref.SpawnRay(wi);
+        SurfaceInteraction isectLight;
+        if (!TriIntersect(tri, ray, &isectLight)) return 0;
+        Float pdf = DistanceSquared(ref.p, isectLight.p) / (AbsDot(isectLight.n, -wi) * TriArea(tri));
+        if (std::isinf(pdf)) pdf = 0.f;
+        return pdf;
+    }
+};
+
+// ---------------- Perspective camera, camera/Perspective.cpp + core/Camera.h:54-75 -----------------
+struct Camera {
+    M44 rasterToCamera, cameraToWorld;
+    V3 dxCamera, dyCamera;
+    Float lensRadius, focalDistance;
+    int medium = -1;
+    Camera() {}
+    Camera(const gnxr_camera &c, int W, int H) {
+        // RenderThread.cpp:62-68
+        Xform lookat = LookAt(V3(c.eye[0], c.eye[1], c.eye[2]), V3(c.look[0], c.look[1], c.look[2]), V3(c.up[0], c.up[1], c.up[2]));
+        cameraToWorld = lookat.mInv;  // Inverse(lookat)
+        // Perspective.cpp:114-135
+        float frame = (float)W / (float)H;
+        float sxmin, sxmax, symin, symax;
+        if (frame > 1.f) { sxmin = -frame; sxmax = frame; symin = -1.f; symax = 1.f; }
+        else { sxmin = -1.f; sxmax = 1.f; symin = -1.f / frame; symax = 1.f / frame; }
+        lensRadius = c.lens_radius; focalDistance = c.focal_distance;
+        Xform cameraToScreen = Perspective(c.fov_deg, 1e-2f, 1000.f);
+        // Camera.h:64-70
+        Xform screenToRaster = XMul(XMul(Scale(W, H, 1), Scale(1 / (sxmax - sxmin), 1 / (symin - symax), 1)), Translate(V3(-sxmin, -symax, 0)));
+        Xform rasterToScreen = XInverse(screenToRaster);
+        Xform r2c = XMul(XInverse(cameraToScreen), rasterToScreen);
+        rasterToCamera = r2c.m;
+        dxCamera = XPoint(rasterToCamera, V3(1, 0, 0)) - XPoint(rasterToCamera, V3(0, 0, 0));
+        dyCamera = XPoint(rasterToCamera, V3(0, 1, 0)) - XPoint(rasterToCamera, V3(0, 0, 0));
+    }
+    // Perspective.cpp:62-112 (main ray only; differentials are dropped by PathIntegrator's Ray copy,
+    // PathIntegrator.cpp:67) + Transform::operator()(Ray), Transform.h:230-244
+    Ray GenerateRay(const P2 &pFilm, const P2 &pLens) const {
+        V3 pCamera = XPoint(rasterToCamera, V3(pFilm.x, pFilm.y, 0));
+        V3 dir = Normalize(V3(pCamera.x, pCamera.y, pCamera.z));
+        V3 o(0, 0, 0), d = dir;
+        if (lensRadius > 0) {
+            P2 dsk = ConcentricSampleDisk(pLens);
+            P2 pl(lensRadius * dsk.x, lensRadius * dsk.y);
+            Float ft = focalDistance / d.z;
+            V3 pFocus = o + d * ft;
+            o = V3(pl.x, pl.y, 0);
+            d = Normalize(pFocus - o);
+        }
+        V3 oError;
+        V3 ow = XPointErr(cameraToWorld, o, &oError);
+        V3 dw = XVector(cameraToWorld, d);
+        Float lengthSquared = dw.LengthSquared();
+        Float tMax = Infinity;
+        if (lengthSquared > 0) {
+            Float dt = Dot(Abs(dw), oError) / lengthSquared;
+            ow += dw * dt;
+            tMax -= dt;
+        }
+        return Ray(ow, dw, tMax, medium);
+    }
+};
+
+}  // namespace gnxo
