@@ -1,0 +1,417 @@
+// api.hip -- C ABI of libgnxr.so (include/gnxr.h): device scene upload, the wavefront render loop and
+// the batched Aggregate-seam entry points.  One process drives one GPU (gnxr_init binds the device);
+// multi-GPU runs are one process per GPU with the image rows sharded by gnxr_render_params.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <mutex>
+
+#include "host_scene.h"
+#include "kernels.hip.h"
+
+using namespace gnxr;
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);       \
+            return e_ == hipErrorOutOfMemory ? GNXR_ERR_OOM : GNXR_ERR_NO_DEVICE;                        \
+        }                                                                                               \
+    } while (0)
+
+namespace {
+
+int g_device = -1;
+int g_num_cus = 256;
+
+int ensure_device() {
+    if (g_device >= 0) return GNXR_OK;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device available (%s); libgnxr has no CPU fallback", e != hipSuccess ? hipGetErrorString(e) : "0 devices");
+        return GNXR_ERR_NO_DEVICE;
+    }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    g_device = dev;
+    return GNXR_OK;
+}
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    int alloc(size_t count) {
+        if (count <= n && p) return GNXR_OK;
+        release();
+        if (count == 0) count = 1;
+        HIP_TRY(hipMalloc((void **)&p, count * sizeof(T)));
+        n = count;
+        return GNXR_OK;
+    }
+    int upload(const T *src, size_t count) {
+        int rc = alloc(count);
+        if (rc) return rc;
+        if (count) HIP_TRY(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+        return GNXR_OK;
+    }
+    template <typename V> int upload(const V &v) { return upload(v.data(), v.size()); }
+};
+
+int grid_for(long long n, int blocks_per_cu = 8) {
+    long long need = (n + kBlock - 1) / kBlock;
+    long long cap = (long long)g_num_cus * blocks_per_cu;
+    return (int)std::max<long long>(1, std::min(need, cap));
+}
+
+}  // namespace
+
+struct gnxr_scene {
+    CompiledScene cs;
+    // device tables
+    DevBuf<DNode> nodes;
+    DevBuf<DTri> tris;
+    DevBuf<DMaterial> materials;
+    DevBuf<DLight> lights;
+    DevBuf<int32_t> infinite;
+    DevBuf<uint16_t> perms;
+    DevBuf<int32_t> primes, prime_sums;
+    DevBuf<uint32_t> prime_magic;
+    DevBuf<float> env_texels, env_cond_func, env_cond_cdf, env_cond_int, env_marg_func, env_marg_cdf;
+    DevBuf<float> grid_table;
+    DLightGrid grid;
+    int grid_strategy = -1;
+    // per-render state (grown on demand)
+    DevBuf<float4> ray_o, ray_d, beta, L, sh_o, sh_d, sh_X, mis_o, mis_d, mis_Y, nbeta, accum, out;
+    DevBuf<uint2> meta;
+    DevBuf<int> hit, queue_a, queue_b, queue_nee;
+    DevBuf<Counters> counters;
+    Counters *h_counters = nullptr;  // pinned
+    int stack_size = 32;
+    std::mutex render_mutex;
+
+    ~gnxr_scene() { if (h_counters) (void)hipHostFree(h_counters); }
+
+    DScene device_scene(int W, int H) {
+        DScene d;
+        d.nodes = reinterpret_cast<const float4 *>(nodes.p);
+        d.tris = tris.p;
+        d.materials = materials.p;
+        d.lt.lights = lights.p;
+        d.lt.n_lights = (int)cs.desc_lights.size();
+        d.lt.infinite = infinite.p;
+        d.lt.n_infinite = (int)cs.infinite_lights.size();
+        d.lt.grid = grid;
+        d.lt.grid_table = grid_table.p;
+        d.lt.has_env = cs.has_env ? 1 : 0;
+        d.lt.env = cs.env;
+        d.lt.env_texels = env_texels.p;
+        d.lt.env_cond_func = env_cond_func.p; d.lt.env_cond_cdf = env_cond_cdf.p; d.lt.env_cond_int = env_cond_int.p;
+        d.lt.env_marg_func = env_marg_func.p; d.lt.env_marg_cdf = env_marg_cdf.p;
+        d.st.perms = perms.p; d.st.primes = primes.p; d.st.prime_sums = prime_sums.p; d.st.prime_magic = prime_magic.p;
+        d.st.h = make_halton(W, H);
+        return d;
+    }
+    int ensure_grid(int strategy) {
+        if (grid_strategy == strategy) return GNXR_OK;
+        std::vector<float> table;
+        build_light_grid(cs, strategy, &grid, &table);
+        int rc = grid_table.upload(table);
+        if (rc) return rc;
+        grid_strategy = strategy;
+        return GNXR_OK;
+    }
+};
+
+extern "C" {
+
+int gnxr_init(int device_id) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { set_error("no HIP device available; libgnxr has no CPU fallback"); return GNXR_ERR_NO_DEVICE; }
+    if (device_id < 0 || device_id >= n) { set_error("device %d out of range (%d visible)", device_id, n); return GNXR_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(device_id));
+    g_device = -1;
+    return ensure_device();
+}
+void gnxr_shutdown(void) { g_device = -1; }
+
+int gnxr_scene_create(const gnxr_scene_desc *desc, gnxr_scene **out) {
+    if (!desc || !out) { set_error("null argument"); return GNXR_ERR_INVALID; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    gnxr_scene *s = new (std::nothrow) gnxr_scene();
+    if (!s) return GNXR_ERR_OOM;
+    if (!compile_scene(desc, &s->cs)) { delete s; return GNXR_ERR_INVALID; }
+    CompiledScene &cs = s->cs;
+    if (cs.bvh_max_depth + 1 > 64) { set_error("BVH depth %d exceeds the 64-entry traversal stack (BVHAccel.cpp:661)", cs.bvh_max_depth); delete s; return GNXR_ERR_UNSUPPORTED; }
+    s->stack_size = cs.bvh_max_depth + 1 <= 32 ? 32 : 64;
+#define UP(field) if ((rc = s->field.upload(cs.field)) != GNXR_OK) { delete s; return rc; }
+    UP(nodes) UP(tris) UP(materials) UP(lights) UP(perms) UP(primes) UP(prime_sums) UP(prime_magic)
+    UP(env_texels) UP(env_cond_func) UP(env_cond_cdf) UP(env_cond_int) UP(env_marg_func) UP(env_marg_cdf)
+#undef UP
+    if ((rc = s->infinite.upload(cs.infinite_lights)) != GNXR_OK) { delete s; return rc; }
+    if ((rc = s->counters.alloc(1)) != GNXR_OK) { delete s; return rc; }
+    if (hipHostMalloc((void **)&s->h_counters, sizeof(Counters)) != hipSuccess) { set_error("hipHostMalloc failed"); delete s; return GNXR_ERR_OOM; }
+    *out = s;
+    return GNXR_OK;
+}
+void gnxr_scene_destroy(gnxr_scene *s) { delete s; }
+
+int gnxr_scene_info(const gnxr_scene *s, int32_t *n_nodes, int32_t *max_depth, int32_t *n_vox) {
+    if (!s) return GNXR_ERR_INVALID;
+    if (n_nodes) *n_nodes = (int32_t)s->cs.nodes.size();
+    if (max_depth) *max_depth = s->cs.bvh_max_depth;
+    if (n_vox) *n_vox = s->grid_strategy >= 0 ? s->grid.nvox[0] * s->grid.nvox[1] * s->grid.nvox[2] : 0;
+    return GNXR_OK;
+}
+
+static int count_local_rows(const gnxr_render_params *p) {
+    int rows = 0;
+    for (int y = 0; y < p->height; ++y)
+        if ((y / p->shard_rows) % p->shard_count == p->shard_index) ++rows;
+    return rows;
+}
+
+int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba_out, void *hip_stream, gnxr_stats *stats) {
+    if (!s || !pin || !d_rgba_out) { set_error("null argument"); return GNXR_ERR_INVALID; }
+    gnxr_render_params p = *pin;
+    if (p.shard_count <= 0) p.shard_count = 1;
+    if (p.shard_rows <= 0) p.shard_rows = 1;
+    if (p.spp_end <= 0) p.spp_end = p.spp;
+    if (p.width <= 0 || p.height <= 0 || p.spp <= 0 || p.spp_begin < 0 || p.spp_end > p.spp || p.spp_begin >= p.spp_end || p.shard_index < 0 ||
+        p.shard_index >= p.shard_count || p.max_depth < 0 || p.max_depth > 250) {
+        set_error("invalid render parameters");
+        return GNXR_ERR_INVALID;
+    }
+    if (p.integrator != GNXR_INTEGRATOR_PATH) { set_error("integrator %d has no device implementation yet", p.integrator); return GNXR_ERR_UNSUPPORTED; }
+    std::lock_guard<std::mutex> lock(s->render_mutex);
+    auto t_start = std::chrono::steady_clock::now();
+    hipStream_t stream = (hipStream_t)hip_stream;
+    int rc = s->ensure_grid(p.light_strategy);
+    if (rc) return rc;
+    DScene sc = s->device_scene(p.width, p.height);
+    // the device sampler keeps the Halton index in 32 bits
+    if ((unsigned long long)sc.st.h.stride * (unsigned long long)(p.spp + 1) >= (1ull << 32)) { set_error("spp too large for 32-bit Halton indices"); return GNXR_ERR_UNSUPPORTED; }
+    DRender r;
+    memset(&r, 0, sizeof(r));
+    r.cam = make_camera(s->cs.camera, p.width, p.height, s->cs.camera_medium);
+    r.W = p.width; r.H = p.height; r.spp = p.spp; r.max_depth = p.max_depth; r.rr_threshold = p.rr_threshold;
+    r.shard_index = p.shard_index; r.shard_count = p.shard_count; r.shard_rows = p.shard_rows;
+    int local_rows = count_local_rows(&p);
+    r.npix = local_rows * p.width;
+    if (r.npix == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return GNXR_OK; }
+    int nsamples = p.spp_end - p.spp_begin;
+    int k = p.samples_per_pass;
+    if (k <= 0) {  // auto: about 4M paths in flight
+        long long target = 4ll << 20;
+        k = (int)std::max<long long>(1, std::min<long long>(nsamples, target / r.npix));
+    }
+    k = std::min(k, nsamples);
+    size_t cap = (size_t)r.npix * k;
+    if (cap >= (1ull << 31)) { set_error("pass too large"); return GNXR_ERR_INVALID; }
+#define AL(f) if ((rc = s->f.alloc(cap)) != GNXR_OK) return rc;
+    AL(ray_o) AL(ray_d) AL(beta) AL(L) AL(sh_o) AL(sh_d) AL(sh_X) AL(mis_o) AL(mis_d) AL(mis_Y) AL(nbeta) AL(meta) AL(hit) AL(queue_a) AL(queue_b) AL(queue_nee)
+#undef AL
+    if ((rc = s->accum.alloc(r.npix)) != GNXR_OK) return rc;
+    PathArrays pa;
+    pa.ray_o = s->ray_o.p; pa.ray_d = s->ray_d.p; pa.beta = s->beta.p; pa.L = s->L.p; pa.meta = s->meta.p; pa.hit = s->hit.p;
+    pa.sh_o = s->sh_o.p; pa.sh_d = s->sh_d.p; pa.sh_X = s->sh_X.p; pa.mis_o = s->mis_o.p; pa.mis_d = s->mis_d.p; pa.mis_Y = s->mis_Y.p; pa.nbeta = s->nbeta.p;
+
+    HIP_TRY(hipMemsetAsync(s->accum.p, 0, sizeof(float4) * r.npix, stream));
+    HIP_TRY(hipMemsetAsync(s->counters.p, 0, sizeof(Counters), stream));
+    hipEvent_t ev0, ev1;
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+    HIP_TRY(hipEventRecord(ev0, stream));
+    unsigned long long rays_closest = 0;
+    unsigned int launches = 0, passes = 0;
+    const bool big = s->stack_size > 32;
+    Counters *dctr = s->counters.p;
+    for (int s0 = p.spp_begin; s0 < p.spp_end; s0 += k) {
+        int kk = std::min(k, p.spp_end - s0);
+        int n_paths = r.npix * kk;
+        hipLaunchKernelGGL(k_raygen, dim3(grid_for(n_paths)), dim3(kBlock), 0, stream, sc, r, pa, n_paths, s0);
+        ++launches;
+        int n = n_paths;
+        const int *q_in = nullptr;
+        int *q_cur = s->queue_a.p, *q_other = s->queue_b.p;
+        int guard = 0;
+        while (n > 0) {
+            if (big) hipLaunchKernelGGL((k_closest<64, false>), dim3(grid_for(n, 2)), dim3(kBlock), 0, stream, sc, pa, q_in, n, dctr);
+            else hipLaunchKernelGGL((k_closest<32, false>), dim3(grid_for(n, 5)), dim3(kBlock), 0, stream, sc, pa, q_in, n, dctr);
+            rays_closest += (unsigned long long)n;
+            hipLaunchKernelGGL(k_shade, dim3(grid_for(n)), dim3(kBlock), 0, stream, sc, r, pa, q_in, n, q_cur, s->queue_nee.p, dctr);
+            launches += 2;
+            HIP_TRY(hipMemcpyAsync(s->h_counters, dctr, sizeof(Counters), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            int n_next = (int)s->h_counters->q_next, n_nee = (int)s->h_counters->q_nee;
+            if (n_nee > 0) {
+                if (big) hipLaunchKernelGGL((k_nee<64, false>), dim3(grid_for(n_nee, 2)), dim3(kBlock), 0, stream, sc, pa, (const int *)s->queue_nee.p, n_nee, dctr);
+                else hipLaunchKernelGGL((k_nee<32, false>), dim3(grid_for(n_nee, 5)), dim3(kBlock), 0, stream, sc, pa, (const int *)s->queue_nee.p, n_nee, dctr);
+                ++launches;
+            }
+            // reset the two queue counters (they sit behind the 64-bit ray counters)
+            HIP_TRY(hipMemsetAsync(&dctr->q_next, 0, 2 * sizeof(unsigned int), stream));
+            q_in = q_cur;
+            std::swap(q_cur, q_other);
+            n = n_next;
+            if (++guard > 4096) { set_error("path loop did not terminate"); return GNXR_ERR_INVALID; }
+        }
+        hipLaunchKernelGGL(k_resolve, dim3(grid_for(r.npix)), dim3(kBlock), 0, stream, pa, s->accum.p, r.npix, kk);
+        ++launches;
+        ++passes;
+    }
+    hipLaunchKernelGGL(k_finish, dim3(grid_for(r.npix)), dim3(kBlock), 0, stream, r, (const float4 *)s->accum.p, (float4 *)d_rgba_out);
+    ++launches;
+    HIP_TRY(hipEventRecord(ev1, stream));
+    HIP_TRY(hipMemcpyAsync(s->h_counters, dctr, sizeof(Counters), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipGetLastError());
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        stats->rays_closest = rays_closest + s->h_counters->rays_closest;
+        stats->rays_any = s->h_counters->rays_any;
+        stats->camera_samples = (uint64_t)r.npix * nsamples;
+        stats->nodes_visited = s->h_counters->nodes;
+        stats->tris_tested = s->h_counters->tris;
+        stats->seconds_render = ms * 1e-3;
+        stats->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+        stats->kernel_launches = launches;
+        stats->passes = passes;
+    }
+    return GNXR_OK;
+}
+
+int gnxr_render(gnxr_scene *s, const gnxr_render_params *p, float *rgba_out, gnxr_stats *stats) {
+    if (!s || !p || !rgba_out) { set_error("null argument"); return GNXR_ERR_INVALID; }
+    if (p->width <= 0 || p->height <= 0) { set_error("invalid image size"); return GNXR_ERR_INVALID; }
+    size_t npx = (size_t)p->width * p->height;
+    int rc = s->out.alloc(npx);
+    if (rc) return rc;
+    HIP_TRY(hipMemset(s->out.p, 0, npx * sizeof(float4)));
+    rc = gnxr_render_device(s, p, s->out.p, nullptr, stats);
+    if (rc) return rc;
+    // copy back only the rows this shard owns
+    int sc = p->shard_count > 0 ? p->shard_count : 1, sr = p->shard_rows > 0 ? p->shard_rows : 1;
+    if (sc == 1) {
+        HIP_TRY(hipMemcpy(rgba_out, s->out.p, npx * sizeof(float4), hipMemcpyDeviceToHost));
+    } else {
+        for (int y = 0; y < p->height; ++y)
+            if ((y / sr) % sc == p->shard_index)
+                HIP_TRY(hipMemcpy(rgba_out + (size_t)y * p->width * 4, s->out.p + (size_t)y * p->width, (size_t)p->width * sizeof(float4), hipMemcpyDeviceToHost));
+    }
+    return GNXR_OK;
+}
+
+int gnxr_trace_closest(gnxr_scene *s, const gnxr_ray *rays, int64_t n, gnxr_hit *hits) {
+    if (!s || !rays || !hits || n < 0) { set_error("bad argument"); return GNXR_ERR_INVALID; }
+    if (n == 0) return GNXR_OK;
+    DevBuf<gnxr_ray> dr;
+    DevBuf<gnxr_hit> dh;
+    int rc;
+    if ((rc = dr.upload(rays, (size_t)n)) || (rc = dh.alloc((size_t)n))) return rc;
+    DScene sc = s->device_scene(1, 1);
+    if (s->stack_size > 32) hipLaunchKernelGGL((k_trace_closest_api<64>), dim3(grid_for(n, 2)), dim3(kBlock), 0, 0, sc, (const gnxr_ray *)dr.p, (long long)n, dh.p);
+    else hipLaunchKernelGGL((k_trace_closest_api<32>), dim3(grid_for(n, 5)), dim3(kBlock), 0, 0, sc, (const gnxr_ray *)dr.p, (long long)n, dh.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(hits, dh.p, (size_t)n * sizeof(gnxr_hit), hipMemcpyDeviceToHost));
+    return GNXR_OK;
+}
+int gnxr_trace_any(gnxr_scene *s, const gnxr_ray *rays, int64_t n, uint8_t *occluded) {
+    if (!s || !rays || !occluded || n < 0) { set_error("bad argument"); return GNXR_ERR_INVALID; }
+    if (n == 0) return GNXR_OK;
+    DevBuf<gnxr_ray> dr;
+    DevBuf<unsigned char> dob;
+    int rc;
+    if ((rc = dr.upload(rays, (size_t)n)) || (rc = dob.alloc((size_t)n))) return rc;
+    DScene sc = s->device_scene(1, 1);
+    if (s->stack_size > 32) hipLaunchKernelGGL((k_trace_any_api<64>), dim3(grid_for(n, 2)), dim3(kBlock), 0, 0, sc, (const gnxr_ray *)dr.p, (long long)n, dob.p);
+    else hipLaunchKernelGGL((k_trace_any_api<32>), dim3(grid_for(n, 5)), dim3(kBlock), 0, 0, sc, (const gnxr_ray *)dr.p, (long long)n, dob.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(occluded, dob.p, (size_t)n, hipMemcpyDeviceToHost));
+    return GNXR_OK;
+}
+
+// sampler tables without a scene (probes)
+static int probe_tables(CompiledScene *cs, DevBuf<uint16_t> *perms, DevBuf<int32_t> *primes, DevBuf<int32_t> *sums, DevBuf<uint32_t> *magic, DSamplerTables *st,
+                        int W, int H) {
+    // a one-triangle scene is the cheapest way to reuse the table builder
+    float v[9] = {0, 0, 0, 1, 0, 0, 0, 1, 0};
+    int32_t idx[3] = {0, 1, 2}, mat[1] = {-1}, lt[1] = {-1};
+    gnxr_scene_desc d;
+    memset(&d, 0, sizeof(d));
+    d.abi_version = GNXR_ABI_VERSION; d.n_vertices = 3; d.n_triangles = 1; d.vertices = v; d.indices = idx; d.tri_material = mat; d.tri_light = lt;
+    if (!compile_scene(&d, cs)) return GNXR_ERR_INVALID;
+    int rc;
+    if ((rc = perms->upload(cs->perms)) || (rc = primes->upload(cs->primes)) || (rc = sums->upload(cs->prime_sums)) || (rc = magic->upload(cs->prime_magic))) return rc;
+    st->perms = perms->p; st->primes = primes->p; st->prime_sums = sums->p; st->prime_magic = magic->p;
+    st->h = make_halton(W, H);
+    return GNXR_OK;
+}
+
+int gnxr_sample_halton(int32_t width, int32_t height, const int32_t *px, const int32_t *py, const int64_t *sidx, const int32_t *dim, int64_t n, float *out) {
+    if (!px || !py || !sidx || !dim || !out || n < 0 || width <= 0 || height <= 0) { set_error("bad argument"); return GNXR_ERR_INVALID; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n == 0) return GNXR_OK;
+    CompiledScene cs;
+    DevBuf<uint16_t> perms; DevBuf<int32_t> primes, sums; DevBuf<uint32_t> magic;
+    DSamplerTables st;
+    if ((rc = probe_tables(&cs, &perms, &primes, &sums, &magic, &st, width, height))) return rc;
+    DevBuf<int32_t> dpx, dpy, ddim; DevBuf<long long> ds; DevBuf<float> dout;
+    if ((rc = dpx.upload(px, n)) || (rc = dpy.upload(py, n)) || (rc = ddim.upload(dim, n)) || (rc = ds.upload((const long long *)sidx, n)) || (rc = dout.alloc(n))) return rc;
+    hipLaunchKernelGGL(k_halton_probe, dim3(grid_for(n)), dim3(kBlock), 0, 0, st, (const int *)dpx.p, (const int *)dpy.p, (const long long *)ds.p, (const int *)ddim.p, (long long)n, dout.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return GNXR_OK;
+}
+
+int gnxr_camera_rays(const gnxr_camera *cam, int32_t width, int32_t height, const int32_t *px, const int32_t *py, const int64_t *sidx, int64_t n, float *o_out,
+                     float *d_out) {
+    if (!cam || !px || !py || !sidx || !o_out || !d_out || n < 0 || width <= 0 || height <= 0) { set_error("bad argument"); return GNXR_ERR_INVALID; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n == 0) return GNXR_OK;
+    CompiledScene cs;
+    DevBuf<uint16_t> perms; DevBuf<int32_t> primes, sums; DevBuf<uint32_t> magic;
+    DSamplerTables st;
+    if ((rc = probe_tables(&cs, &perms, &primes, &sums, &magic, &st, width, height))) return rc;
+    DCamera dc = make_camera(*cam, width, height, -1);
+    DevBuf<int32_t> dpx, dpy; DevBuf<long long> ds; DevBuf<float> dob, dd;
+    if ((rc = dpx.upload(px, n)) || (rc = dpy.upload(py, n)) || (rc = ds.upload((const long long *)sidx, n)) || (rc = dob.alloc(3 * n)) || (rc = dd.alloc(3 * n))) return rc;
+    hipLaunchKernelGGL(k_camera_probe, dim3(grid_for(n)), dim3(kBlock), 0, 0, st, dc, (const int *)dpx.p, (const int *)dpy.p, (const long long *)ds.p, (long long)n, dob.p, dd.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(o_out, dob.p, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(d_out, dd.p, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
+    return GNXR_OK;
+}
+
+int gnxr_framebuffer_update(float *running_mean_rgba, const float *frame_rgba, int32_t width, int32_t height, int32_t frame_count, uint8_t *rgba8_out) {
+    if (!running_mean_rgba || !frame_rgba || !rgba8_out || width <= 0 || height <= 0 || frame_count <= 0) { set_error("bad argument"); return GNXR_ERR_INVALID; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    size_t nv = (size_t)width * height * 4;
+    DevBuf<float> dm, df;
+    DevBuf<unsigned char> du;
+    if ((rc = dm.upload(running_mean_rgba, nv)) || (rc = df.upload(frame_rgba, nv)) || (rc = du.alloc(nv))) return rc;
+    hipLaunchKernelGGL(k_framebuffer_update, dim3(grid_for((long long)nv)), dim3(kBlock), 0, 0, dm.p, (const float *)df.p, (long long)nv, frame_count, du.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(running_mean_rgba, dm.p, nv * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(rgba8_out, du.p, nv, hipMemcpyDeviceToHost));
+    return GNXR_OK;
+}
+
+}  // extern "C"

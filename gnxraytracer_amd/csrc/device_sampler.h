@@ -1,0 +1,116 @@
+// device_sampler.h -- the reference's Halton stream on the device, bit-exact.
+//   HaltonSampler::GetIndexForSample / SampleDimension   samplers/HaltonSampler.cpp:63-94
+//   RadicalInverse / ScrambledRadicalInverse             samplers/LowDiscrepancy.cpp:358-403, 2475-4532
+//   warps                                                core/Sampling.cpp:87-135, core/Sampling.h:140-161
+// A sample index never exceeds offset + spp * stride < 2^32 for the configs in scope (stride <= 31104,
+// spp <= 131072), so digits are peeled with exact 32-bit magic-number division (2 VALU ops + shifts)
+// instead of the reference's 64-bit `a / base`; the integer results are identical by construction and
+// the float tail keeps the reference's operation order.
+#pragma once
+#include "device_math.h"
+#include "gnxr_device_types.h"
+
+namespace gnxr {
+
+struct DSamplerTables {
+    const uint16_t *perms;
+    const int32_t *primes;
+    const int32_t *prime_sums;
+    const uint32_t *prime_magic;  // (M, s) per prime
+    DHalton h;
+};
+
+// exact n / d for any n < 2^32 (Granlund-Montgomery round-up method)
+GX_DEV uint32_t div_magic(uint32_t n, uint32_t M, uint32_t s) {
+    uint32_t t = __umulhi(M, n);
+    return (t + ((n - t) >> 1)) >> (s - 1);
+}
+
+// RadicalInverseSpecialized<base>, LowDiscrepancy.cpp:358-372
+GX_DEV float radical_inverse_base(uint32_t a, uint32_t base, uint32_t M, uint32_t s) {
+    const float invBase = 1.f / (float)base;
+    uint64_t reversedDigits = 0;
+    float invBaseN = 1;
+    while (a) {
+        uint32_t next = div_magic(a, M, s);
+        uint32_t digit = a - next * base;
+        reversedDigits = reversedDigits * base + digit;
+        invBaseN *= invBase;
+        a = next;
+    }
+    return fminf((float)reversedDigits * invBaseN, GX_ONE_MINUS_EPS);
+}
+// ScrambledRadicalInverseSpecialized<base>, LowDiscrepancy.cpp:374-393
+GX_DEV float scrambled_radical_inverse_base(uint32_t a, uint32_t base, uint32_t M, uint32_t s, const uint16_t *perm) {
+    const float invBase = 1.f / (float)base;
+    uint64_t reversedDigits = 0;
+    float invBaseN = 1;
+    while (a) {
+        uint32_t next = div_magic(a, M, s);
+        uint32_t digit = a - next * base;
+        reversedDigits = reversedDigits * base + perm[digit];
+        invBaseN *= invBase;
+        a = next;
+    }
+    return fminf(invBaseN * ((float)reversedDigits + invBase * (float)(int)perm[0] / (1 - invBase)), GX_ONE_MINUS_EPS);
+}
+// base 2: ReverseBits64(a) * 2^-64 evaluated in double, LowDiscrepancy.cpp:396-403.  For a < 2^32 the
+// reversed word is brev(a) << 32, so the product is brev(a) * 2^-32 and one rounding to float remains.
+GX_DEV float radical_inverse_2(uint32_t a) { return (float)((double)__brev(a) * 0x1p-32); }
+
+// HaltonSampler::SampleDimension, HaltonSampler.cpp:85-94 (sampleAtPixelCenter == false)
+GX_DEV float halton_sample(const DSamplerTables &t, uint32_t index, int dim) {
+    if (dim >= 1000) dim = 2 + (dim - 2) % 998;  // reference reads PrimeSums out of bounds here; defined to wrap
+    if (dim == 0) return radical_inverse_2(index >> t.h.base_exp[0]);
+    uint32_t base = (uint32_t)t.primes[dim], M = t.prime_magic[2 * dim], s = t.prime_magic[2 * dim + 1];
+    if (dim == 1) return radical_inverse_base(index / (uint32_t)t.h.base_scale[1], base, M, s);
+    return scrambled_radical_inverse_base(index, base, M, s, t.perms + t.prime_sums[dim]);
+}
+
+// HaltonSampler::GetIndexForSample offset part, HaltonSampler.cpp:63-83 (kMaxResolution = 128)
+GX_DEV uint32_t halton_pixel_offset(const DHalton &h, int px, int py) {
+    if (h.stride <= 1) return 0;
+    uint32_t pm0 = (uint32_t)(px & 127), pm1 = (uint32_t)(py & 127);  // Mod(p, 128) for p >= 0
+    // InverseRadicalInverse<2>, <3>  (LowDiscrepancy.h:47-56)
+    uint64_t i0 = 0, i1 = 0;
+    for (int i = 0; i < h.base_exp[0]; ++i) { uint32_t digit = pm0 & 1; pm0 >>= 1; i0 = i0 * 2 + digit; }
+    for (int i = 0; i < h.base_exp[1]; ++i) { uint32_t digit = pm1 % 3; pm1 /= 3; i1 = i1 * 3 + digit; }
+    uint64_t offset = i0 * (uint64_t)(h.stride / h.base_scale[0]) * (uint64_t)h.mult_inv[0] +
+                      i1 * (uint64_t)(h.stride / h.base_scale[1]) * (uint64_t)h.mult_inv[1];
+    return (uint32_t)(offset % (uint64_t)h.stride);
+}
+
+// GlobalSampler::Get1D / Get2D view of one pixel sample, core/Sampler.cpp:162-179
+struct SampleStream {
+    const DSamplerTables &t;
+    uint32_t index;
+    int dim;
+    GX_DEV SampleStream(const DSamplerTables &t, uint32_t index, int dim) : t(t), index(index), dim(dim) {}
+    GX_DEV float get1d() { return halton_sample(t, index, dim++); }
+    GX_DEV void get2d(float *u0, float *u1) { *u0 = halton_sample(t, index, dim); *u1 = halton_sample(t, index, dim + 1); dim += 2; }
+};
+
+// core/Sampling.cpp:87-105
+GX_DEV void concentric_sample_disk(float u0, float u1, float *dx, float *dy) {
+    float ox = 2.f * u0 - 1, oy = 2.f * u1 - 1;
+    if (ox == 0 && oy == 0) { *dx = 0; *dy = 0; return; }
+    float theta, r;
+    if (fabsf(ox) > fabsf(oy)) { r = ox; theta = GX_PI_OVER_4 * (oy / ox); }
+    else { r = oy; theta = GX_PI_OVER_2 - GX_PI_OVER_4 * (ox / oy); }
+    *dx = r * gx_cos(theta);
+    *dy = r * gx_sin(theta);
+}
+// core/Sampling.h:140-145
+GX_DEV V3 cosine_sample_hemisphere(float u0, float u1) {
+    float dx, dy;
+    concentric_sample_disk(u0, u1, &dx, &dy);
+    float z = gx_sqrt(fmaxf(0.f, 1 - dx * dx - dy * dy));
+    return V3(dx, dy, z);
+}
+// core/Sampling.h:157-161
+GX_DEV float power_heuristic(float fPdf, float gPdf) {
+    float f = 1 * fPdf, g = 1 * gPdf;
+    return (f * f) / (f * f + g * g);
+}
+
+}  // namespace gnxr

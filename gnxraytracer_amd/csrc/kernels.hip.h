@@ -1,0 +1,466 @@
+// kernels.hip.h -- the wavefront stages of the path tracer as hand-written HIP kernels for gfx950.
+//
+// Pipeline per pass (a pass = `k` consecutive Halton samples of every pixel this shard owns):
+//
+//   k_raygen        Sampler::GetCameraSample + PerspectiveCamera::GenerateRayDifferential      (A2, A4)
+//   loop over path vertices:
+//     k_closest     BVHAccel::Intersect for the continuation rays                              (A5, A6)
+//     k_shade       PathIntegrator::Li body at one vertex: Le, BSDF, UniformSampleOneLight set-up
+//                   (shadow ray + MIS ray records), BSDF sampling, Russian roulette, compaction  (A7-A21)
+//     k_nee         BVHAccel::IntersectP (shadow) + BVHAccel::Intersect (MIS) and L += beta * Ld (A16)
+//   k_resolve       colObj += Li in sample order, box average                                   (A1)
+//
+// State is SoA-of-float4 in HBM (one dwordx4 per lane per field, coalesced); queues hold path slots and
+// are compacted with wave64 ballots (one atomic per wave).  No MFMA: the work is BVH pointer chasing and
+// divergent shading, bound by memory latency / bandwidth.
+#pragma once
+#include "device_bsdf.h"
+#include "device_lights.h"
+
+namespace gnxr {
+
+constexpr int kBlock = 256;
+
+struct PathArrays {
+    float4 *ray_o;    // origin.xyz, tMax
+    float4 *ray_d;    // direction.xyz, medium (int bits)
+    float4 *beta;     // beta.rgb, etaScale
+    float4 *L;        // L.rgb
+    uint2 *meta;      // x: Halton sample index, y: dim | bounces << 16 | specularBounce << 31
+    int *hit;         // leaf-order triangle of the closest hit, -1 == miss
+    // next-event-estimation records written by k_shade, consumed by k_nee
+    float4 *sh_o;     // shadow ray origin, tMax
+    float4 *sh_d;     // shadow ray direction, flags (bit0 shadow ray valid, bit1 MIS ray valid)
+    float4 *sh_X;     // f*Li*w/lightPdf, w: light-selection pdf
+    float4 *mis_o;    // MIS ray origin, w: expected leaf triangle (int bits; -1 == expects a miss)
+    float4 *mis_d;    // MIS ray direction
+    float4 *mis_Y;    // f*Li*w/scatteringPdf if the expectation holds
+    float4 *nbeta;    // beta at the vertex
+};
+
+struct Counters {
+    unsigned long long rays_closest, rays_any, nodes, tris;
+    unsigned int q_next, q_nee;
+    unsigned int _pad[2];
+};
+
+struct DScene {
+    const float4 *nodes;
+    const DTri *tris;
+    const DMaterial *materials;
+    DLightTables lt;
+    DSamplerTables st;
+};
+
+struct DRender {
+    DCamera cam;
+    int W, H, spp, max_depth;
+    float rr_threshold;
+    int shard_index, shard_count, shard_rows;
+    int npix;       // pixels owned by this shard (local rows * W)
+};
+
+// local pixel -> raster coordinates for the row-interleaved sharding
+GX_DEV void local_pixel(const DRender &r, int lp, int *x, int *y) {
+    int row = lp / r.W;
+    *x = lp - row * r.W;
+    int blk = row / r.shard_rows;
+    *y = (blk * r.shard_count + r.shard_index) * r.shard_rows + (row - blk * r.shard_rows);
+}
+
+// Sampler::GetCameraSample (core/Sampler.cpp:14-20) + PerspectiveCamera::GenerateRayDifferential main ray
+// (camera/Perspective.cpp:62-112) + Transform::operator()(Ray) (Transform.h:230-244)
+GX_DEV void camera_ray(const DCamera &cam, const DSamplerTables &st, int px, int py, uint32_t index, V3 *o, V3 *d, float *tMax, int *dimOut) {
+    SampleStream s(st, index, 0);
+    float fx, fy, lx, ly;
+    s.get2d(&fx, &fy);
+    float pfx = (float)px + fx, pfy = (float)py + fy;
+    (void)s.get1d();  // time
+    s.get2d(&lx, &ly);
+    V3 pCamera = xform_point(cam.r2c, V3(pfx, pfy, 0));
+    V3 dir = normalize(V3(pCamera.x, pCamera.y, pCamera.z));
+    V3 oc(0, 0, 0), dc = dir;
+    if (cam.lens_radius > 0) {
+        float dx, dy;
+        concentric_sample_disk(lx, ly, &dx, &dy);
+        float plx = cam.lens_radius * dx, ply = cam.lens_radius * dy;
+        float ft = cam.focal_distance / dc.z;
+        V3 pFocus = oc + dc * ft;
+        oc = V3(plx, ply, 0);
+        dc = normalize(pFocus - oc);
+    }
+    // (*this)(r.o, &oError), Transform.h:259-283
+    const float *m = cam.c2w;
+    float x = oc.x, y = oc.y, z = oc.z;
+    float xp = (m[0] * x + m[1] * y) + (m[2] * z + m[3]);
+    float yp = (m[4] * x + m[5] * y) + (m[6] * z + m[7]);
+    float zp = (m[8] * x + m[9] * y) + (m[10] * z + m[11]);
+    float wp = (m[12] * x + m[13] * y) + (m[14] * z + m[15]);
+    float xAbs = (fabsf(m[0] * x) + fabsf(m[1] * y) + fabsf(m[2] * z) + fabsf(m[3]));
+    float yAbs = (fabsf(m[4] * x) + fabsf(m[5] * y) + fabsf(m[6] * z) + fabsf(m[7]));
+    float zAbs = (fabsf(m[8] * x) + fabsf(m[9] * y) + fabsf(m[10] * z) + fabsf(m[11]));
+    V3 oError = GX_GAMMA(3) * V3(xAbs, yAbs, zAbs);
+    V3 ow = (wp == 1) ? V3(xp, yp, zp) : V3((1.f / wp) * xp, (1.f / wp) * yp, (1.f / wp) * zp);
+    V3 dw = xform_vector(m, dc);
+    float lengthSquared = length_sq(dw);
+    float tm = GX_INF;
+    if (lengthSquared > 0) {
+        float dt = dot(vabs(dw), oError) / lengthSquared;
+        ow = ow + dw * dt;
+        tm -= dt;
+    }
+    *o = ow; *d = dw; *tMax = tm; *dimOut = s.dim;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_raygen(DScene sc, DRender r, PathArrays pa, int n_paths, int s0) {
+    for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_paths; slot += gridDim.x * blockDim.x) {
+        int j = slot / r.npix;
+        int lp = slot - j * r.npix;
+        int px, py;
+        local_pixel(r, lp, &px, &py);
+        uint32_t index = halton_pixel_offset(sc.st.h, px, py) + (uint32_t)(s0 + j) * (uint32_t)sc.st.h.stride;
+        V3 o, d;
+        float tMax;
+        int dim;
+        camera_ray(r.cam, sc.st, px, py, index, &o, &d, &tMax, &dim);
+        pa.ray_o[slot] = make_float4(o.x, o.y, o.z, tMax);
+        pa.ray_d[slot] = make_float4(d.x, d.y, d.z, __int_as_float(r.cam.medium));
+        pa.beta[slot] = make_float4(1.f, 1.f, 1.f, 1.f);
+        pa.L[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+        pa.meta[slot] = make_uint2(index, (uint32_t)dim);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int STACK, bool COUNT>
+__global__ void __launch_bounds__(kBlock) k_closest(DScene sc, PathArrays pa, const int *__restrict__ queue, int n, Counters *ctr) {
+    __shared__ int stack[STACK * kBlock];
+    TraceCounters tc = {0, 0};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int path = queue ? queue[i] : i;
+        float4 o4 = pa.ray_o[path], d4 = pa.ray_d[path];
+        TriHit h;
+        int leaf = bvh_traverse<false, kBlock, COUNT>(sc.nodes, sc.tris, V3(o4.x, o4.y, o4.z), V3(d4.x, d4.y, d4.z), o4.w, &stack[threadIdx.x], &h, &tc);
+        pa.hit[path] = leaf;
+    }
+    if (COUNT) {
+        atomicAdd(&ctr->nodes, (unsigned long long)tc.nodes);
+        atomicAdd(&ctr->tris, (unsigned long long)tc.tris);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+GX_DEV void wave_append(int *queue, unsigned int *counter, bool pred, int value) {
+    unsigned long long mask = __ballot(pred);
+    if (mask == 0) return;
+    int lane = __lane_id();
+    int leader = __ffsll((long long)mask) - 1;
+    unsigned int base = 0;
+    if (lane == leader) base = atomicAdd(counter, (unsigned int)__popcll(mask));
+    base = __shfl(base, leader);
+    if (pred) queue[base + __popcll(mask & ((1ull << lane) - 1ull))] = value;
+}
+
+__global__ void __launch_bounds__(kBlock) k_shade(DScene sc, DRender r, PathArrays pa, const int *__restrict__ queue, int n, int *queue_next, int *queue_nee,
+                                                  Counters *ctr) {
+    int nIter = (n + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
+    for (int it = 0; it < nIter; ++it) {
+        int i = it * gridDim.x * blockDim.x + blockIdx.x * blockDim.x + threadIdx.x;
+        bool active = i < n;
+        bool survive = false, wantNee = false;
+        int path = -1;
+        if (active) {
+            path = queue ? queue[i] : i;
+            uint2 m = pa.meta[path];
+            uint32_t index = m.x;
+            int dim = (int)(m.y & 0xffffu), bounces = (int)((m.y >> 16) & 0xffu);
+            bool specularBounce = (m.y >> 31) != 0;
+            float4 o4 = pa.ray_o[path], d4 = pa.ray_d[path], b4 = pa.beta[path], L4 = pa.L[path];
+            V3 ro(o4.x, o4.y, o4.z), rd(d4.x, d4.y, d4.z);
+            Spec beta(b4.x, b4.y, b4.z), L(L4.x, L4.y, L4.z);
+            float etaScale = b4.w;
+            int leaf = pa.hit[path];
+            bool found = leaf >= 0;
+            V3 p0, p1, p2;
+            int triMat = -1, triLight = -1;
+            TriHit h;
+            SurfacePoint sp;
+            sp.valid = false;
+            if (found) {
+                const float4 *q = reinterpret_cast<const float4 *>(sc.tris + leaf);
+                float4 a = q[0], b = q[1], c = q[2];
+                p0 = V3(a.x, a.y, a.z); p1 = V3(b.x, b.y, b.z); p2 = V3(c.x, c.y, c.z);
+                triMat = __float_as_int(b.w); triLight = __float_as_int(c.w);
+                found = tri_test(p0, p1, p2, ro, rd, o4.w, &h);  // same arithmetic as the traversal: always true here
+                if (found) {
+                    sp = surface_point(p0, p1, p2, h, triMat >= 0 ? sc.materials[triMat].has_bump != 0 : false);
+                    found = sp.valid;
+                }
+            }
+            // PathIntegrator.cpp:101-111: emitted light at the vertex / from the environment
+            if (bounces == 0 || specularBounce) {
+                if (found) {
+                    if (triLight >= 0) L = L + beta * area_L(sc.lt.lights[triLight], sp.n, -rd);
+                } else {
+                    for (int k = 0; k < sc.lt.n_infinite; ++k) L = L + beta * light_Le(sc.lt, sc.lt.infinite[k], ro, rd);
+                }
+            }
+            if (found && bounces < r.max_depth) {
+                if (triMat < 0) {
+                    // null material: skip the boundary, PathIntegrator.cpp:121-126 (bounces-- ; continue)
+                    V3 o2 = offset_ray_origin(sp.p, sp.pError, sp.n, rd);
+                    pa.ray_o[path] = make_float4(o2.x, o2.y, o2.z, GX_INF);
+                    survive = true;
+                } else {
+                    const DMaterial *mat = sc.materials + triMat;
+                    Bsdf bsdf;
+                    bsdf.mat = mat; bsdf.ns = sp.ns; bsdf.ng = sp.n; bsdf.ss = sp.ss; bsdf.ts = sp.ts;
+                    SampleStream ss(sc.st, index, dim);
+                    V3 woN = normalize(-rd);  // Interaction::wo
+                    // ---- UniformSampleOneLight, Integrator.cpp:57-79
+                    if (mat->n_nonspecular > 0 && sc.lt.n_lights > 0) {
+                        float lightPdfSel;
+                        int lightNum = light_select(sc.lt, sp.p, ss.get1d(), &lightPdfSel);
+                        if (lightPdfSel != 0) {
+                            float ul0, ul1, us0, us1;
+                            ss.get2d(&ul0, &ul1);
+                            ss.get2d(&us0, &us1);
+                            // ---- EstimateDirect, Integrator.cpp:93-210 (handleMedia = false, specular = false)
+                            const int bsdfFlags = BSDF_ALL & ~BSDF_SPECULAR;
+                            int nflags = 0;
+                            V3 so, sd, mo, wi2;
+                            Spec X(0.f), Y(0.f);
+                            int expect = -1;
+                            LightSample ls = light_sample(sc.lt, lightNum, sp.p, ul0, ul1);
+                            float scatteringPdf = 0;
+                            if (ls.pdf > 0 && !ls.Li.is_black()) {
+                                Spec f = bsdf.f(woN, ls.wi, bsdfFlags) * absdot(ls.wi, sp.ns);
+                                scatteringPdf = bsdf.pdf(woN, ls.wi, bsdfFlags);
+                                if (!f.is_black()) {
+                                    // visibility.Unoccluded(scene): shadow ray p0.SpawnRayTo(p1), Light.cpp:28-31
+                                    spawn_ray_to(sp.p, sp.pError, sp.n, ls.p1, ls.p1Error, ls.n1, &so, &sd);
+                                    float weight = power_heuristic(ls.pdf, scatteringPdf);
+                                    X = f * ls.Li * weight / ls.pdf;
+                                    nflags |= 1;
+                                }
+                            }
+                            {
+                                int sampledType;
+                                Spec f = bsdf.sample_f(woN, &wi2, us0, us1, &scatteringPdf, bsdfFlags, &sampledType);
+                                f = f * absdot(wi2, sp.ns);
+                                bool sampledSpecular = (sampledType & BSDF_SPECULAR) != 0;
+                                if (!f.is_black() && scatteringPdf > 0) {
+                                    float weight = 1;
+                                    bool skip = false;
+                                    if (!sampledSpecular) {
+                                        float lightPdf = light_pdf(sc.lt, lightNum, sp.p, sp.pError, sp.n, wi2);
+                                        if (lightPdf == 0) skip = true;  // `return Ld`
+                                        else weight = power_heuristic(scatteringPdf, lightPdf);
+                                    }
+                                    if (!skip) {
+                                        // closest-hit ray isect.SpawnRay(wi) (Integrator.cpp:193-197); what it must find for
+                                        // the light to contribute is known up front: this light's triangle, or nothing.
+                                        const DLight &lt = sc.lt.lights[lightNum];
+                                        mo = offset_ray_origin(sp.p, sp.pError, sp.n, wi2);
+                                        Spec Li2;
+                                        if (lt.type == GNXR_LIGHT_AREA_TRI) {
+                                            V3 lp0(lt.p0[0], lt.p0[1], lt.p0[2]), lp1(lt.p1[0], lt.p1[1], lt.p1[2]), lp2(lt.p2[0], lt.p2[1], lt.p2[2]);
+                                            V3 ln = normalize(cross(lp0 - lp2, lp1 - lp2));  // lightIsect.n
+                                            Li2 = area_L(lt, ln, -wi2);
+                                            expect = lt.tri_leaf;
+                                        } else {
+                                            Li2 = light_Le(sc.lt, lightNum, mo, wi2);
+                                            expect = -1;
+                                        }
+                                        if (!Li2.is_black()) Y = f * Li2 * Spec(1.f) * weight / scatteringPdf;
+                                        nflags |= 2;  // traced (and counted) even when Li2 is black, as in the reference
+                                    }
+                                }
+                            }
+                            if (nflags) {
+                                pa.sh_o[path] = make_float4(so.x, so.y, so.z, 1 - GX_SHADOW_EPS);
+                                pa.sh_d[path] = make_float4(sd.x, sd.y, sd.z, __int_as_float(nflags));
+                                pa.sh_X[path] = make_float4(X.r, X.g, X.b, lightPdfSel);
+                                if (nflags & 2) {
+                                    pa.mis_o[path] = make_float4(mo.x, mo.y, mo.z, __int_as_float(expect));
+                                    pa.mis_d[path] = make_float4(wi2.x, wi2.y, wi2.z, 0.f);
+                                    pa.mis_Y[path] = make_float4(Y.r, Y.g, Y.b, 0.f);
+                                }
+                                pa.nbeta[path] = make_float4(beta.r, beta.g, beta.b, 0.f);
+                                wantNee = true;
+                            }
+                        }
+                    }
+                    // ---- BSDF sampling for the next path vertex, PathIntegrator.cpp:144-163
+                    V3 wo = -rd, wi;
+                    float pdf, u0, u1;
+                    int flags;
+                    ss.get2d(&u0, &u1);
+                    Spec f = bsdf.sample_f(wo, &wi, u0, u1, &pdf, BSDF_ALL, &flags);
+                    if (!(f.is_black() || pdf == 0.f)) {
+                        beta = beta * (f * absdot(wi, sp.ns) / pdf);
+                        specularBounce = (flags & BSDF_SPECULAR) != 0;
+                        if ((flags & BSDF_SPECULAR) && (flags & BSDF_TRANSMISSION)) {
+                            float eta = mat->eta;
+                            etaScale *= (dot(wo, sp.n) > 0) ? (eta * eta) : 1 / (eta * eta);
+                        }
+                        V3 o2 = offset_ray_origin(sp.p, sp.pError, sp.n, wi);
+                        // Russian roulette, PathIntegrator.cpp:198-204
+                        Spec rrBeta = beta * etaScale;
+                        survive = true;
+                        if (rrBeta.max_value() < r.rr_threshold && bounces > 3) {
+                            float q = fmaxf(.05f, 1 - rrBeta.max_value());
+                            if (ss.get1d() < q) survive = false;
+                            else beta = beta / (1 - q);
+                        }
+                        if (survive) {
+                            pa.ray_o[path] = make_float4(o2.x, o2.y, o2.z, GX_INF);
+                            pa.ray_d[path] = make_float4(wi.x, wi.y, wi.z, d4.w);
+                            pa.beta[path] = make_float4(beta.r, beta.g, beta.b, etaScale);
+                            pa.meta[path] = make_uint2(index, (uint32_t)ss.dim | ((uint32_t)(bounces + 1) << 16) | (specularBounce ? 0x80000000u : 0u));
+                        }
+                    }
+                }
+            }
+            pa.L[path] = make_float4(L.r, L.g, L.b, 0.f);
+        }
+        wave_append(queue_next, &ctr->q_next, survive, path);
+        wave_append(queue_nee, &ctr->q_nee, wantNee, path);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int STACK, bool COUNT>
+__global__ void __launch_bounds__(kBlock) k_nee(DScene sc, PathArrays pa, const int *__restrict__ queue, int n, Counters *ctr) {
+    __shared__ int stack[STACK * kBlock];
+    TraceCounters tc = {0, 0};
+    unsigned int nAny = 0, nClosest = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int path = queue[i];
+        float4 sd4 = pa.sh_d[path], X4 = pa.sh_X[path];
+        int flags = __float_as_int(sd4.w);
+        Spec Ld(0.f);
+        TriHit h;
+        if (flags & 1) {
+            float4 so4 = pa.sh_o[path];
+            int leaf = bvh_traverse<true, kBlock, COUNT>(sc.nodes, sc.tris, V3(so4.x, so4.y, so4.z), V3(sd4.x, sd4.y, sd4.z), so4.w, &stack[threadIdx.x], &h, &tc);
+            ++nAny;
+            if (leaf < 0) Ld = Ld + Spec(X4.x, X4.y, X4.z);
+        }
+        if (flags & 2) {
+            float4 mo4 = pa.mis_o[path], md4 = pa.mis_d[path], Y4 = pa.mis_Y[path];
+            int expect = __float_as_int(mo4.w);
+            int leaf = bvh_traverse<false, kBlock, COUNT>(sc.nodes, sc.tris, V3(mo4.x, mo4.y, mo4.z), V3(md4.x, md4.y, md4.z), GX_INF, &stack[threadIdx.x], &h, &tc);
+            ++nClosest;
+            bool ok = (expect >= 0) ? (leaf == expect) : (leaf < 0);
+            Spec Y(Y4.x, Y4.y, Y4.z);
+            if (ok && !Y.is_black()) Ld = Ld + Y;
+        }
+        float4 nb = pa.nbeta[path], L4 = pa.L[path];
+        Spec add = Spec(nb.x, nb.y, nb.z) * (Ld / X4.w);
+        pa.L[path] = make_float4(L4.x + add.r, L4.y + add.g, L4.z + add.b, 0.f);
+    }
+    // one atomic per wave for the ray counters
+    for (int off = 32; off > 0; off >>= 1) { nAny += __shfl_down(nAny, off); nClosest += __shfl_down(nClosest, off); }
+    if (__lane_id() == 0) {
+        if (nAny) atomicAdd(&ctr->rays_any, (unsigned long long)nAny);
+        if (nClosest) atomicAdd(&ctr->rays_closest, (unsigned long long)nClosest);
+    }
+    if (COUNT) {
+        atomicAdd(&ctr->nodes, (unsigned long long)tc.nodes);
+        atomicAdd(&ctr->tris, (unsigned long long)tc.tris);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// colObj += Li(...) in sample order (core/Integrator.cpp:286), one lane per pixel, no atomics.
+__global__ void __launch_bounds__(kBlock) k_resolve(PathArrays pa, float4 *accum, int npix, int k) {
+    for (int lp = blockIdx.x * blockDim.x + threadIdx.x; lp < npix; lp += gridDim.x * blockDim.x) {
+        float4 a = accum[lp];
+        for (int j = 0; j < k; ++j) {
+            float4 l = pa.L[(size_t)j * npix + lp];
+            a.x += l.x; a.y += l.y; a.z += l.z;
+        }
+        accum[lp] = a;
+    }
+}
+// colObj / samplesPerPixel and the FrameBuffer layout (x + y*W)*4 + c (core/Integrator.cpp:293-310)
+__global__ void __launch_bounds__(kBlock) k_finish(DRender r, const float4 *accum, float4 *out) {
+    for (int lp = blockIdx.x * blockDim.x + threadIdx.x; lp < r.npix; lp += gridDim.x * blockDim.x) {
+        int x, y;
+        local_pixel(r, lp, &x, &y);
+        float4 a = accum[lp];
+        float spp = (float)(long long)r.spp;
+        out[(size_t)y * r.W + x] = make_float4(a.x / spp, a.y / spp, a.z / spp, 1.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Aggregate seam kernels: Scene::Intersect / IntersectP for caller-supplied rays
+template <int STACK>
+__global__ void __launch_bounds__(kBlock) k_trace_closest_api(DScene sc, const gnxr_ray *rays, long long n, gnxr_hit *hits) {
+    __shared__ int stack[STACK * kBlock];
+    TraceCounters tc = {0, 0};
+    for (long long i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        gnxr_ray r = rays[i];
+        V3 ro(r.o[0], r.o[1], r.o[2]), rd(r.d[0], r.d[1], r.d[2]);
+        TriHit h;
+        int leaf = bvh_traverse<false, kBlock, false>(sc.nodes, sc.tris, ro, rd, r.tmax, &stack[threadIdx.x], &h, &tc);
+        gnxr_hit out;
+        out.prim = -1; out.t = 0; out.b0 = out.b1 = out.b2 = 0; out.n[0] = out.n[1] = out.n[2] = 0;
+        if (leaf >= 0) {
+            V3 p0, p1, p2;
+            load_tri(sc.tris, leaf, &p0, &p1, &p2);
+            V3 nn = normalize(cross(p0 - p2, p1 - p2));
+            out.prim = sc.tris[leaf].prim; out.t = h.t; out.b0 = h.b0; out.b1 = h.b1; out.b2 = h.b2;
+            out.n[0] = nn.x; out.n[1] = nn.y; out.n[2] = nn.z;
+        }
+        hits[i] = out;
+    }
+}
+template <int STACK>
+__global__ void __launch_bounds__(kBlock) k_trace_any_api(DScene sc, const gnxr_ray *rays, long long n, unsigned char *occluded) {
+    __shared__ int stack[STACK * kBlock];
+    TraceCounters tc = {0, 0};
+    for (long long i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        gnxr_ray r = rays[i];
+        TriHit h;
+        int leaf = bvh_traverse<true, kBlock, false>(sc.nodes, sc.tris, V3(r.o[0], r.o[1], r.o[2]), V3(r.d[0], r.d[1], r.d[2]), r.tmax, &stack[threadIdx.x], &h, &tc);
+        occluded[i] = leaf >= 0 ? 1 : 0;
+    }
+}
+
+// probes
+__global__ void k_halton_probe(DSamplerTables st, const int *px, const int *py, const long long *s, const int *dim, long long n, float *out) {
+    for (long long i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        uint32_t index = halton_pixel_offset(st.h, px[i], py[i]) + (uint32_t)s[i] * (uint32_t)st.h.stride;
+        out[i] = halton_sample(st, index, dim[i]);
+    }
+}
+__global__ void k_camera_probe(DSamplerTables st, DCamera cam, const int *px, const int *py, const long long *s, long long n, float *o_out, float *d_out) {
+    for (long long i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        uint32_t index = halton_pixel_offset(st.h, px[i], py[i]) + (uint32_t)s[i] * (uint32_t)st.h.stride;
+        V3 o, d;
+        float tMax;
+        int dim;
+        camera_ray(cam, st, px[i], py[i], index, &o, &d, &tMax, &dim);
+        o_out[3 * i] = o.x; o_out[3 * i + 1] = o.y; o_out[3 * i + 2] = o.z;
+        d_out[3 * i] = d.x; d_out[3 * i + 1] = d.y; d_out[3 * i + 2] = d.z;
+    }
+}
+
+// FrameBuffer::update_f_u_c, ui/FrameBuffer.h:127-149
+__global__ void k_framebuffer_update(float *mean, const float *frame, long long nvals, int frame_count, unsigned char *rgba8) {
+    for (long long i = blockIdx.x * blockDim.x + threadIdx.x; i < nvals; i += (long long)gridDim.x * blockDim.x) {
+        if ((i & 3) == 3) { rgba8[i] = 255; continue; }  // set_uc(i, j, 3, 255)
+        float weight = (1.0f / (float)frame_count);
+        float fValue = weight * frame[i] + (1.0f - weight) * mean[i];
+        mean[i] = fValue;
+        float exposure = 0.75f;
+        float temp_c = 1.0f - gx_exp(-fValue * 1.0f / (1 - exposure));
+        rgba8[i] = (unsigned char)(temp_c * 255);
+    }
+}
+
+}  // namespace gnxr

@@ -229,7 +229,7 @@ bool write_synthetic_3d(const char *path, int target_tris, uint32_t seed) {
     const double TWO_PI = 6.283185307179586;
     auto knot = [&](double t, double *p) {
         double r = 0.055 * (2 + std::cos(3 * t)) / 3.0 + 0.025;
-        p[0] = r * std::cos(2 * t) * 1.45;
+        p[0] = r * std::cos(2 * t) * 1.15;
         p[1] = 0.13 + 0.075 * std::sin(3 * t);
         p[2] = r * std::sin(2 * t) * 0.95;
     };
