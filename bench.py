@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Mrays/s (+ wall-clock to 1024 spp) on the "dragon" Cornell scene.
+
+Workload (BASELINE.json configs[2]): Cornell box + ~100k-triangle mesh, Glass + Metal, PathIntegrator
+maxDepth 8, rrThreshold 1, "spatial" light sampling, HaltonSampler(1024), 1920x1080.  The mesh is the
+seeded SYNTHETIC stand-in for the reference's dragon.3d, which is absent from the snapshot
+(.MISSING_LARGE_BLOBS) -- numbers are not comparable with anyone else's "dragon".
+
+A step = one pass of the hot path over one batch: `--spp-per-step` (default 8) consecutive Halton samples
+of every pixel (16.6 M camera samples at 1080p).  The default --steps 128 therefore renders the full
+1024 spp image and `wall_to_1024spp_s` is measured, not extrapolated.
+
+With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) image rows are interleaved over
+the ranks, no collective runs during rendering, and the final FrameBuffer is gathered to rank 0 with one
+RCCL gather inside the timed region.  value = rays traced by all ranks / max-over-ranks time.
+
+Ray = one Scene::Intersect or Scene::IntersectP query (closest-hit, shadow and MIS rays), the unit the
+reference was profiled in.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--spp-per-step", type=int, default=8)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=1024, help="HaltonSampler samplesPerPixel")
+    ap.add_argument("--tris", type=int, default=100000)
+    ap.add_argument("--max-depth", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP-event timing")
+    ap.add_argument("--save-image", type=str, default="")
+    return ap.parse_args()
+
+
+def cpu_baseline(builder, args):
+    """Oracle (CPU restatement of the reference path, OpenMP over pixel columns like Integrator.cpp:256)
+    on the host cores, on a bounded sample of the same workload."""
+    import gnxraytracer_amd as gx
+    import oracle_lib as ol
+
+    osc = ol.OracleScene(builder)
+    integ = gx.PathIntegrator(args.max_depth, 1.0, "spatial")
+    w, h, spp = 240, 135, 8           # same scene / camera / sampler, 1/64 of the pixels, first 8 of 1024 samples
+    cores = os.cpu_count() or 1
+    img, st = osc.render(integ, w, h, args.spp, spp_begin=0, spp_end=spp)   # warms the light cache
+    t = time.time()
+    img, st = osc.render(integ, w, h, args.spp, spp_begin=0, spp_end=spp)
+    dt = time.time() - t
+    rays = st["rays_closest"] + st["rays_any"]
+    return {"value": rays / st["seconds_render"] / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"{w}x{h} px, samples 0..{spp - 1} of HaltonSampler({args.spp}), same scene; {rays} rays in {st['seconds_render']:.1f} s; "
+                      "oracle = CPU restatement, OpenMP over pixel columns"}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import gnxraytracer_amd as gx
+    import scenes
+
+    gx.init(local_rank)
+    W, H = args.width, args.height
+    # every rank builds the same scene (replicated: ~12 MB of tables); rank 0 writes the mesh file once
+    mesh_path = os.path.join(ROOT, "gpurun_out", "_meshes", f"synthetic_dragon_{args.tris}_1.3d")
+    if rank == 0:
+        scenes.synthetic_mesh_path(args.tris)
+    if world > 1:
+        dist.barrier()
+    builder = scenes.dragon_cornell(args.tris, "glass+metal", mesh_path=mesh_path)
+    scene = gx.Scene(builder)
+    integ = gx.PathIntegrator(args.max_depth, 1.0, "spatial")
+    shard = dict(shard_index=rank, shard_count=world, shard_rows=1)
+    out = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    acc = torch.zeros_like(out)
+    stream = torch.cuda.current_stream().cuda_stream
+    sps = args.spp_per_step
+
+    def step(i):
+        s0 = (i * sps) % args.spp
+        s1 = min(s0 + sps, args.spp)
+        st = integ.RenderDevice(scene, out.data_ptr(), W, H, args.spp, stream=stream, spp_begin=s0, spp_end=s1,
+                                samples_per_pass=sps, **shard)
+        acc.add_(out)
+        return st
+
+    for i in range(args.warmup):
+        step(i)
+    acc.zero_()
+    if not args.no_kernel_timing:
+        gx.lib().gnxr_set_profiling(1)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    tot = dict(rays_closest=0, rays_any=0, seconds_closest=0.0, seconds_nee=0.0, seconds_shade=0.0, launches_closest=0,
+               launches_nee=0, rays_closest_nee=0, camera_samples=0, kernel_launches=0)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        st = step(i)
+        for k in tot:
+            tot[k] += st[k]
+    # final FrameBuffer gather: each rank owns rows y with y % world == rank
+    if world > 1:
+        mine = acc[rank::world].contiguous()
+        parts = [torch.empty_like(acc[r::world]) for r in range(world)] if rank == 0 else None
+        dist.gather(mine, parts, dst=0)
+        if rank == 0:
+            for r in range(world):
+                acc[r::world] = parts[r]
+    sync()
+    dt = time.perf_counter() - t0
+    gx.lib().gnxr_set_profiling(0)
+
+    rays = tot["rays_closest"] + tot["rays_any"]
+    tvec = torch.tensor([dt, float(rays), float(tot["rays_closest"]), float(tot["rays_any"])], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = tvec.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tvec.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt_max, rays_all = tmax[0].item(), tsum[1].item()
+    else:
+        dt_max, rays_all = dt, float(rays)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    spp_done = min(args.steps * sps, args.spp)
+    result = {
+        "metric": "Mrays/s (path tracing, closest-hit + shadow + MIS rays), dragon-stand-in Cornell 1920x1080",
+        "value": rays_all / dt_max / 1e6,
+        "unit": "Mrays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt_max / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"cfg3: Cornell + synthetic {args.tris}-tri mesh (stand-in for absent dragon.3d), Glass+Metal, "
+                               f"PathIntegrator maxDepth {args.max_depth} rr 1 spatial, Halton({args.spp}), {W}x{H}",
+                   "spp_per_step": sps, "spp_rendered": spp_done, "sharding": f"rows y % {world} == rank" if world > 1 else "none",
+                   "gather": "RCCL gather of row shards to rank 0 (in timed region)" if world > 1 else "n/a"},
+        "wall_to_1024spp_s": dt_max * (1024.0 / spp_done),
+        "wall_measured_s": dt_max,
+        "rays": {"closest": tot["rays_closest"], "any": tot["rays_any"], "per_camera_sample": rays / max(1, tot["camera_samples"])},
+    }
+
+    # ---- roofline of the dominant kernel (rank 0's launches, HIP events on the render stream)
+    if not args.no_kernel_timing and tot["launches_closest"] > 0:
+        # mean nodes visited / triangles tested per ray from the counting variant of the same kernels (untimed)
+        gx.lib().gnxr_set_profiling(2)
+        stc = integ.RenderDevice(scene, out.data_ptr(), W, H, args.spp, stream=stream, spp_begin=0, spp_end=1, samples_per_pass=1, **shard)
+        gx.lib().gnxr_set_profiling(0)
+        torch.cuda.synchronize()
+        nr = stc["rays_closest"] + stc["rays_any"]
+        n_nodes, n_tris = stc["nodes_visited"] / nr, stc["tris_tested"] / nr
+        b_ray = 136.0 + 32.0 * n_nodes + 48.0 * n_tris
+        rays_k_closest = tot["rays_closest"] - tot["rays_closest_nee"]
+        rays_k_nee = tot["rays_any"] + tot["rays_closest_nee"]
+        kern = [("k_closest", tot["seconds_closest"], tot["launches_closest"], rays_k_closest),
+                ("k_nee", tot["seconds_nee"], tot["launches_nee"], rays_k_nee)]
+        name, secs, launches, krays = max(kern, key=lambda k: k[1])
+        achieved = krays * b_ray / secs / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                              "traffic": traffic, "kernel": name, "launches": launches, "avg_launch_ms": secs / launches * 1e3,
+                              "rays_per_launch": krays / launches, "bytes_per_ray": b_ray, "nodes_per_ray": n_nodes, "tris_per_ray": n_tris,
+                              "kernel_seconds": {"k_closest": tot["seconds_closest"], "k_nee": tot["seconds_nee"], "k_shade": tot["seconds_shade"]},
+                              "note": "algorithmic bytes (SURVEY 8d) / HIP-event kernel time; the 11 MB BVH lives in L2/Infinity Cache, "
+                                      "so measured HBM traffic is far below the algorithmic figure"}
+    if args.save_image and rank == 0:
+        np.save(args.save_image, acc.cpu().numpy())
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(builder, args)
+        result["cpu_baseline"]["reference_in_survey_container"] = "cfg 2 only: 1.58 Mrays/s as-is, 6.3 Mrays/s printf-free, 8-core Xeon 2.1 GHz (BASELINE.md)"
+    print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

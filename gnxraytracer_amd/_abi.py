@@ -75,6 +75,8 @@ class Stats(C.Structure):
         ("rays_closest", u64), ("rays_any", u64), ("camera_samples", u64), ("nodes_visited", u64), ("tris_tested", u64),
         ("seconds_render", C.c_double), ("seconds_trace", C.c_double), ("seconds_total", C.c_double),
         ("kernel_launches", u32), ("passes", u32),
+        ("seconds_closest", C.c_double), ("seconds_nee", C.c_double), ("seconds_shade", C.c_double),
+        ("launches_closest", u32), ("launches_nee", u32), ("rays_closest_nee", u64),
     ]
 
 
@@ -95,6 +97,7 @@ PROTOTYPES = {
     "gnxr_init": (C.c_int, [C.c_int]),
     "gnxr_shutdown": (None, []),
     "gnxr_last_error": (C.c_char_p, []),
+    "gnxr_set_profiling": (C.c_int, [C.c_int]),
     "gnxr_scene_create": (C.c_int, [P(SceneDesc), P(VP)]),
     "gnxr_scene_destroy": (None, [VP]),
     "gnxr_scene_info": (C.c_int, [VP, P(i32), P(i32), P(i32)]),

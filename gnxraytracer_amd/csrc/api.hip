@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cstdio>
 #include <mutex>
+#include <vector>
 
 #include "host_scene.h"
 #include "kernels.hip.h"
@@ -25,6 +26,31 @@ namespace {
 
 int g_device = -1;
 int g_num_cus = 256;
+int g_profiling = 0;
+
+// Per-kernel timing with HIP events on the render stream.  Events are recycled from a pool and resolved
+// after the stream has been synchronised.
+struct KernelTimer {
+    std::vector<hipEvent_t> pool;
+    struct Span { int kind; hipEvent_t a, b; };
+    std::vector<Span> open;
+    size_t used = 0;
+    double seconds[3] = {0, 0, 0};
+    unsigned launches[3] = {0, 0, 0};
+    hipEvent_t get() {
+        if (used == pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; pool.push_back(e); }
+        return pool[used++];
+    }
+    void begin(int kind, hipStream_t st) { Span s{kind, get(), get()}; if (s.a && s.b) { (void)hipEventRecord(s.a, st); open.push_back(s); } }
+    void end(hipStream_t st) { if (!open.empty()) (void)hipEventRecord(open.back().b, st); }
+    // call only after the stream has been synchronised
+    void collect() {
+        for (auto &s : open) { float ms = 0; if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { seconds[s.kind] += ms * 1e-3; launches[s.kind]++; } }
+        open.clear();
+        used = 0;
+    }
+    ~KernelTimer() { for (auto e : pool) (void)hipEventDestroy(e); }
+};
 
 int ensure_device() {
     if (g_device >= 0) return GNXR_OK;
@@ -143,6 +169,7 @@ int gnxr_init(int device_id) {
     return ensure_device();
 }
 void gnxr_shutdown(void) { g_device = -1; }
+int gnxr_set_profiling(int flags) { g_profiling = flags; return GNXR_OK; }
 
 int gnxr_scene_create(const gnxr_scene_desc *desc, gnxr_scene **out) {
     if (!desc || !out) { set_error("null argument"); return GNXR_ERR_INVALID; }
@@ -235,6 +262,8 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     unsigned long long rays_closest = 0;
     unsigned int launches = 0, passes = 0;
     const bool big = s->stack_size > 32;
+    const bool timing = (g_profiling & 1) != 0, counting = (g_profiling & 2) != 0;
+    KernelTimer timer;
     Counters *dctr = s->counters.p;
     for (int s0 = p.spp_begin; s0 < p.spp_end; s0 += k) {
         int kk = std::min(k, p.spp_end - s0);
@@ -246,17 +275,32 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
         int *q_cur = s->queue_a.p, *q_other = s->queue_b.p;
         int guard = 0;
         while (n > 0) {
-            if (big) hipLaunchKernelGGL((k_closest<64, false>), dim3(grid_for(n, 2)), dim3(kBlock), 0, stream, sc, pa, q_in, n, dctr);
-            else hipLaunchKernelGGL((k_closest<32, false>), dim3(grid_for(n, 5)), dim3(kBlock), 0, stream, sc, pa, q_in, n, dctr);
+            if (timing) timer.begin(0, stream);
+            if (counting) {
+                if (big) hipLaunchKernelGGL((k_closest<64, true>), dim3(grid_for(n, 2)), dim3(kBlock), 0, stream, sc, pa, q_in, n, dctr);
+                else hipLaunchKernelGGL((k_closest<32, true>), dim3(grid_for(n, 5)), dim3(kBlock), 0, stream, sc, pa, q_in, n, dctr);
+            } else {
+                if (big) hipLaunchKernelGGL((k_closest<64, false>), dim3(grid_for(n, 2)), dim3(kBlock), 0, stream, sc, pa, q_in, n, dctr);
+                else hipLaunchKernelGGL((k_closest<32, false>), dim3(grid_for(n, 5)), dim3(kBlock), 0, stream, sc, pa, q_in, n, dctr);
+            }
+            if (timing) { timer.end(stream); timer.begin(2, stream); }
             rays_closest += (unsigned long long)n;
             hipLaunchKernelGGL(k_shade, dim3(grid_for(n)), dim3(kBlock), 0, stream, sc, r, pa, q_in, n, q_cur, s->queue_nee.p, dctr);
+            if (timing) timer.end(stream);
             launches += 2;
             HIP_TRY(hipMemcpyAsync(s->h_counters, dctr, sizeof(Counters), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             int n_next = (int)s->h_counters->q_next, n_nee = (int)s->h_counters->q_nee;
             if (n_nee > 0) {
-                if (big) hipLaunchKernelGGL((k_nee<64, false>), dim3(grid_for(n_nee, 2)), dim3(kBlock), 0, stream, sc, pa, (const int *)s->queue_nee.p, n_nee, dctr);
-                else hipLaunchKernelGGL((k_nee<32, false>), dim3(grid_for(n_nee, 5)), dim3(kBlock), 0, stream, sc, pa, (const int *)s->queue_nee.p, n_nee, dctr);
+                if (timing) timer.begin(1, stream);
+                if (counting) {
+                    if (big) hipLaunchKernelGGL((k_nee<64, true>), dim3(grid_for(n_nee, 2)), dim3(kBlock), 0, stream, sc, pa, (const int *)s->queue_nee.p, n_nee, dctr);
+                    else hipLaunchKernelGGL((k_nee<32, true>), dim3(grid_for(n_nee, 5)), dim3(kBlock), 0, stream, sc, pa, (const int *)s->queue_nee.p, n_nee, dctr);
+                } else {
+                    if (big) hipLaunchKernelGGL((k_nee<64, false>), dim3(grid_for(n_nee, 2)), dim3(kBlock), 0, stream, sc, pa, (const int *)s->queue_nee.p, n_nee, dctr);
+                    else hipLaunchKernelGGL((k_nee<32, false>), dim3(grid_for(n_nee, 5)), dim3(kBlock), 0, stream, sc, pa, (const int *)s->queue_nee.p, n_nee, dctr);
+                }
+                if (timing) timer.end(stream);
                 ++launches;
             }
             // reset the two queue counters (they sit behind the 64-bit ray counters)
@@ -269,6 +313,7 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
         hipLaunchKernelGGL(k_resolve, dim3(grid_for(r.npix)), dim3(kBlock), 0, stream, pa, s->accum.p, r.npix, kk);
         ++launches;
         ++passes;
+        if (timing) { HIP_TRY(hipStreamSynchronize(stream)); timer.collect(); }
     }
     hipLaunchKernelGGL(k_finish, dim3(grid_for(r.npix)), dim3(kBlock), 0, stream, r, (const float4 *)s->accum.p, (float4 *)d_rgba_out);
     ++launches;
@@ -291,6 +336,10 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
         stats->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
         stats->kernel_launches = launches;
         stats->passes = passes;
+        stats->seconds_closest = timer.seconds[0]; stats->seconds_nee = timer.seconds[1]; stats->seconds_shade = timer.seconds[2];
+        stats->seconds_trace = timer.seconds[0] + timer.seconds[1];
+        stats->launches_closest = timer.launches[0]; stats->launches_nee = timer.launches[1];
+        stats->rays_closest_nee = s->h_counters->rays_closest;
     }
     return GNXR_OK;
 }

@@ -201,6 +201,11 @@ typedef struct gnxr_stats {
     double seconds_total;
     uint32_t kernel_launches;
     uint32_t passes;
+    double seconds_closest;     /* k_closest launches (profiling bit 0)                      */
+    double seconds_nee;         /* k_nee launches                                            */
+    double seconds_shade;       /* k_shade launches                                          */
+    uint32_t launches_closest, launches_nee;
+    uint64_t rays_closest_nee;  /* closest-hit rays traced by k_nee (MIS rays)               */
 } gnxr_stats;
 
 typedef struct gnxr_ray { float o[3]; float tmax; float d[3]; float _pad; } gnxr_ray;
@@ -217,6 +222,11 @@ int gnxr_abi_version(void);
 int gnxr_init(int device_id);          /* binds the calling process to one HIP device    */
 void gnxr_shutdown(void);
 const char *gnxr_last_error(void);
+/* Measurement switches (process-wide).  bit 0: bracket every traversal kernel launch with HIP events on
+ * the render stream and report their summed duration in gnxr_stats.seconds_trace (+ per-kernel split in
+ * seconds_closest / seconds_nee); bit 1: run the counting variant of the traversal kernels and fill
+ * nodes_visited / tris_tested (slower; never combine with a timed run).                              */
+int gnxr_set_profiling(int flags);
 
 /* -- scene (replaces `Scene(make_shared<BVHAccel>(prims,1), lights)`, RenderThread.cpp:155) */
 int gnxr_scene_create(const gnxr_scene_desc *desc, gnxr_scene **out);
