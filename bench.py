@@ -131,14 +131,12 @@ def main():
         st = step(i)
         for k in tot:
             tot[k] += st[k]
-    # final FrameBuffer gather: each rank owns rows y with y % world == rank
+    # final FrameBuffer gather: each rank owns rows y with y % world == rank (one RCCL gather, timed)
     if world > 1:
-        mine = acc[rank::world].contiguous()
-        parts = [torch.empty_like(acc[r::world]) for r in range(world)] if rank == 0 else None
-        dist.gather(mine, parts, dst=0)
+        from gnxraytracer_amd.distributed import gather_framebuffer
+        full = gather_framebuffer(acc, rank, world, 1, dst=0)
         if rank == 0:
-            for r in range(world):
-                acc[r::world] = parts[r]
+            acc = full
     sync()
     dt = time.perf_counter() - t0
     gx.lib().gnxr_set_profiling(0)

@@ -94,6 +94,7 @@ VP = C.c_void_p
 # name -> (restype, argtypes); every symbol include/gnxr.h declares
 PROTOTYPES = {
     "gnxr_abi_version": (C.c_int, []),
+    "gnxr_abi_sizeof": (C.c_int, [C.c_int]),
     "gnxr_init": (C.c_int, [C.c_int]),
     "gnxr_shutdown": (None, []),
     "gnxr_last_error": (C.c_char_p, []),
@@ -129,6 +130,9 @@ PROTOTYPES = {
     "gnxr_builder_desc": (C.c_int, [VP, P(SceneDesc)]),
     "gnxr_write_synthetic_3d": (C.c_int, [C.c_char_p, i32, u32]),
 }
+
+
+ABI_STRUCTS = [Material, Light, Camera, Medium, SceneDesc, RenderParams, Stats, Ray, Hit]
 
 
 def bind(lib):

@@ -88,7 +88,8 @@ GX_DEV Spec skybox_Le(const DLight &l, V3 ro, V3 rd) {  // SkyBoxLight.cpp:55-85
     float c = dot(oc, oc) - R * R;
     float disc = b * b - 4 * a * c;
     if (disc < 0) return Spec(0.f);
-    float tt = (float)((-(double)b + sqrt((double)disc)) / (2.0 * (double)a));
+    // float sqrt (SkyBoxLight.cpp sees <math.h> via stb_image.h), double division by `2.0 * a`
+    float tt = (float)((double)(-b + gx_sqrt(disc)) / (2.0 * (double)a));
     V3 hp = ro + tt * rd;
     V3 q = hp - center;
     return Spec((q.x + R) / (2.f * R), (q.y + R) / (2.f * R), (q.z + R) / (2.f * R));

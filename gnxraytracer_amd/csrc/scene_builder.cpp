@@ -553,6 +553,21 @@ int gnxr_write_synthetic_3d(const char *path, int32_t target_triangles, uint32_t
 }
 
 const char *gnxr_last_error(void) { return gnxr::get_error(); }
+// sizeof() of the ABI structs, in the order they appear in include/gnxr.h (binding self-check)
+int gnxr_abi_sizeof(int which) {
+    switch (which) {
+    case 0: return (int)sizeof(gnxr_material);
+    case 1: return (int)sizeof(gnxr_light);
+    case 2: return (int)sizeof(gnxr_camera);
+    case 3: return (int)sizeof(gnxr_medium);
+    case 4: return (int)sizeof(gnxr_scene_desc);
+    case 5: return (int)sizeof(gnxr_render_params);
+    case 6: return (int)sizeof(gnxr_stats);
+    case 7: return (int)sizeof(gnxr_ray);
+    case 8: return (int)sizeof(gnxr_hit);
+    default: return -1;
+    }
+}
 int gnxr_abi_version(void) { return GNXR_ABI_VERSION; }
 
 }  // extern "C"

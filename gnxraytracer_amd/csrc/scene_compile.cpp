@@ -440,13 +440,19 @@ static void dist1d(const float *f, int n, float *cdf /*n+1*/, float *funcInt) { 
     else for (int i = 1; i < n + 1; ++i) cdf[i] /= *funcInt;
 }
 
-static void build_env(const gnxr_scene_desc *d, const gnxr_light &l, CompiledScene *cs) {
+// flip_y: SkyBoxLight::loadImage switches stb_image to vertically flipped loading for the whole process
+// (stbi_set_flip_vertically_on_load(true), lights/SkyBoxLight.cpp:19); an InfiniteAreaLight constructed after
+// a SkyBoxLight -- the order of ui/RenderThread.cpp:145-151 -- therefore sees its map upside down.
+static void build_env(const gnxr_scene_desc *d, const gnxr_light &l, bool flip_y, CompiledScene *cs) {
     int w = d->env_width, h = d->env_height;
     std::vector<float> tex((size_t)w * h * 3);
-    for (size_t i = 0; i < (size_t)w * h; ++i)
-        for (int c = 0; c < 3; ++c) {  // texel = r * Sqrt(r), r = L * rgb (InfiniteAreaLight.cpp:33-41)
-            float r = l.le[c] * d->env_rgb[3 * i + c];
-            tex[3 * i + c] = r * std::sqrt(r);
+    for (int j = 0; j < h; ++j)
+        for (int i0 = 0; i0 < w; ++i0) {
+            size_t i = (size_t)j * w + i0, src = (size_t)(flip_y ? h - 1 - j : j) * w + i0;
+            for (int c = 0; c < 3; ++c) {  // texel = r * Sqrt(r), r = L * rgb (InfiniteAreaLight.cpp:33-41)
+                float r = l.le[c] * d->env_rgb[3 * src + c];
+                tex[3 * i + c] = r * std::sqrt(r);
+            }
         }
     int rx = w, ry = h;
     if ((rx & (rx - 1)) || (ry & (ry - 1))) {  // MIPMap ctor resample, MIPMap.h:93-146 (wrap = Repeat)
@@ -596,7 +602,9 @@ bool compile_scene(const gnxr_scene_desc *d, CompiledScene *cs) {
             if (!d->env_rgb || d->env_width <= 0 || d->env_height <= 0) { set_error("INFINITE light without env map"); return false; }
             if (cs->has_env) { set_error("only one INFINITE light is supported"); return false; }
             dl.env = 1;
-            build_env(d, l, cs);
+            bool flip_y = false;
+            for (int k = 0; k < i; ++k) if (d->lights[k].type == GNXR_LIGHT_SKYBOX) flip_y = true;
+            build_env(d, l, flip_y, cs);
             cs->infinite_lights.push_back(i);
         } else if (l.type == GNXR_LIGHT_SKYBOX) {
             memcpy(dl.center, l.center, 12);

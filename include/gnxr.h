@@ -219,6 +219,7 @@ typedef struct gnxr_scene gnxr_scene;
 
 /* -- lifecycle ---------------------------------------------------------------------- */
 int gnxr_abi_version(void);
+int gnxr_abi_sizeof(int which);        /* sizeof of the structs above in declaration order (binding self-check) */
 int gnxr_init(int device_id);          /* binds the calling process to one HIP device    */
 void gnxr_shutdown(void);
 const char *gnxr_last_error(void);

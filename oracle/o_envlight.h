@@ -132,7 +132,10 @@ struct InfiniteAreaLight {
     Float worldRadius = 0;
     // InfiniteAreaLight.cpp:12-82.  env_rgb is the decoded .hdr (what stbi_loadf returns); texels =
     // (L*rgb)^1.5 (`r * Sqrt(r)`, :41).
-    InfiniteAreaLight(const gnxr_light &l, const float *rgb, int w, int h) {
+    // flipY: SkyBoxLight::loadImage calls stbi_set_flip_vertically_on_load(true) (SkyBoxLight.cpp:19), a
+    // process-wide stb_image switch, so an InfiniteAreaLight constructed AFTER a SkyBoxLight (the order of
+    // ui/RenderThread.cpp:145-151) decodes its map upside down.
+    InfiniteAreaLight(const gnxr_light &l, const float *rgb, int w, int h, bool flipY = false) {
         lightToWorld = M44::FromRowMajor(l.light_to_world);
         worldToLight = Inverse(lightToWorld);
         std::vector<Spec> texels;
@@ -142,9 +145,10 @@ struct InfiniteAreaLight {
             for (int j = 0; j < h; j++)
                 for (int i = 0; i < w; i++) {
                     Spec r;
-                    r[0] = l.le[0] * rgb[(i + j * w) * 3 + 0];
-                    r[1] = l.le[1] * rgb[(i + j * w) * 3 + 1];
-                    r[2] = l.le[2] * rgb[(i + j * w) * 3 + 2];
+                    int js = flipY ? (h - 1 - j) : j;
+                    r[0] = l.le[0] * rgb[(i + js * w) * 3 + 0];
+                    r[1] = l.le[1] * rgb[(i + js * w) * 3 + 1];
+                    r[2] = l.le[2] * rgb[(i + js * w) * 3 + 2];
                     texels[i + j * w] = r * Sqrt(r);
                 }
         } else {
@@ -215,7 +219,9 @@ inline Spec SkyBoxLe(const gnxr_light &l, const Ray &ray) {
     float discriminant = b * b - 4 * a * c;
     float t;
     if (discriminant < 0) return Spec(0.f);
-    t = (-b + ::sqrt((double)discriminant)) / (2.0 * a);  // unqualified sqrt -> double
+    // SkyBoxLight.cpp pulls in <math.h> through 3rd/stb_image.h, so the unqualified sqrt(float) binds to the float
+    // overload there (unlike MicroFacet.cpp / DisneyMaterial.cpp); the division by `2.0 * a` is a double expression.
+    t = (-b + std::sqrt(discriminant)) / (2.0 * a);
     V3 hitPos = ray.o + t * ray.d;
     V3 hitPos_temp = hitPos - worldCenter;
     Spec Col;

@@ -103,7 +103,9 @@ struct RenderContext {
             else {
                 infiniteLights.push_back(i);
                 if (l.type == GNXR_LIGHT_INFINITE) {
-                    envLights[i].reset(new InfiniteAreaLight(l, s->envRgb.data(), s->envW, s->envH));
+                    bool flipY = false;  // a SkyBoxLight built earlier switched stb_image to flipped loading
+                    for (int k = 0; k < i; ++k) if (s->lights[k].type == GNXR_LIGHT_SKYBOX) flipY = true;
+                    envLights[i].reset(new InfiniteAreaLight(l, s->envRgb.data(), s->envW, s->envH, flipY));
                     envLights[i]->Preprocess(worldBound);  // Scene ctor -> light->Preprocess(*this)
                 }
             }

@@ -1,0 +1,105 @@
+"""Host-side logic that runs without a GPU: scene authoring (ModelList/MaterialList mirror), `.3d` IO,
+sharding arithmetic, argument validation of the oracle side of the harness."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import scenes
+from conftest import GOLDEN
+
+
+def test_cornell_authoring_matches_modellist(gx):
+    b = scenes.cornell()
+    d = b.desc()
+    assert (d.n_triangles, d.n_vertices, d.n_materials, d.n_lights) == (12, 36, 3, 2)       # ModelList.cpp:71-147
+    v = np.ctypeslib.as_array(d.vertices, shape=(d.n_vertices, 3))
+    assert v[:30].min() == -2.5 and v[:30].max() == 2.5                                       # box side 5 centred at origin
+    assert np.allclose(v[30:, 1], 2.45) and np.abs(v[30:, [0, 2]]).max() == np.float32(1.4)  # light quad, ModelList.cpp:125-129
+    mats = np.ctypeslib.as_array(d.tri_material, shape=(12,))
+    assert list(mats) == [0, 0, 0, 0, 0, 0, 1, 1, 2, 2, 0, 0]                                # tris 6,7 red; 8,9 blue
+    lights = np.ctypeslib.as_array(d.tri_light, shape=(12,))
+    assert list(lights[10:]) == [0, 1] and (lights[:10] == -1).all()
+    assert d.lights[0].le[0] == 5.0 and d.lights[0].two_sided == 0
+    cam = d.camera
+    assert tuple(cam.eye) == (0.0, 0.0, 5.0) and cam.fov_deg == 90.0 and cam.lens_radius == 0.0  # RenderThread.cpp:60-68
+
+
+def test_material_factories(gx):
+    b = gx.SceneBuilder()
+    p, m, g = b.getPurplePlasticMaterial(), b.getYelloMetalMaterial(), b.getWhiteGlassMaterial()
+    d = b.desc()
+    assert np.allclose(list(d.materials[p].kd), [0.35, 0.12, 0.48]) and d.materials[p].remap_roughness == 1
+    assert np.allclose(list(d.materials[p].ks), [0.65, 0.88, 0.52])
+    assert np.allclose(list(d.materials[m].eta), [0.2, 0.2, 0.8]) and d.materials[m].urough == np.float32(0.15)
+    assert d.materials[g].eta[0] == 1.5 and d.materials[g].remap_roughness == 0 and d.materials[g].urough == np.float32(0.1)
+    assert all(d.materials[i].has_bump == 1 for i in (p, m, g))
+
+
+def test_synthetic_mesh_is_deterministic_and_loader_scales(tmp_path, gx):
+    a, b2 = tmp_path / "a.3d", tmp_path / "b.3d"
+    gx.write_synthetic_3d(str(a), 2000, 7)
+    gx.write_synthetic_3d(str(b2), 2000, 7)
+    assert a.read_bytes() == b2.read_bytes() == open(os.path.join(GOLDEN, "mesh_2k.3d"), "rb").read()
+    head = a.read_text().split("\n")[:2]
+    assert head[0].startswith("vertex ") and head[1].startswith("face ")                   # plyRead.h:23-28
+    b = gx.SceneBuilder()
+    m = b.MatteMaterial((0.5, 0.5, 0.5))
+    b.AddModel(str(a), m)
+    d = b.desc()
+    raw = np.loadtxt(str(a), skiprows=2, max_rows=d.n_vertices, dtype=np.float32)
+    v = np.ctypeslib.as_array(d.vertices, shape=(d.n_vertices, 3))
+    expect = raw * np.float32(20)
+    expect[:, 1] = expect[:, 1] + np.float32(-2.9)                                          # x20 (plyRead.h:38), y-2.9 (ModelList.cpp:56)
+    assert (v == expect).all()
+    assert v.min() > -2.5 and v.max() < 2.5                                                  # sits inside the box
+
+
+def test_bad_inputs_are_rejected(gx, tmp_path):
+    b = gx.SceneBuilder()
+    with pytest.raises(gx.GnxrError):
+        b.AddModel(str(tmp_path / "missing.3d"), 0)
+    with pytest.raises(gx.GnxrError):
+        b.add_mesh([[0, 0, 0], [1, 0, 0], [0, 1, 0]], [[0, 1, 5]], 0)     # index out of range
+    with pytest.raises(gx.GnxrError):
+        b.AddInfLight(str(tmp_path / "missing.hdr"))
+
+
+def test_shard_rows_partition_the_image():
+    from gnxraytracer_amd.distributed import shard_row_index
+    for H, world, sr in [(1080, 8, 1), (1080, 7, 1), (270, 4, 8), (5, 8, 1), (64, 2, 3)]:
+        rows = [shard_row_index(H, r, world, sr) for r in range(world)]
+        assert sorted(sum(rows, [])) == list(range(H))
+
+
+def test_oracle_sharded_render_equals_full(gx):
+    """Every pixel depends only on (x, y, sample): shards and spp ranges recombine bit-exactly."""
+    b = scenes.cornell()
+    osc = ol.OracleScene(b)
+    integ = gx.PathIntegrator(8, 1.0, "spatial")
+    full, st = osc.render(integ, 48, 40, 8)
+    acc = np.zeros_like(full)
+    rays = 0
+    for r in range(3):
+        part, s = osc.render(integ, 48, 40, 8, shard_index=r, shard_count=3, shard_rows=2)
+        acc += part
+        rays += s["rays_closest"] + s["rays_any"]
+    assert (acc.view(np.uint32) == full.view(np.uint32)).all()
+    assert rays == st["rays_closest"] + st["rays_any"]
+
+
+def test_oracle_edge_cases(gx):
+    integ0 = gx.PathIntegrator(0, 1.0, "spatial")
+    b = scenes.cornell()
+    osc = ol.OracleScene(b)
+    img, st = osc.render(integ0, 8, 8, 2)                         # maxDepth 0: emission of directly seen lights only
+    assert st["rays_any"] == 0 and st["rays_closest"] == 8 * 8 * 2
+    img1, _ = osc.render(gx.PathIntegrator(8), 1, 1, 4)             # 1x1 image
+    assert np.isfinite(img1).all()
+    # rays that start outside and point away miss everything
+    rays = gx.make_rays([[0, 0, 100]] * 4, [[0, 0, 1]] * 4)
+    assert (osc.Intersect(rays)["prim"] == -1).all() and (osc.IntersectP(rays) == 0).all()
+    # zero-length batch
+    assert len(osc.Intersect(np.zeros((0, 8), np.float32))) == 0
