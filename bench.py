@@ -190,11 +190,9 @@ def main():
         nr = stc["rays_closest"] + stc["rays_any"]
         n_nodes, n_tris = stc["nodes_visited"] / nr, stc["tris_tested"] / nr
         b_ray = 136.0 + 32.0 * n_nodes + 48.0 * n_tris
-        rays_k_closest = tot["rays_closest"] - tot["rays_closest_nee"]
-        rays_k_nee = tot["rays_any"] + tot["rays_closest_nee"]
-        kern = [("k_closest", tot["seconds_closest"], tot["launches_closest"], rays_k_closest),
-                ("k_nee", tot["seconds_nee"], tot["launches_nee"], rays_k_nee)]
-        name, secs, launches, krays = max(kern, key=lambda k: k[1])
+        # k_trace traces every ray of the pass (continuation, shadow and MIS rays); seconds_closest / launches_closest
+        # are its HIP-event time and launch count
+        name, secs, launches, krays = "k_trace", tot["seconds_closest"], tot["launches_closest"], rays
         achieved = krays * b_ray / secs / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -206,7 +204,7 @@ def main():
         result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                               "traffic": traffic, "kernel": name, "launches": launches, "avg_launch_ms": secs / launches * 1e3,
                               "rays_per_launch": krays / launches, "bytes_per_ray": b_ray, "nodes_per_ray": n_nodes, "tris_per_ray": n_tris,
-                              "kernel_seconds": {"k_closest": tot["seconds_closest"], "k_nee": tot["seconds_nee"], "k_shade": tot["seconds_shade"]},
+                              "kernel_seconds": {"k_trace": tot["seconds_closest"], "k_nee_combine": tot["seconds_nee"], "k_shade": tot["seconds_shade"]},
                               "note": "algorithmic bytes (SURVEY 8d) / HIP-event kernel time; the 11 MB BVH lives in L2/Infinity Cache, "
                                       "so measured HBM traffic is far below the algorithmic figure"}
     if args.save_image and rank == 0:

@@ -118,7 +118,7 @@ struct gnxr_scene {
     // per-render state (grown on demand)
     DevBuf<float4> ray_o, ray_d, beta, L, sh_o, sh_d, sh_X, mis_o, mis_d, mis_Y, nbeta, accum, out;
     DevBuf<uint2> meta;
-    DevBuf<int> hit, queue_a, queue_b, queue_nee;
+    DevBuf<int> hit, queue_a, queue_b, queue_nee, queue_shadow, queue_mis;
     DevBuf<Counters> counters;
     Counters *h_counters = nullptr;  // pinned
     int stack_size = 32;
@@ -180,7 +180,7 @@ int gnxr_scene_create(const gnxr_scene_desc *desc, gnxr_scene **out) {
     if (!compile_scene(desc, &s->cs)) { delete s; return GNXR_ERR_INVALID; }
     CompiledScene &cs = s->cs;
     if (cs.bvh_max_depth + 1 > 64) { set_error("BVH depth %d exceeds the 64-entry traversal stack (BVHAccel.cpp:661)", cs.bvh_max_depth); delete s; return GNXR_ERR_UNSUPPORTED; }
-    s->stack_size = cs.bvh_max_depth + 1 <= 32 ? 32 : 64;
+    s->stack_size = cs.bvh_max_depth + 1 <= 24 ? 24 : (cs.bvh_max_depth + 1 <= 32 ? 32 : 64);
 #define UP(field) if ((rc = s->field.upload(cs.field)) != GNXR_OK) { delete s; return rc; }
     UP(nodes) UP(tris) UP(materials) UP(lights) UP(perms) UP(primes) UP(prime_sums) UP(prime_magic)
     UP(env_texels) UP(env_cond_func) UP(env_cond_cdf) UP(env_cond_int) UP(env_marg_func) UP(env_marg_cdf)
@@ -246,7 +246,7 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     size_t cap = (size_t)r.npix * k;
     if (cap >= (1ull << 31)) { set_error("pass too large"); return GNXR_ERR_INVALID; }
 #define AL(f) if ((rc = s->f.alloc(cap)) != GNXR_OK) return rc;
-    AL(ray_o) AL(ray_d) AL(beta) AL(L) AL(sh_o) AL(sh_d) AL(sh_X) AL(mis_o) AL(mis_d) AL(mis_Y) AL(nbeta) AL(meta) AL(hit) AL(queue_a) AL(queue_b) AL(queue_nee)
+    AL(ray_o) AL(ray_d) AL(beta) AL(L) AL(sh_o) AL(sh_d) AL(sh_X) AL(mis_o) AL(mis_d) AL(mis_Y) AL(nbeta) AL(meta) AL(hit) AL(queue_a) AL(queue_b) AL(queue_nee) AL(queue_shadow) AL(queue_mis)
 #undef AL
     if ((rc = s->accum.alloc(r.npix)) != GNXR_OK) return rc;
     PathArrays pa;
@@ -259,9 +259,8 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     HIP_TRY(hipEventCreate(&ev0));
     HIP_TRY(hipEventCreate(&ev1));
     HIP_TRY(hipEventRecord(ev0, stream));
-    unsigned long long rays_closest = 0;
+    unsigned long long rays_closest = 0, rays_any = 0, rays_mis = 0;
     unsigned int launches = 0, passes = 0;
-    const bool big = s->stack_size > 32;
     const bool timing = (g_profiling & 1) != 0, counting = (g_profiling & 2) != 0;
     KernelTimer timer;
     Counters *dctr = s->counters.p;
@@ -274,37 +273,42 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
         const int *q_in = nullptr;
         int *q_cur = s->queue_a.p, *q_other = s->queue_b.p;
         int guard = 0;
-        while (n > 0) {
+        auto launch_trace = [&](TraceWork w) {
+            long long total = (long long)w.n_closest + w.n_shadow + w.n_mis;
+            if (total <= 0) return;
+            (void)hipMemsetAsync(&dctr->cursor, 0, sizeof(unsigned int), stream);
+            int per_cu = s->stack_size == 24 ? 6 : (s->stack_size == 32 ? 5 : 2);
+            // persistent waves: enough blocks to fill the chip, never more than the work needs
+            int blocks = (int)std::min<long long>((long long)g_num_cus * per_cu, (total + kBlock - 1) / kBlock);
             if (timing) timer.begin(0, stream);
-            if (counting) {
-                if (big) hipLaunchKernelGGL((k_closest<64, true>), dim3(grid_for(n, 2)), dim3(kBlock), 0, stream, sc, pa, q_in, n, dctr);
-                else hipLaunchKernelGGL((k_closest<32, true>), dim3(grid_for(n, 5)), dim3(kBlock), 0, stream, sc, pa, q_in, n, dctr);
-            } else {
-                if (big) hipLaunchKernelGGL((k_closest<64, false>), dim3(grid_for(n, 2)), dim3(kBlock), 0, stream, sc, pa, q_in, n, dctr);
-                else hipLaunchKernelGGL((k_closest<32, false>), dim3(grid_for(n, 5)), dim3(kBlock), 0, stream, sc, pa, q_in, n, dctr);
-            }
-            if (timing) { timer.end(stream); timer.begin(2, stream); }
-            rays_closest += (unsigned long long)n;
-            hipLaunchKernelGGL(k_shade, dim3(grid_for(n)), dim3(kBlock), 0, stream, sc, r, pa, q_in, n, q_cur, s->queue_nee.p, dctr);
+#define GX_LAUNCH_TRACE(ST, CNT) hipLaunchKernelGGL((k_trace<ST, CNT>), dim3(blocks), dim3(kBlock), 0, stream, sc, pa, w, &dctr->cursor, dctr)
+            if (counting) { if (s->stack_size == 24) GX_LAUNCH_TRACE(24, true); else if (s->stack_size == 32) GX_LAUNCH_TRACE(32, true); else GX_LAUNCH_TRACE(64, true); }
+            else { if (s->stack_size == 24) GX_LAUNCH_TRACE(24, false); else if (s->stack_size == 32) GX_LAUNCH_TRACE(32, false); else GX_LAUNCH_TRACE(64, false); }
+#undef GX_LAUNCH_TRACE
             if (timing) timer.end(stream);
-            launches += 2;
+            rays_closest += (unsigned long long)w.n_closest + (unsigned long long)w.n_mis;
+            rays_any += (unsigned long long)w.n_shadow;
+            rays_mis += (unsigned long long)w.n_mis;
+            ++launches;
+        };
+        launch_trace(TraceWork{nullptr, n, nullptr, 0, nullptr, 0});   // camera rays
+        while (n > 0) {
+            if (timing) timer.begin(2, stream);
+            hipLaunchKernelGGL(k_shade, dim3(grid_for(n)), dim3(kBlock), 0, stream, sc, r, pa, q_in, n, q_cur, s->queue_nee.p, s->queue_shadow.p, s->queue_mis.p, dctr);
+            if (timing) timer.end(stream);
+            ++launches;
             HIP_TRY(hipMemcpyAsync(s->h_counters, dctr, sizeof(Counters), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             int n_next = (int)s->h_counters->q_next, n_nee = (int)s->h_counters->q_nee;
+            int n_sh = (int)s->h_counters->q_shadow, n_mis = (int)s->h_counters->q_mis;
+            HIP_TRY(hipMemsetAsync(&dctr->q_next, 0, 4 * sizeof(unsigned int), stream));
+            launch_trace(TraceWork{q_cur, n_next, s->queue_shadow.p, n_sh, s->queue_mis.p, n_mis});
             if (n_nee > 0) {
                 if (timing) timer.begin(1, stream);
-                if (counting) {
-                    if (big) hipLaunchKernelGGL((k_nee<64, true>), dim3(grid_for(n_nee, 2)), dim3(kBlock), 0, stream, sc, pa, (const int *)s->queue_nee.p, n_nee, dctr);
-                    else hipLaunchKernelGGL((k_nee<32, true>), dim3(grid_for(n_nee, 5)), dim3(kBlock), 0, stream, sc, pa, (const int *)s->queue_nee.p, n_nee, dctr);
-                } else {
-                    if (big) hipLaunchKernelGGL((k_nee<64, false>), dim3(grid_for(n_nee, 2)), dim3(kBlock), 0, stream, sc, pa, (const int *)s->queue_nee.p, n_nee, dctr);
-                    else hipLaunchKernelGGL((k_nee<32, false>), dim3(grid_for(n_nee, 5)), dim3(kBlock), 0, stream, sc, pa, (const int *)s->queue_nee.p, n_nee, dctr);
-                }
+                hipLaunchKernelGGL(k_nee_combine, dim3(grid_for(n_nee)), dim3(kBlock), 0, stream, pa, (const int *)s->queue_nee.p, n_nee);
                 if (timing) timer.end(stream);
                 ++launches;
             }
-            // reset the two queue counters (they sit behind the 64-bit ray counters)
-            HIP_TRY(hipMemsetAsync(&dctr->q_next, 0, 2 * sizeof(unsigned int), stream));
             q_in = q_cur;
             std::swap(q_cur, q_other);
             n = n_next;
@@ -327,8 +331,8 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     (void)hipEventDestroy(ev1);
     if (stats) {
         memset(stats, 0, sizeof(*stats));
-        stats->rays_closest = rays_closest + s->h_counters->rays_closest;
-        stats->rays_any = s->h_counters->rays_any;
+        stats->rays_closest = rays_closest;
+        stats->rays_any = rays_any;
         stats->camera_samples = (uint64_t)r.npix * nsamples;
         stats->nodes_visited = s->h_counters->nodes;
         stats->tris_tested = s->h_counters->tris;
@@ -339,7 +343,7 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
         stats->seconds_closest = timer.seconds[0]; stats->seconds_nee = timer.seconds[1]; stats->seconds_shade = timer.seconds[2];
         stats->seconds_trace = timer.seconds[0] + timer.seconds[1];
         stats->launches_closest = timer.launches[0]; stats->launches_nee = timer.launches[1];
-        stats->rays_closest_nee = s->h_counters->rays_closest;
+        stats->rays_closest_nee = rays_mis;
     }
     return GNXR_OK;
 }

@@ -4,10 +4,11 @@
 //
 //   k_raygen        Sampler::GetCameraSample + PerspectiveCamera::GenerateRayDifferential      (A2, A4)
 //   loop over path vertices:
-//     k_closest     BVHAccel::Intersect for the continuation rays                              (A5, A6)
+//     k_trace       BVHAccel::Intersect / IntersectP for the continuation, shadow and MIS rays   (A5, A6)
+//                   (trace_kernel.hip.h)
+//     k_nee_combine L += beta * Ld once the two visibility results of the vertex are known       (A16)
 //     k_shade       PathIntegrator::Li body at one vertex: Le, BSDF, UniformSampleOneLight set-up
 //                   (shadow ray + MIS ray records), BSDF sampling, Russian roulette, compaction  (A7-A21)
-//     k_nee         BVHAccel::IntersectP (shadow) + BVHAccel::Intersect (MIS) and L += beta * Ld (A16)
 //   k_resolve       colObj += Li in sample order, box average                                   (A1)
 //
 // State is SoA-of-float4 in HBM (one dwordx4 per lane per field, coalesced); queues hold path slots and
@@ -39,9 +40,10 @@ struct PathArrays {
 };
 
 struct Counters {
-    unsigned long long rays_closest, rays_any, nodes, tris;
-    unsigned int q_next, q_nee;
-    unsigned int _pad[2];
+    unsigned long long nodes, tris;
+    unsigned int q_next, q_nee, q_shadow, q_mis;   // queue fill counts of the current vertex
+    unsigned int cursor;                            // k_trace work cursor
+    unsigned int _pad[3];
 };
 
 struct DScene {
@@ -59,6 +61,10 @@ struct DRender {
     int shard_index, shard_count, shard_rows;
     int npix;       // pixels owned by this shard (local rows * W)
 };
+
+}  // namespace gnxr
+#include "trace_kernel.hip.h"
+namespace gnxr {
 
 // local pixel -> raster coordinates for the row-interleaved sharding
 GX_DEV void local_pixel(const DRender &r, int lp, int *x, int *y) {
@@ -133,24 +139,6 @@ __global__ void __launch_bounds__(kBlock) k_raygen(DScene sc, DRender r, PathArr
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int STACK, bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_closest(DScene sc, PathArrays pa, const int *__restrict__ queue, int n, Counters *ctr) {
-    __shared__ int stack[STACK * kBlock];
-    TraceCounters tc = {0, 0};
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        int path = queue ? queue[i] : i;
-        float4 o4 = pa.ray_o[path], d4 = pa.ray_d[path];
-        TriHit h;
-        int leaf = bvh_traverse<false, kBlock, COUNT>(sc.nodes, sc.tris, V3(o4.x, o4.y, o4.z), V3(d4.x, d4.y, d4.z), o4.w, &stack[threadIdx.x], &h, &tc);
-        pa.hit[path] = leaf;
-    }
-    if (COUNT) {
-        atomicAdd(&ctr->nodes, (unsigned long long)tc.nodes);
-        atomicAdd(&ctr->tris, (unsigned long long)tc.tris);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 GX_DEV void wave_append(int *queue, unsigned int *counter, bool pred, int value) {
     unsigned long long mask = __ballot(pred);
     if (mask == 0) return;
@@ -163,12 +151,12 @@ GX_DEV void wave_append(int *queue, unsigned int *counter, bool pred, int value)
 }
 
 __global__ void __launch_bounds__(kBlock) k_shade(DScene sc, DRender r, PathArrays pa, const int *__restrict__ queue, int n, int *queue_next, int *queue_nee,
-                                                  Counters *ctr) {
+                                                  int *queue_shadow, int *queue_mis, Counters *ctr) {
     int nIter = (n + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
     for (int it = 0; it < nIter; ++it) {
         int i = it * gridDim.x * blockDim.x + blockIdx.x * blockDim.x + threadIdx.x;
         bool active = i < n;
-        bool survive = false, wantNee = false;
+        bool survive = false, wantNee = false, wantShadow = false, wantMis = false;
         int path = -1;
         if (active) {
             path = queue ? queue[i] : i;
@@ -289,6 +277,8 @@ __global__ void __launch_bounds__(kBlock) k_shade(DScene sc, DRender r, PathArra
                                 }
                                 pa.nbeta[path] = make_float4(beta.r, beta.g, beta.b, 0.f);
                                 wantNee = true;
+                                wantShadow = (nflags & 1) != 0;
+                                wantMis = (nflags & 2) != 0;
                             }
                         }
                     }
@@ -327,49 +317,8 @@ __global__ void __launch_bounds__(kBlock) k_shade(DScene sc, DRender r, PathArra
         }
         wave_append(queue_next, &ctr->q_next, survive, path);
         wave_append(queue_nee, &ctr->q_nee, wantNee, path);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-template <int STACK, bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_nee(DScene sc, PathArrays pa, const int *__restrict__ queue, int n, Counters *ctr) {
-    __shared__ int stack[STACK * kBlock];
-    TraceCounters tc = {0, 0};
-    unsigned int nAny = 0, nClosest = 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        int path = queue[i];
-        float4 sd4 = pa.sh_d[path], X4 = pa.sh_X[path];
-        int flags = __float_as_int(sd4.w);
-        Spec Ld(0.f);
-        TriHit h;
-        if (flags & 1) {
-            float4 so4 = pa.sh_o[path];
-            int leaf = bvh_traverse<true, kBlock, COUNT>(sc.nodes, sc.tris, V3(so4.x, so4.y, so4.z), V3(sd4.x, sd4.y, sd4.z), so4.w, &stack[threadIdx.x], &h, &tc);
-            ++nAny;
-            if (leaf < 0) Ld = Ld + Spec(X4.x, X4.y, X4.z);
-        }
-        if (flags & 2) {
-            float4 mo4 = pa.mis_o[path], md4 = pa.mis_d[path], Y4 = pa.mis_Y[path];
-            int expect = __float_as_int(mo4.w);
-            int leaf = bvh_traverse<false, kBlock, COUNT>(sc.nodes, sc.tris, V3(mo4.x, mo4.y, mo4.z), V3(md4.x, md4.y, md4.z), GX_INF, &stack[threadIdx.x], &h, &tc);
-            ++nClosest;
-            bool ok = (expect >= 0) ? (leaf == expect) : (leaf < 0);
-            Spec Y(Y4.x, Y4.y, Y4.z);
-            if (ok && !Y.is_black()) Ld = Ld + Y;
-        }
-        float4 nb = pa.nbeta[path], L4 = pa.L[path];
-        Spec add = Spec(nb.x, nb.y, nb.z) * (Ld / X4.w);
-        pa.L[path] = make_float4(L4.x + add.r, L4.y + add.g, L4.z + add.b, 0.f);
-    }
-    // one atomic per wave for the ray counters
-    for (int off = 32; off > 0; off >>= 1) { nAny += __shfl_down(nAny, off); nClosest += __shfl_down(nClosest, off); }
-    if (__lane_id() == 0) {
-        if (nAny) atomicAdd(&ctr->rays_any, (unsigned long long)nAny);
-        if (nClosest) atomicAdd(&ctr->rays_closest, (unsigned long long)nClosest);
-    }
-    if (COUNT) {
-        atomicAdd(&ctr->nodes, (unsigned long long)tc.nodes);
-        atomicAdd(&ctr->tris, (unsigned long long)tc.tris);
+        wave_append(queue_shadow, &ctr->q_shadow, wantShadow, path);
+        wave_append(queue_mis, &ctr->q_mis, wantMis, path);
     }
 }
 
