@@ -118,7 +118,9 @@ struct gnxr_scene {
     // per-render state (grown on demand)
     DevBuf<float4> ray_o, ray_d, beta, L, sh_o, sh_d, sh_X, mis_o, mis_d, mis_Y, nbeta, accum, out;
     DevBuf<uint2> meta;
-    DevBuf<int> hit, queue_a, queue_b, queue_nee, queue_shadow, queue_mis;
+    DevBuf<int> hit, queue_a, queue_b, queue_nee, queue_c0, queue_c1, queue_c2;
+    DevBuf<unsigned char> pflags, pclass;
+    DevBuf<unsigned int> tile_counts;
     DevBuf<Counters> counters;
     Counters *h_counters = nullptr;  // pinned
     int stack_size = 32;
@@ -246,11 +248,13 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     size_t cap = (size_t)r.npix * k;
     if (cap >= (1ull << 31)) { set_error("pass too large"); return GNXR_ERR_INVALID; }
 #define AL(f) if ((rc = s->f.alloc(cap)) != GNXR_OK) return rc;
-    AL(ray_o) AL(ray_d) AL(beta) AL(L) AL(sh_o) AL(sh_d) AL(sh_X) AL(mis_o) AL(mis_d) AL(mis_Y) AL(nbeta) AL(meta) AL(hit) AL(queue_a) AL(queue_b) AL(queue_nee) AL(queue_shadow) AL(queue_mis)
+    AL(ray_o) AL(ray_d) AL(beta) AL(L) AL(sh_o) AL(sh_d) AL(sh_X) AL(mis_o) AL(mis_d) AL(mis_Y) AL(nbeta) AL(meta) AL(hit) AL(queue_a) AL(queue_b) AL(queue_nee) AL(queue_c0) AL(queue_c1) AL(queue_c2) AL(pflags) AL(pclass)
 #undef AL
     if ((rc = s->accum.alloc(r.npix)) != GNXR_OK) return rc;
+    const int max_tiles = (int)((cap + kCompactBlock - 1) / kCompactBlock);
+    if ((rc = s->tile_counts.alloc((size_t)4 * max_tiles)) != GNXR_OK) return rc;
     PathArrays pa;
-    pa.ray_o = s->ray_o.p; pa.ray_d = s->ray_d.p; pa.beta = s->beta.p; pa.L = s->L.p; pa.meta = s->meta.p; pa.hit = s->hit.p;
+    pa.ray_o = s->ray_o.p; pa.ray_d = s->ray_d.p; pa.beta = s->beta.p; pa.L = s->L.p; pa.meta = s->meta.p; pa.hit = s->hit.p; pa.pflags = s->pflags.p; pa.pclass = s->pclass.p;
     pa.sh_o = s->sh_o.p; pa.sh_d = s->sh_d.p; pa.sh_X = s->sh_X.p; pa.mis_o = s->mis_o.p; pa.mis_d = s->mis_d.p; pa.mis_Y = s->mis_Y.p; pa.nbeta = s->nbeta.p;
 
     HIP_TRY(hipMemsetAsync(s->accum.p, 0, sizeof(float4) * r.npix, stream));
@@ -262,6 +266,10 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     unsigned long long rays_closest = 0, rays_any = 0, rays_mis = 0;
     unsigned int launches = 0, passes = 0;
     const bool timing = (g_profiling & 1) != 0, counting = (g_profiling & 2) != 0;
+    int class_mask = 0;
+    for (const DMaterial &m : s->cs.materials) class_mask |= 1 << m.shade_class;
+    bool area_only = true;
+    for (const gnxr_light &l : s->cs.desc_lights) if (l.type != GNXR_LIGHT_AREA_TRI) area_only = false;
     KernelTimer timer;
     Counters *dctr = s->counters.p;
     for (int s0 = p.spp_begin; s0 < p.spp_end; s0 += k) {
@@ -270,11 +278,11 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
         hipLaunchKernelGGL(k_raygen, dim3(grid_for(n_paths)), dim3(kBlock), 0, stream, sc, r, pa, n_paths, s0);
         ++launches;
         int n = n_paths;
-        const int *q_in = nullptr;
+        const int *q_in = nullptr;            // paths alive at this vertex (nullptr == identity), ascending
         int *q_cur = s->queue_a.p, *q_other = s->queue_b.p;
         int guard = 0;
-        auto launch_trace = [&](TraceWork w) {
-            long long total = (long long)w.n_closest + w.n_shadow + w.n_mis;
+        auto launch_trace = [&](TraceWork w, int n_sh, int n_mis) {
+            long long total = (long long)w.n_closest + 2ll * w.n_nee;
             if (total <= 0) return;
             (void)hipMemsetAsync(&dctr->cursor, 0, sizeof(unsigned int), stream);
             int per_cu = s->stack_size == 24 ? 6 : (s->stack_size == 32 ? 5 : 2);
@@ -286,23 +294,51 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
             else { if (s->stack_size == 24) GX_LAUNCH_TRACE(24, false); else if (s->stack_size == 32) GX_LAUNCH_TRACE(32, false); else GX_LAUNCH_TRACE(64, false); }
 #undef GX_LAUNCH_TRACE
             if (timing) timer.end(stream);
-            rays_closest += (unsigned long long)w.n_closest + (unsigned long long)w.n_mis;
-            rays_any += (unsigned long long)w.n_shadow;
-            rays_mis += (unsigned long long)w.n_mis;
+            rays_closest += (unsigned long long)w.n_closest + (unsigned long long)n_mis;
+            rays_any += (unsigned long long)n_sh;
+            rays_mis += (unsigned long long)n_mis;
             ++launches;
         };
-        launch_trace(TraceWork{nullptr, n, nullptr, 0, nullptr, 0});   // camera rays
+        // stream compaction (compact_kernel.hip.h): count -> scan -> scatter, no global atomics
+        auto compact = [&](int mode, const int *qin, int nin, const unsigned char *keys, int nout, int nscatter, unsigned int *totals, int *o0, int *o1, int *o2) {
+            int tiles = (nin + kCompactBlock - 1) / kCompactBlock;
+            int g = std::min(tiles, g_num_cus * 8);
+            if (mode == COMPACT_FLAGS) hipLaunchKernelGGL((k_compact_count<COMPACT_FLAGS, 4>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles);
+            else hipLaunchKernelGGL((k_compact_count<COMPACT_CLASS, 3>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles);
+            hipLaunchKernelGGL(k_compact_scan, dim3(nout), dim3(1024), 0, stream, s->tile_counts.p, tiles, totals);
+            if (mode == COMPACT_FLAGS) hipLaunchKernelGGL((k_compact_scatter<COMPACT_FLAGS, 2>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, (const unsigned int *)s->tile_counts.p, tiles, o0, o1, o2);
+            else hipLaunchKernelGGL((k_compact_scatter<COMPACT_CLASS, 3>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, (const unsigned int *)s->tile_counts.p, tiles, o0, o1, o2);
+            launches += 3;
+        };
+        launch_trace(TraceWork{nullptr, n, nullptr, 0}, 0, 0);   // camera rays
         while (n > 0) {
             if (timing) timer.begin(2, stream);
-            hipLaunchKernelGGL(k_shade, dim3(grid_for(n)), dim3(kBlock), 0, stream, sc, r, pa, q_in, n, q_cur, s->queue_nee.p, s->queue_shadow.p, s->queue_mis.p, dctr);
+            // bin the paths by the shade specialisation of the material they hit (pclass written by k_trace)
+            compact(COMPACT_CLASS, q_in, n, s->pclass.p, 3, 3, &dctr->q_class[0], s->queue_c0.p, s->queue_c1.p, s->queue_c2.p);
+            {
+                int *qc[3] = {s->queue_c0.p, s->queue_c1.p, s->queue_c2.p};
+                dim3 g(grid_for(n)), b(kBlock);
+#define GX_SHADE(LMV, LTV, C) hipLaunchKernelGGL((k_shade<LMV, LTV>), g, b, 0, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C])
+                if (area_only) {
+                    GX_SHADE(LM_DIFFUSE, LT_AREA, 0);
+                    if (class_mask & 2) GX_SHADE(LM_GLOSSY, LT_AREA, 1);
+                    if (class_mask & 4) GX_SHADE(LM_ALL, LT_AREA, 2);
+                } else {
+                    GX_SHADE(LM_DIFFUSE, LT_ALL, 0);
+                    if (class_mask & 2) GX_SHADE(LM_GLOSSY, LT_ALL, 1);
+                    if (class_mask & 4) GX_SHADE(LM_ALL, LT_ALL, 2);
+                }
+#undef GX_SHADE
+                launches += 1 + ((class_mask & 2) ? 1 : 0) + ((class_mask & 4) ? 1 : 0);
+            }
+            // next-vertex queue + NEE queue from the per-path flags; totals also count shadow and MIS rays
+            compact(COMPACT_FLAGS, q_in, n, s->pflags.p, 4, 2, &dctr->q_next, q_cur, s->queue_nee.p, nullptr);
             if (timing) timer.end(stream);
-            ++launches;
             HIP_TRY(hipMemcpyAsync(s->h_counters, dctr, sizeof(Counters), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             int n_next = (int)s->h_counters->q_next, n_nee = (int)s->h_counters->q_nee;
             int n_sh = (int)s->h_counters->q_shadow, n_mis = (int)s->h_counters->q_mis;
-            HIP_TRY(hipMemsetAsync(&dctr->q_next, 0, 4 * sizeof(unsigned int), stream));
-            launch_trace(TraceWork{q_cur, n_next, s->queue_shadow.p, n_sh, s->queue_mis.p, n_mis});
+            launch_trace(TraceWork{q_cur, n_next, s->queue_nee.p, n_nee}, n_sh, n_mis);
             if (n_nee > 0) {
                 if (timing) timer.begin(1, stream);
                 hipLaunchKernelGGL(k_nee_combine, dim3(grid_for(n_nee)), dim3(kBlock), 0, stream, pa, (const int *)s->queue_nee.p, n_nee);

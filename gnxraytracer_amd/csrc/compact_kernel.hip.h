@@ -1,0 +1,111 @@
+// compact_kernel.hip.h -- stream compaction of the path queues without global atomics.
+//
+// Atomic appends cap out at ~88 increments/us per address on MI355X (MI355X_MICROARCH.md, row "dequeue"): with
+// one append per wave the first version spent 1.3 ms per launch just binning 16 M paths (profiles/r01_c_*).
+// Here each 256-item tile counts its survivors with wave64 ballots, one small block scans the tile counts, and the
+// scatter pass recomputes the ballots to write every survivor at its final, ORDER-PRESERVING position: queues stay
+// sorted by path slot, so the float4 state arrays keep being read in (mostly) ascending, coalesced order.
+//
+//   mode FLAGS : predicate o = bit o of pflags[path]   (bit0 path continues, bit1 has NEE record,
+//                                                       bit2 shadow ray valid, bit3 MIS ray valid -- 2,3 counted only)
+//   mode CLASS : predicate o = (pclass[path] == o)     (shade-kernel specialisation of the hit material)
+#pragma once
+#include "device_math.h"
+
+namespace gnxr {
+
+constexpr int kCompactBlock = 256;
+enum CompactMode { COMPACT_FLAGS = 0, COMPACT_CLASS = 1 };
+
+template <int MODE>
+GX_DEV unsigned compact_key(const unsigned char *keys, int path) { return keys[path]; }
+template <int MODE>
+GX_DEV bool compact_pred(unsigned key, int o) { return MODE == COMPACT_FLAGS ? ((key >> o) & 1u) != 0 : key == (unsigned)o; }
+
+// pass 1: tile_counts[o * nTiles + tile] = number of items of the tile that satisfy predicate o
+template <int MODE, int NOUT>
+__global__ void __launch_bounds__(kCompactBlock) k_compact_count(const int *__restrict__ q_in, int n, const unsigned char *__restrict__ keys, unsigned int *tile_counts,
+                                                                 int nTiles) {
+    __shared__ unsigned int wsum[NOUT][kCompactBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+        int i = tile * kCompactBlock + threadIdx.x;
+        unsigned key = 0xffu;
+        bool valid = i < n;
+        if (valid) key = compact_key<MODE>(keys, q_in ? q_in[i] : i);
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            unsigned long long m = __ballot(valid && compact_pred<MODE>(key, o));
+            if (lane == 0) wsum[o][wave] = (unsigned)__popcll(m);
+        }
+        __syncthreads();
+        if (threadIdx.x < NOUT) {
+            unsigned s = 0;
+            for (int w = 0; w < kCompactBlock / 64; ++w) s += wsum[threadIdx.x][w];
+            tile_counts[(size_t)threadIdx.x * nTiles + tile] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// pass 2: exclusive scan of each predicate's tile counts (one 1024-thread block per predicate), totals[o] = sum
+__global__ void __launch_bounds__(1024) k_compact_scan(unsigned int *tile_counts, int nTiles, unsigned int *totals) {
+    __shared__ unsigned int wtot[16];
+    __shared__ unsigned int carry_s;
+    unsigned int *c = tile_counts + (size_t)blockIdx.x * nTiles;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nTiles; base += 1024) {
+        int i = base + threadIdx.x;
+        unsigned v = i < nTiles ? c[i] : 0u;
+        unsigned x = v;  // inclusive scan inside the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { unsigned y = __shfl_up(x, off); if (lane >= off) x += y; }
+        if (lane == 63) wtot[wave] = x;
+        __syncthreads();
+        unsigned woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wtot[w];
+        unsigned carry = carry_s;
+        if (i < nTiles) c[i] = carry + woff + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
+}
+
+// pass 3: write the survivors of the first NSCATTER predicates at tile_offset + rank-within-tile
+template <int MODE, int NSCATTER>
+__global__ void __launch_bounds__(kCompactBlock) k_compact_scatter(const int *__restrict__ q_in, int n, const unsigned char *__restrict__ keys,
+                                                                   const unsigned int *__restrict__ tile_offsets, int nTiles, int *out0, int *out1, int *out2) {
+    __shared__ unsigned int wsum[NSCATTER][kCompactBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int *outs[3] = {out0, out1, out2};
+    for (int tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+        int i = tile * kCompactBlock + threadIdx.x;
+        unsigned key = 0xffu;
+        bool valid = i < n;
+        int path = -1;
+        if (valid) { path = q_in ? q_in[i] : i; key = compact_key<MODE>(keys, path); }
+        unsigned long long masks[NSCATTER];
+#pragma unroll
+        for (int o = 0; o < NSCATTER; ++o) {
+            masks[o] = __ballot(valid && compact_pred<MODE>(key, o));
+            if (lane == 0) wsum[o][wave] = (unsigned)__popcll(masks[o]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < NSCATTER; ++o) {
+            if (valid && compact_pred<MODE>(key, o)) {
+                unsigned woff = 0;
+                for (int w = 0; w < wave; ++w) woff += wsum[o][w];
+                unsigned pos = tile_offsets[(size_t)o * nTiles + tile] + woff + (unsigned)__popcll(masks[o] & ((1ull << lane) - 1ull));
+                outs[o][pos] = path;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace gnxr

@@ -78,13 +78,24 @@ GX_DEV float smith_g_ggx(float cosTheta, float alpha) {  // DisneyMaterial.cpp:2
     return (float)(1 / ((double)cosTheta + sqrt((double)(alpha2 + cosTheta2 - alpha2 * cosTheta2))));
 }
 
+// LM: compile-time mask of the lobe kinds (bit LobeKind) and Fresnel kinds (bit 16 + FresnelKind) a shade-kernel
+// specialisation can meet; everything else is compiled out, which is what keeps the Matte kernel small.
+#define GX_HAS_LOBE(K) ((LM >> (K)) & 1u)
+#define GX_HAS_FRESNEL(K) ((LM >> (16 + (K))) & 1u)
+constexpr uint32_t lobe_bit(int k) { return 1u << k; }
+constexpr uint32_t fresnel_bit(int k) { return 1u << (16 + k); }
+constexpr uint32_t LM_DIFFUSE = lobe_bit(LOBE_LAMBERT) | lobe_bit(LOBE_OREN);
+constexpr uint32_t LM_GLOSSY = LM_DIFFUSE | lobe_bit(LOBE_SPEC_REFL) | lobe_bit(LOBE_SPEC_TRANS) | lobe_bit(LOBE_FRESNEL_SPEC) | lobe_bit(LOBE_MICRO_REFL) |
+                               lobe_bit(LOBE_MICRO_TRANS) | fresnel_bit(FRESNEL_NOOP) | fresnel_bit(FRESNEL_DIELECTRIC) | fresnel_bit(FRESNEL_CONDUCTOR);
+constexpr uint32_t LM_ALL = 0xffffffffu;
+
+template <uint32_t LM>
 GX_DEV Spec fresnel_eval(const DLobe &l, float cosI) {
-    switch (l.fresnel) {
-    case FRESNEL_DIELECTRIC: return Spec(fr_dielectric(cosI, l.f_etaI, l.f_etaT));
-    case FRESNEL_CONDUCTOR: return fr_conductor(fabsf(cosI), spec3(l.f_cEtaT), spec3(l.f_cK));
-    case FRESNEL_DISNEY: return slerp(l.f_metallic, Spec(fr_dielectric(cosI, 1, l.f_eta)), fr_schlick_spec(spec3(l.f_R0), cosI));
-    default: return Spec(1.f);
-    }
+    if (GX_HAS_FRESNEL(FRESNEL_DIELECTRIC) && l.fresnel == FRESNEL_DIELECTRIC) return Spec(fr_dielectric(cosI, l.f_etaI, l.f_etaT));
+    if (GX_HAS_FRESNEL(FRESNEL_CONDUCTOR) && l.fresnel == FRESNEL_CONDUCTOR) return fr_conductor(fabsf(cosI), spec3(l.f_cEtaT), spec3(l.f_cK));
+    if (GX_HAS_FRESNEL(FRESNEL_DISNEY) && l.fresnel == FRESNEL_DISNEY)
+        return slerp(l.f_metallic, Spec(fr_dielectric(cosI, 1, l.f_eta)), fr_schlick_spec(spec3(l.f_R0), cosI));
+    return Spec(1.f);
 }
 
 // ---- Trowbridge-Reitz, MicroFacet.cpp ----
@@ -154,11 +165,12 @@ GX_DEV V3 tr_sample_wh(float ax, float ay, V3 wo, float u0, float u1) {  // Micr
 }
 
 // ---- per-lobe f / Pdf / Sample_f (local shading space) ----
+template <uint32_t LM>
 GX_DEV Spec lobe_f(const DLobe &l, V3 wo, V3 wi) {
     switch (l.kind) {
-    case LOBE_LAMBERT: return spec3(l.R) * GX_INV_PI;
-    case LOBE_LAMBERT_TRANS: return spec3(l.T) * GX_INV_PI;
-    case LOBE_OREN: {  // Reflection.cpp:173-198
+    case LOBE_LAMBERT: if (GX_HAS_LOBE(LOBE_LAMBERT)) return spec3(l.R) * GX_INV_PI; break;
+    case LOBE_LAMBERT_TRANS: if (GX_HAS_LOBE(LOBE_LAMBERT_TRANS)) return spec3(l.T) * GX_INV_PI; break;
+    case LOBE_OREN: if (GX_HAS_LOBE(LOBE_OREN)) {  // Reflection.cpp:173-198
         float sinThetaI = sin_theta(wi), sinThetaO = sin_theta(wo);
         float maxCos = 0;
         if (sinThetaI > 1e-4 && sinThetaO > 1e-4) {
@@ -172,16 +184,18 @@ GX_DEV Spec lobe_f(const DLobe &l, V3 wo, V3 wi) {
         else { sinAlpha = sinThetaI; tanBeta = sinThetaO / abs_cos_theta(wo); }
         return spec3(l.R) * GX_INV_PI * (l.A + l.B * maxCos * sinAlpha * tanBeta);
     }
-    case LOBE_MICRO_REFL: {  // Reflection.cpp:223-237
+    break;
+    case LOBE_MICRO_REFL: if (GX_HAS_LOBE(LOBE_MICRO_REFL)) {  // Reflection.cpp:223-237
         float cosThetaO = abs_cos_theta(wo), cosThetaI = abs_cos_theta(wi);
         V3 wh = wi + wo;
         if (cosThetaI == 0 || cosThetaO == 0) return Spec(0.f);
         if (wh.x == 0 && wh.y == 0 && wh.z == 0) return Spec(0.f);
         wh = normalize(wh);
-        Spec F = fresnel_eval(l, dot(wi, faceforward(wh, V3(0, 0, 1))));
+        Spec F = fresnel_eval<LM>(l, dot(wi, faceforward(wh, V3(0, 0, 1))));
         return spec3(l.R) * tr_D(l.alphax, l.alphay, wh) * tr_G(l, wo, wi) * F / (4 * cosThetaI * cosThetaO);
     }
-    case LOBE_MICRO_TRANS: {  // Reflection.cpp:278-302 (TransportMode::Radiance)
+    break;
+    case LOBE_MICRO_TRANS: if (GX_HAS_LOBE(LOBE_MICRO_TRANS)) {  // Reflection.cpp:278-302 (TransportMode::Radiance)
         if (same_hemisphere(wo, wi)) return Spec(0.f);
         float cosThetaO = cos_theta(wo), cosThetaI = cos_theta(wi);
         if (cosThetaI == 0 || cosThetaO == 0) return Spec(0.f);
@@ -189,18 +203,20 @@ GX_DEV Spec lobe_f(const DLobe &l, V3 wo, V3 wi) {
         V3 wh = normalize(wo + wi * eta);
         if (wh.z < 0) wh = -wh;
         if (dot(wo, wh) * dot(wi, wh) > 0) return Spec(0.f);
-        Spec F = fresnel_eval(l, dot(wo, wh));
+        Spec F = fresnel_eval<LM>(l, dot(wo, wh));
         float sqrtDenom = dot(wo, wh) + eta * dot(wi, wh);
         float factor = (1 / eta);
         return (Spec(1.f) - F) * spec3(l.T) *
                fabsf(tr_D(l.alphax, l.alphay, wh) * tr_G(l, wo, wi) * eta * eta * absdot(wi, wh) * absdot(wo, wh) * factor * factor /
                      (cosThetaI * cosThetaO * sqrtDenom * sqrtDenom));
     }
-    case LOBE_DISNEY_DIFFUSE: {  // DisneyMaterial.cpp:64-72
+    break;
+    case LOBE_DISNEY_DIFFUSE: if (GX_HAS_LOBE(LOBE_DISNEY_DIFFUSE)) {  // DisneyMaterial.cpp:64-72
         float Fo = schlick_weight(abs_cos_theta(wo)), Fi = schlick_weight(abs_cos_theta(wi));
         return spec3(l.R) * GX_INV_PI * (1 - Fo / 2) * (1 - Fi / 2);
     }
-    case LOBE_DISNEY_FAKESS: {  // DisneyMaterial.cpp:105-122
+    break;
+    case LOBE_DISNEY_FAKESS: if (GX_HAS_LOBE(LOBE_DISNEY_FAKESS)) {  // DisneyMaterial.cpp:105-122
         V3 wh = wi + wo;
         if (wh.x == 0 && wh.y == 0 && wh.z == 0) return Spec(0.f);
         wh = normalize(wh);
@@ -211,7 +227,8 @@ GX_DEV Spec lobe_f(const DLobe &l, V3 wo, V3 wi) {
         float ss = 1.25f * (Fss * (1 / (abs_cos_theta(wo) + abs_cos_theta(wi)) - .5f) + .5f);
         return spec3(l.R) * GX_INV_PI * ss;
     }
-    case LOBE_DISNEY_RETRO: {  // DisneyMaterial.cpp:151-164
+    break;
+    case LOBE_DISNEY_RETRO: if (GX_HAS_LOBE(LOBE_DISNEY_RETRO)) {  // DisneyMaterial.cpp:151-164
         V3 wh = wi + wo;
         if (wh.x == 0 && wh.y == 0 && wh.z == 0) return Spec(0.f);
         wh = normalize(wh);
@@ -220,13 +237,15 @@ GX_DEV Spec lobe_f(const DLobe &l, V3 wo, V3 wi) {
         float Rr = 2 * l.roughness * cosThetaD * cosThetaD;
         return spec3(l.R) * GX_INV_PI * Rr * (Fo + Fi + Fo * Fi * (Rr - 1));
     }
-    case LOBE_DISNEY_SHEEN: {  // DisneyMaterial.cpp:189-197
+    break;
+    case LOBE_DISNEY_SHEEN: if (GX_HAS_LOBE(LOBE_DISNEY_SHEEN)) {  // DisneyMaterial.cpp:189-197
         V3 wh = wi + wo;
         if (wh.x == 0 && wh.y == 0 && wh.z == 0) return Spec(0.f);
         wh = normalize(wh);
         return spec3(l.R) * schlick_weight(dot(wi, wh));
     }
-    case LOBE_DISNEY_CLEARCOAT: {  // DisneyMaterial.cpp:239-253
+    break;
+    case LOBE_DISNEY_CLEARCOAT: if (GX_HAS_LOBE(LOBE_DISNEY_CLEARCOAT)) {  // DisneyMaterial.cpp:239-253
         V3 wh = wi + wo;
         if (wh.x == 0 && wh.y == 0 && wh.z == 0) return Spec(0.f);
         wh = normalize(wh);
@@ -235,20 +254,24 @@ GX_DEV Spec lobe_f(const DLobe &l, V3 wo, V3 wi) {
         float Gr = smith_g_ggx(abs_cos_theta(wo), .25f) * smith_g_ggx(abs_cos_theta(wi), .25f);
         return Spec(l.weight * Gr * Fr * Dr / 4);
     }
-    default: return Spec(0.f);  // specular lobes
+    break;
+    default: break;  // specular lobes
     }
+    return Spec(0.f);
 }
 
+template <uint32_t LM>
 GX_DEV float lobe_pdf(const DLobe &l, V3 wo, V3 wi) {
     switch (l.kind) {
     case LOBE_SPEC_REFL: case LOBE_SPEC_TRANS: case LOBE_FRESNEL_SPEC: return 0.f;
-    case LOBE_LAMBERT_TRANS: return !same_hemisphere(wo, wi) ? abs_cos_theta(wi) * GX_INV_PI : 0.f;
-    case LOBE_MICRO_REFL: {
+    case LOBE_LAMBERT_TRANS: if (GX_HAS_LOBE(LOBE_LAMBERT_TRANS)) return !same_hemisphere(wo, wi) ? abs_cos_theta(wi) * GX_INV_PI : 0.f; break;
+    case LOBE_MICRO_REFL: if (GX_HAS_LOBE(LOBE_MICRO_REFL)) {
         if (!same_hemisphere(wo, wi)) return 0.f;
         V3 wh = normalize(wo + wi);
         return tr_pdf(l.alphax, l.alphay, wo, wh) / (4 * dot(wo, wh));
     }
-    case LOBE_MICRO_TRANS: {
+    break;
+    case LOBE_MICRO_TRANS: if (GX_HAS_LOBE(LOBE_MICRO_TRANS)) {
         if (same_hemisphere(wo, wi)) return 0.f;
         float eta = cos_theta(wo) > 0 ? (l.etaB / l.etaA) : (l.etaA / l.etaB);
         V3 wh = normalize(wo + wi * eta);
@@ -257,7 +280,8 @@ GX_DEV float lobe_pdf(const DLobe &l, V3 wo, V3 wi) {
         float dwh_dwi = fabsf((eta * eta * dot(wi, wh)) / (sqrtDenom * sqrtDenom));
         return tr_pdf(l.alphax, l.alphay, wo, wh) * dwh_dwi;
     }
-    case LOBE_DISNEY_CLEARCOAT: {
+    break;
+    case LOBE_DISNEY_CLEARCOAT: if (GX_HAS_LOBE(LOBE_DISNEY_CLEARCOAT)) {
         if (!same_hemisphere(wo, wi)) return 0.f;
         V3 wh = wi + wo;
         if (wh.x == 0 && wh.y == 0 && wh.z == 0) return 0.f;
@@ -265,28 +289,33 @@ GX_DEV float lobe_pdf(const DLobe &l, V3 wo, V3 wi) {
         float Dr = gtr1(abs_cos_theta(wh), l.gloss);
         return Dr * abs_cos_theta(wh) / (4 * dot(wo, wh));
     }
-    default: return same_hemisphere(wo, wi) ? abs_cos_theta(wi) * GX_INV_PI : 0.f;  // BxDF::Pdf
+    break;
+    default: break;
     }
+    return same_hemisphere(wo, wi) ? abs_cos_theta(wi) * GX_INV_PI : 0.f;  // BxDF::Pdf
 }
 
 // *pdf is left untouched on early-outs (the caller zeroes it), as in the reference.
+template <uint32_t LM>
 GX_DEV Spec lobe_sample(const DLobe &l, V3 wo, V3 *wi, float u0, float u1, float *pdf, int *sampledType) {
     switch (l.kind) {
-    case LOBE_SPEC_REFL: {  // Reflection.cpp:89-97
+    case LOBE_SPEC_REFL: if (GX_HAS_LOBE(LOBE_SPEC_REFL)) {  // Reflection.cpp:89-97
         *wi = V3(-wo.x, -wo.y, wo.z);
         *pdf = 1;
-        return fresnel_eval(l, cos_theta(*wi)) * spec3(l.R) / abs_cos_theta(*wi);
+        return fresnel_eval<LM>(l, cos_theta(*wi)) * spec3(l.R) / abs_cos_theta(*wi);
     }
-    case LOBE_SPEC_TRANS: {  // Reflection.cpp:105-122
+    break;
+    case LOBE_SPEC_TRANS: if (GX_HAS_LOBE(LOBE_SPEC_TRANS)) {  // Reflection.cpp:105-122
         bool entering = cos_theta(wo) > 0;
         float etaI = entering ? l.etaA : l.etaB, etaT = entering ? l.etaB : l.etaA;
         if (!refract(wo, faceforward(V3(0, 0, 1), wo), etaI / etaT, wi)) return Spec(0.f);
         *pdf = 1;
-        Spec ft = spec3(l.T) * (Spec(1.f) - fresnel_eval(l, cos_theta(*wi)));
+        Spec ft = spec3(l.T) * (Spec(1.f) - fresnel_eval<LM>(l, cos_theta(*wi)));
         ft = ft * ((etaI * etaI) / (etaT * etaT));
         return ft / abs_cos_theta(*wi);
     }
-    case LOBE_FRESNEL_SPEC: {  // Reflection.cpp:346-380
+    break;
+    case LOBE_FRESNEL_SPEC: if (GX_HAS_LOBE(LOBE_FRESNEL_SPEC)) {  // Reflection.cpp:346-380
         float F = fr_dielectric(cos_theta(wo), l.etaA, l.etaB);
         if (u0 < F) {
             *wi = V3(-wo.x, -wo.y, wo.z);
@@ -304,31 +333,35 @@ GX_DEV Spec lobe_sample(const DLobe &l, V3 wo, V3 *wi, float u0, float u1, float
             return ft / abs_cos_theta(*wi);
         }
     }
-    case LOBE_MICRO_REFL: {  // Reflection.cpp:206-214
+    break;
+    case LOBE_MICRO_REFL: if (GX_HAS_LOBE(LOBE_MICRO_REFL)) {  // Reflection.cpp:206-214
         if (wo.z == 0) return Spec(0.f);
         V3 wh = tr_sample_wh(l.alphax, l.alphay, wo, u0, u1);
         if (dot(wo, wh) < 0) return Spec(0.f);
         *wi = reflect(wo, wh);
         if (!same_hemisphere(wo, *wi)) return Spec(0.f);
         *pdf = tr_pdf(l.alphax, l.alphay, wo, wh) / (4 * dot(wo, wh));
-        return lobe_f(l, wo, *wi);
+        return lobe_f<LM>(l, wo, *wi);
     }
-    case LOBE_MICRO_TRANS: {  // Reflection.cpp:249-260
+    break;
+    case LOBE_MICRO_TRANS: if (GX_HAS_LOBE(LOBE_MICRO_TRANS)) {  // Reflection.cpp:249-260
         if (wo.z == 0) return Spec(0.f);
         V3 wh = tr_sample_wh(l.alphax, l.alphay, wo, u0, u1);
         if (dot(wo, wh) < 0) return Spec(0.f);
         float eta = cos_theta(wo) > 0 ? (l.etaA / l.etaB) : (l.etaB / l.etaA);
         if (!refract(wo, wh, eta, wi)) return Spec(0.f);
-        *pdf = lobe_pdf(l, wo, *wi);
-        return lobe_f(l, wo, *wi);
+        *pdf = lobe_pdf<LM>(l, wo, *wi);
+        return lobe_f<LM>(l, wo, *wi);
     }
-    case LOBE_LAMBERT_TRANS: {  // Reflection.cpp:146-155
+    break;
+    case LOBE_LAMBERT_TRANS: if (GX_HAS_LOBE(LOBE_LAMBERT_TRANS)) {  // Reflection.cpp:146-155
         *wi = cosine_sample_hemisphere(u0, u1);
         if (wo.z > 0) wi->z *= -1;
-        *pdf = lobe_pdf(l, wo, *wi);
-        return lobe_f(l, wo, *wi);
+        *pdf = lobe_pdf<LM>(l, wo, *wi);
+        return lobe_f<LM>(l, wo, *wi);
     }
-    case LOBE_DISNEY_CLEARCOAT: {  // DisneyMaterial.cpp:255-276
+    break;
+    case LOBE_DISNEY_CLEARCOAT: if (GX_HAS_LOBE(LOBE_DISNEY_CLEARCOAT)) {  // DisneyMaterial.cpp:255-276
         if (wo.z == 0) return Spec(0.f);
         float alpha2 = l.gloss * l.gloss;
         float cosTheta = gx_sqrt(fmaxf(0.f, (1 - gx_pow(alpha2, 1 - u0)) / (1 - alpha2)));
@@ -338,19 +371,21 @@ GX_DEV Spec lobe_sample(const DLobe &l, V3 wo, V3 *wi, float u0, float u1, float
         if (!same_hemisphere(wo, wh)) wh = -wh;
         *wi = reflect(wo, wh);
         if (!same_hemisphere(wo, *wi)) return Spec(0.f);
-        *pdf = lobe_pdf(l, wo, *wi);
-        return lobe_f(l, wo, *wi);
+        *pdf = lobe_pdf<LM>(l, wo, *wi);
+        return lobe_f<LM>(l, wo, *wi);
     }
-    default: {  // BxDF::Sample_f, Reflection.cpp:394-401
-        *wi = cosine_sample_hemisphere(u0, u1);
-        if (wo.z < 0) wi->z *= -1;
-        *pdf = lobe_pdf(l, wo, *wi);
-        return lobe_f(l, wo, *wi);
+    break;
+    default: break;
     }
-    }
+    // BxDF::Sample_f, Reflection.cpp:394-401
+    *wi = cosine_sample_hemisphere(u0, u1);
+    if (wo.z < 0) wi->z *= -1;
+    *pdf = lobe_pdf<LM>(l, wo, *wi);
+    return lobe_f<LM>(l, wo, *wi);
 }
 
 // ---- BSDF container, Reflection.h:102-154 + Reflection.cpp:440-563 ----
+template <uint32_t LM>
 struct Bsdf {
     const DMaterial *mat;
     V3 ns, ng, ss, ts;
@@ -371,7 +406,7 @@ struct Bsdf {
         Spec f(0.f);
         for (int i = 0; i < mat->n_lobes; ++i) {
             const DLobe &l = mat->lobes[i];
-            if (matches(l.type, flags) && ((refl && (l.type & BSDF_REFLECTION)) || (!refl && (l.type & BSDF_TRANSMISSION)))) f = f + lobe_f(l, wo, wi);
+            if (matches(l.type, flags) && ((refl && (l.type & BSDF_REFLECTION)) || (!refl && (l.type & BSDF_TRANSMISSION)))) f = f + lobe_f<LM>(l, wo, wi);
         }
         return f;
     }
@@ -383,7 +418,7 @@ struct Bsdf {
         int matching = 0;
         for (int i = 0; i < mat->n_lobes; ++i) {
             const DLobe &l = mat->lobes[i];
-            if (matches(l.type, flags)) { ++matching; p += lobe_pdf(l, wo, wi); }
+            if (matches(l.type, flags)) { ++matching; p += lobe_pdf<LM>(l, wo, wi); }
         }
         return matching > 0 ? p / matching : 0.f;
     }
@@ -401,19 +436,19 @@ struct Bsdf {
         *pdf = 0;
         if (wo.z == 0) return Spec(0.f);
         *sampledType = bx.type;
-        Spec f = lobe_sample(bx, wo, &wi, ur0, u1, pdf, sampledType);
+        Spec f = lobe_sample<LM>(bx, wo, &wi, ur0, u1, pdf, sampledType);
         if (*pdf == 0) { *sampledType = 0; return Spec(0.f); }
         *wiW = to_world(wi);
         if (!(bx.type & BSDF_SPECULAR) && matching > 1)
             for (int i = 0; i < mat->n_lobes; ++i)
-                if (i != which && matches(mat->lobes[i].type, flags)) *pdf += lobe_pdf(mat->lobes[i], wo, wi);
+                if (i != which && matches(mat->lobes[i].type, flags)) *pdf += lobe_pdf<LM>(mat->lobes[i], wo, wi);
         if (matching > 1) *pdf /= matching;
         if (!(bx.type & BSDF_SPECULAR)) {
             bool refl = dot(*wiW, ng) * dot(woW, ng) > 0;
             f = Spec(0.f);
             for (int i = 0; i < mat->n_lobes; ++i) {
                 const DLobe &l = mat->lobes[i];
-                if (matches(l.type, flags) && ((refl && (l.type & BSDF_REFLECTION)) || (!refl && (l.type & BSDF_TRANSMISSION)))) f = f + lobe_f(l, wo, wi);
+                if (matches(l.type, flags) && ((refl && (l.type & BSDF_REFLECTION)) || (!refl && (l.type & BSDF_TRANSMISSION)))) f = f + lobe_f<LM>(l, wo, wi);
             }
         }
         return f;

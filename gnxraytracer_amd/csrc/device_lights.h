@@ -94,20 +94,26 @@ GX_DEV Spec skybox_Le(const DLight &l, V3 ro, V3 rd) {  // SkyBoxLight.cpp:55-85
     V3 q = hp - center;
     return Spec((q.x + R) / (2.f * R), (q.y + R) / (2.f * R), (q.z + R) / (2.f * R));
 }
+// LT: compile-time mask of the light types a scene holds (bit 0 area triangles, bit 1 InfiniteAreaLight,
+// bit 2 SkyBoxLight); unused types are compiled out of the shade kernels.
+constexpr int LT_AREA = 1, LT_ENV = 2, LT_SKY = 4, LT_ALL = 7;
+
 // Light::Le(ray) for an escaped ray
+template <int LT>
 GX_DEV Spec light_Le(const DLightTables &t, int li, V3 ro, V3 rd) {
     const DLight &l = t.lights[li];
-    if (l.type == GNXR_LIGHT_INFINITE) return env_Le(t, rd);
-    if (l.type == GNXR_LIGHT_SKYBOX) return skybox_Le(l, ro, rd);
+    if ((LT & LT_ENV) && l.type == GNXR_LIGHT_INFINITE) return env_Le(t, rd);
+    if ((LT & LT_SKY) && l.type == GNXR_LIGHT_SKYBOX) return skybox_Le(l, ro, rd);
     return Spec(0.f);
 }
 
 // <Light>::Sample_Li(ref, u)
+template <int LT>
 GX_DEV LightSample light_sample(const DLightTables &t, int li, V3 refP, float u0, float u1) {
     const DLight &l = t.lights[li];
     LightSample s;
     s.pdf = 0; s.Li = Spec(0.f);
-    if (l.type == GNXR_LIGHT_AREA_TRI) {
+    if ((LT & LT_AREA) && (LT == LT_AREA || l.type == GNXR_LIGHT_AREA_TRI)) {
         // Triangle::Sample(u, pdf), Triangle.cpp:464-492
         float su0 = gx_sqrt(u0);
         float b0 = 1 - su0, b1 = u1 * su0;
@@ -132,7 +138,7 @@ GX_DEV LightSample light_sample(const DLightTables &t, int li, V3 refP, float u0
         s.p1 = p; s.p1Error = pError; s.n1 = n;
         s.Li = area_L(l, n, -s.wi);
         return s;
-    } else if (l.type == GNXR_LIGHT_INFINITE) {  // InfiniteAreaLight.cpp:98-121
+    } else if ((LT & LT_ENV) && l.type == GNXR_LIGHT_INFINITE) {  // InfiniteAreaLight.cpp:98-121
         const DEnv &e = t.env;
         float pdfs0, pdfs1;
         int v, dummy;
@@ -150,7 +156,7 @@ GX_DEV LightSample light_sample(const DLightTables &t, int li, V3 refP, float u0
         s.p1Error = V3(); s.n1 = V3();
         s.Li = env_lookup(t, d0, d1);
         return s;
-    } else {  // SkyBoxLight::Sample_Li, SkyBoxLight.cpp:43-53: black, pdf 1/4pi
+    } else if (LT & LT_SKY) {  // SkyBoxLight::Sample_Li, SkyBoxLight.cpp:43-53: black, pdf 1/4pi
         float theta = u1 * GX_PI, phi = u0 * 2 * GX_PI;
         float cosTheta = gx_cos(theta), sinTheta = gx_sin(theta);
         float sinPhi = gx_sin(phi), cosPhi = gx_cos(phi);
@@ -161,12 +167,14 @@ GX_DEV LightSample light_sample(const DLightTables &t, int li, V3 refP, float u0
         s.Li = Spec(0.f);
         return s;
     }
+    return s;
 }
 
 // <Light>::Pdf_Li(ref, wi); the reference point's (p, pError, n) are needed for Shape::Pdf's SpawnRay
+template <int LT>
 GX_DEV float light_pdf(const DLightTables &t, int li, V3 refP, V3 refPError, V3 refN, V3 wi) {
     const DLight &l = t.lights[li];
-    if (l.type == GNXR_LIGHT_AREA_TRI) {  // Shape::Pdf(ref, wi), Shape.cpp:37-53
+    if ((LT & LT_AREA) && (LT == LT_AREA || l.type == GNXR_LIGHT_AREA_TRI)) {  // Shape::Pdf(ref, wi), Shape.cpp:37-53
         V3 o = offset_ray_origin(refP, refPError, refN, wi);
         V3 p0(l.p0[0], l.p0[1], l.p0[2]), p1(l.p1[0], l.p1[1], l.p1[2]), p2(l.p2[0], l.p2[1], l.p2[2]);
         TriHit h;
@@ -177,7 +185,7 @@ GX_DEV float light_pdf(const DLightTables &t, int li, V3 refP, V3 refPError, V3 
         float pdf = length_sq(refP - pHit) / (absdot(nHit, -wi) * l.area);
         if (isinf(pdf)) pdf = 0.f;
         return pdf;
-    } else if (l.type == GNXR_LIGHT_INFINITE) {  // InfiniteAreaLight.cpp:123-132
+    } else if ((LT & LT_ENV) && l.type == GNXR_LIGHT_INFINITE) {  // InfiniteAreaLight.cpp:123-132
         const DEnv &e = t.env;
         V3 w = xform_vector(e.w2l, wi);
         float theta = spherical_theta(w), phi = spherical_phi(w);

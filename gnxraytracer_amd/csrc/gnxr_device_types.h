@@ -53,6 +53,8 @@ struct DMaterial {
     int32_t has_bump;
     int32_t n_nonspecular;   // NumComponents(BSDF_ALL & ~BSDF_SPECULAR)
     float eta;               // BSDF::eta
+    int32_t shade_class;     // which k_shade specialisation can evaluate every lobe: 0 diffuse, 1 glossy, 2 any
+    int32_t _pad[3];
     DLobe lobes[8];
 };
 

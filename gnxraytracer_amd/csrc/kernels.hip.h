@@ -29,6 +29,8 @@ struct PathArrays {
     float4 *L;        // L.rgb
     uint2 *meta;      // x: Halton sample index, y: dim | bounces << 16 | specularBounce << 31
     int *hit;         // leaf-order triangle of the closest hit, -1 == miss
+    unsigned char *pflags;  // written by k_shade: bit0 continues, bit1 NEE record, bit2 shadow ray, bit3 MIS ray
+    unsigned char *pclass;  // written by k_trace: shade-kernel class of the hit material (DMaterial::shade_class)
     // next-event-estimation records written by k_shade, consumed by k_nee
     float4 *sh_o;     // shadow ray origin, tMax
     float4 *sh_d;     // shadow ray direction, flags (bit0 shadow ray valid, bit1 MIS ray valid)
@@ -41,9 +43,9 @@ struct PathArrays {
 
 struct Counters {
     unsigned long long nodes, tris;
-    unsigned int q_next, q_nee, q_shadow, q_mis;   // queue fill counts of the current vertex
+    unsigned int q_next, q_nee, q_shadow, q_mis;   // k_compact_scan totals: paths that continue / have NEE / shadow rays / MIS rays
+    unsigned int q_class[3];                        // fill counts of the per-material-class shade queues
     unsigned int cursor;                            // k_trace work cursor
-    unsigned int _pad[3];
 };
 
 struct DScene {
@@ -63,6 +65,7 @@ struct DRender {
 };
 
 }  // namespace gnxr
+#include "compact_kernel.hip.h"
 #include "trace_kernel.hip.h"
 namespace gnxr {
 
@@ -139,27 +142,16 @@ __global__ void __launch_bounds__(kBlock) k_raygen(DScene sc, DRender r, PathArr
 }
 
 // ------------------------------------------------------------------------------------------------
-GX_DEV void wave_append(int *queue, unsigned int *counter, bool pred, int value) {
-    unsigned long long mask = __ballot(pred);
-    if (mask == 0) return;
-    int lane = __lane_id();
-    int leader = __ffsll((long long)mask) - 1;
-    unsigned int base = 0;
-    if (lane == leader) base = atomicAdd(counter, (unsigned int)__popcll(mask));
-    base = __shfl(base, leader);
-    if (pred) queue[base + __popcll(mask & ((1ull << lane) - 1ull))] = value;
-}
-
-__global__ void __launch_bounds__(kBlock) k_shade(DScene sc, DRender r, PathArrays pa, const int *__restrict__ queue, int n, int *queue_next, int *queue_nee,
-                                                  int *queue_shadow, int *queue_mis, Counters *ctr) {
-    int nIter = (n + gridDim.x * blockDim.x - 1) / (gridDim.x * blockDim.x);
-    for (int it = 0; it < nIter; ++it) {
-        int i = it * gridDim.x * blockDim.x + blockIdx.x * blockDim.x + threadIdx.x;
-        bool active = i < n;
+// One specialisation per (lobe set LM, light-type set LT): device_bsdf.h LM_*, device_lights.h LT_*.  `n_dev`
+// points at the fill count of `queue` written by k_compact_scan (device-side, no host round trip).
+template <uint32_t LM, int LT>
+__global__ void __launch_bounds__(kBlock) k_shade(DScene sc, DRender r, PathArrays pa, const int *__restrict__ queue, const unsigned int *n_dev) {
+    const int n = (int)*n_dev;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         bool survive = false, wantNee = false, wantShadow = false, wantMis = false;
         int path = -1;
-        if (active) {
-            path = queue ? queue[i] : i;
+        {
+            path = queue[i];
             uint2 m = pa.meta[path];
             uint32_t index = m.x;
             int dim = (int)(m.y & 0xffffu), bounces = (int)((m.y >> 16) & 0xffu);
@@ -191,7 +183,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DScene sc, DRender r, PathArra
                 if (found) {
                     if (triLight >= 0) L = L + beta * area_L(sc.lt.lights[triLight], sp.n, -rd);
                 } else {
-                    for (int k = 0; k < sc.lt.n_infinite; ++k) L = L + beta * light_Le(sc.lt, sc.lt.infinite[k], ro, rd);
+                    for (int k = 0; k < sc.lt.n_infinite; ++k) L = L + beta * light_Le<LT>(sc.lt, sc.lt.infinite[k], ro, rd);
                 }
             }
             if (found && bounces < r.max_depth) {
@@ -202,7 +194,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DScene sc, DRender r, PathArra
                     survive = true;
                 } else {
                     const DMaterial *mat = sc.materials + triMat;
-                    Bsdf bsdf;
+                    Bsdf<LM> bsdf;
                     bsdf.mat = mat; bsdf.ns = sp.ns; bsdf.ng = sp.n; bsdf.ss = sp.ss; bsdf.ts = sp.ts;
                     SampleStream ss(sc.st, index, dim);
                     V3 woN = normalize(-rd);  // Interaction::wo
@@ -220,7 +212,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DScene sc, DRender r, PathArra
                             V3 so, sd, mo, wi2;
                             Spec X(0.f), Y(0.f);
                             int expect = -1;
-                            LightSample ls = light_sample(sc.lt, lightNum, sp.p, ul0, ul1);
+                            LightSample ls = light_sample<LT>(sc.lt, lightNum, sp.p, ul0, ul1);
                             float scatteringPdf = 0;
                             if (ls.pdf > 0 && !ls.Li.is_black()) {
                                 Spec f = bsdf.f(woN, ls.wi, bsdfFlags) * absdot(ls.wi, sp.ns);
@@ -242,7 +234,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DScene sc, DRender r, PathArra
                                     float weight = 1;
                                     bool skip = false;
                                     if (!sampledSpecular) {
-                                        float lightPdf = light_pdf(sc.lt, lightNum, sp.p, sp.pError, sp.n, wi2);
+                                        float lightPdf = light_pdf<LT>(sc.lt, lightNum, sp.p, sp.pError, sp.n, wi2);
                                         if (lightPdf == 0) skip = true;  // `return Ld`
                                         else weight = power_heuristic(scatteringPdf, lightPdf);
                                     }
@@ -252,13 +244,13 @@ __global__ void __launch_bounds__(kBlock) k_shade(DScene sc, DRender r, PathArra
                                         const DLight &lt = sc.lt.lights[lightNum];
                                         mo = offset_ray_origin(sp.p, sp.pError, sp.n, wi2);
                                         Spec Li2;
-                                        if (lt.type == GNXR_LIGHT_AREA_TRI) {
+                                        if (LT == LT_AREA || lt.type == GNXR_LIGHT_AREA_TRI) {
                                             V3 lp0(lt.p0[0], lt.p0[1], lt.p0[2]), lp1(lt.p1[0], lt.p1[1], lt.p1[2]), lp2(lt.p2[0], lt.p2[1], lt.p2[2]);
                                             V3 ln = normalize(cross(lp0 - lp2, lp1 - lp2));  // lightIsect.n
                                             Li2 = area_L(lt, ln, -wi2);
                                             expect = lt.tri_leaf;
                                         } else {
-                                            Li2 = light_Le(sc.lt, lightNum, mo, wi2);
+                                            Li2 = light_Le<LT>(sc.lt, lightNum, mo, wi2);
                                             expect = -1;
                                         }
                                         if (!Li2.is_black()) Y = f * Li2 * Spec(1.f) * weight / scatteringPdf;
@@ -315,10 +307,7 @@ __global__ void __launch_bounds__(kBlock) k_shade(DScene sc, DRender r, PathArra
             }
             pa.L[path] = make_float4(L.r, L.g, L.b, 0.f);
         }
-        wave_append(queue_next, &ctr->q_next, survive, path);
-        wave_append(queue_nee, &ctr->q_nee, wantNee, path);
-        wave_append(queue_shadow, &ctr->q_shadow, wantShadow, path);
-        wave_append(queue_mis, &ctr->q_mis, wantMis, path);
+        pa.pflags[path] = (unsigned char)((survive ? 1 : 0) | (wantNee ? 2 : 0) | (wantShadow ? 4 : 0) | (wantMis ? 8 : 0));
     }
 }
 

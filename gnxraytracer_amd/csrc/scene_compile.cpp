@@ -282,6 +282,15 @@ static bool compile_material(const gnxr_material &m, DMaterial *out) {
     default: set_error("unknown material type %d", m.type); return false;
     }
     for (int i = 0; i < out->n_lobes; ++i) if (!(out->lobes[i].type & BSDF_SPECULAR)) out->n_nonspecular++;
+    // smallest shade-kernel specialisation whose lobe set covers this material (device_bsdf.h LM_*)
+    out->shade_class = 0;
+    for (int i = 0; i < out->n_lobes; ++i) {
+        int k = out->lobes[i].kind, f = out->lobes[i].fresnel;
+        int c = (k == LOBE_LAMBERT || k == LOBE_OREN) ? 0
+              : ((k == LOBE_SPEC_REFL || k == LOBE_SPEC_TRANS || k == LOBE_FRESNEL_SPEC || k == LOBE_MICRO_REFL || k == LOBE_MICRO_TRANS) && f != FRESNEL_DISNEY &&
+                 !out->lobes[i].disney_g) ? 1 : 2;
+        out->shade_class = std::max(out->shade_class, c);
+    }
     return true;
 }
 

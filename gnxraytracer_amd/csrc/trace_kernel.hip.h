@@ -23,18 +23,17 @@ namespace gnxr {
 
 struct TraceWork {
     const int *q_closest; int n_closest;   // path slots (nullptr == identity)
-    const int *q_shadow; int n_shadow;
-    const int *q_mis; int n_mis;
+    const int *q_nee; int n_nee;           // paths with an NEE record: two work items each (shadow ray, MIS ray)
 };
 
-constexpr int kTraceChunk = 256;   // rays a wave takes per global atomic
+constexpr int kTraceChunk = 512;   // rays a wave takes per global atomic
 
 template <int STACK, bool COUNT>
 __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, TraceWork w, unsigned int *cursor, Counters *ctr) {
     __shared__ int stack_mem[STACK * kBlock];
     int *stack = &stack_mem[threadIdx.x];
     const int lane = __lane_id();
-    const unsigned total = (unsigned)(w.n_closest + w.n_shadow + w.n_mis);
+    const unsigned total = (unsigned)w.n_closest + 2u * (unsigned)w.n_nee;
     const float4 *__restrict__ nodes = sc.nodes;
     const DTri *__restrict__ tris = sc.tris;
 
@@ -73,22 +72,26 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
                         path = w.q_closest ? w.q_closest[i] : (int)i;
                         o4 = pa.ray_o[path]; d4 = pa.ray_d[path];
                         tMax = o4.w;
-                    } else if (i < (unsigned)(w.n_closest + w.n_shadow)) {
-                        kind = 1;
-                        path = w.q_shadow[i - w.n_closest];
-                        o4 = pa.sh_o[path]; d4 = pa.sh_d[path];
-                        tMax = o4.w;
                     } else {
-                        kind = 2;
-                        path = w.q_mis[i - w.n_closest - w.n_shadow];
-                        o4 = pa.mis_o[path]; d4 = pa.mis_d[path];
-                        expect = __float_as_int(o4.w);
-                        tMax = GX_INF;
+                        unsigned e = i - (unsigned)w.n_closest;
+                        path = w.q_nee[e >> 1];
+                        int nflags = __float_as_int(pa.sh_d[path].w);
+                        if ((e & 1u) == 0) {
+                            kind = 1;
+                            if (nflags & 1) { o4 = pa.sh_o[path]; d4 = pa.sh_d[path]; tMax = o4.w; }
+                            else item = -1;     // this vertex spawned no shadow ray
+                        } else {
+                            kind = 2;
+                            if (nflags & 2) { o4 = pa.mis_o[path]; d4 = pa.mis_d[path]; expect = __float_as_int(o4.w); tMax = GX_INF; }
+                            else item = -1;
+                        }
                     }
-                    ro = V3(o4.x, o4.y, o4.z); rd = V3(d4.x, d4.y, d4.z);
-                    invDir = V3(1.f / rd.x, 1.f / rd.y, 1.f / rd.z);
-                    neg0 = invDir.x < 0; neg1 = invDir.y < 0; neg2 = invDir.z < 0;
-                    cur = 0; toVisit = 0; leafN = 0; hitLeaf = -1;
+                    if (item >= 0) {
+                        ro = V3(o4.x, o4.y, o4.z); rd = V3(d4.x, d4.y, d4.z);
+                        invDir = V3(1.f / rd.x, 1.f / rd.y, 1.f / rd.z);
+                        neg0 = invDir.x < 0; neg1 = invDir.y < 0; neg2 = invDir.z < 0;
+                        cur = 0; toVisit = 0; leafN = 0; hitLeaf = -1;
+                    }
                 }
                 poolBase += take; poolCount -= take;
             }
@@ -141,7 +144,12 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
         }
         // ---------------- phase C: retire finished rays ----------------
         if (item >= 0 && cur < 0 && leafN == 0) {
-            if (kind == 0) pa.hit[path] = hitLeaf;
+            if (kind == 0) {
+                pa.hit[path] = hitLeaf;
+                int cls = 0;   // misses and null materials only need the emission / pass-through code of class 0
+                if (hitLeaf >= 0) { int mat = tris[hitLeaf].material; if (mat >= 0) cls = sc.materials[mat].shade_class; }
+                pa.pclass[path] = (unsigned char)cls;
+            }
             else if (kind == 1) reinterpret_cast<float *>(&pa.sh_o[path])[3] = hitLeaf < 0 ? 1.f : 0.f;
             else {
                 bool ok = (expect >= 0) ? (hitLeaf == expect) : (hitLeaf < 0);
