@@ -24,7 +24,7 @@ from . import _abi
 from ._abi import (Camera, Hit, Light, Material, Medium, Ray, RenderParams, SceneDesc, Stats)  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgnxr.so")
+LIB_PATH = os.environ.get("GNXR_LIB", os.path.join(_HERE, "libgnxr.so"))   # GNXR_LIB: A/B builds during tuning
 
 
 class GnxrError(RuntimeError):

@@ -5,6 +5,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -104,6 +105,7 @@ struct gnxr_scene {
     CompiledScene cs;
     // device tables
     DevBuf<DNode> nodes;
+    DevBuf<DNode4> nodes4;
     DevBuf<DTri> tris;
     DevBuf<DMaterial> materials;
     DevBuf<DLight> lights;
@@ -124,6 +126,7 @@ struct gnxr_scene {
     DevBuf<Counters> counters;
     Counters *h_counters = nullptr;  // pinned
     int stack_size = 32;
+    bool wide_ok = true;   // 4-wide traversal usable (leaf sizes / triangle count fit the reference encoding)
     std::mutex render_mutex;
 
     ~gnxr_scene() { if (h_counters) (void)hipHostFree(h_counters); }
@@ -131,6 +134,8 @@ struct gnxr_scene {
     DScene device_scene(int W, int H) {
         DScene d;
         d.nodes = reinterpret_cast<const float4 *>(nodes.p);
+        d.nodes4 = reinterpret_cast<const float4 *>(nodes4.p);
+        d.root4 = cs.root4;
         d.tris = tris.p;
         d.materials = materials.p;
         d.lt.lights = lights.p;
@@ -182,9 +187,11 @@ int gnxr_scene_create(const gnxr_scene_desc *desc, gnxr_scene **out) {
     if (!compile_scene(desc, &s->cs)) { delete s; return GNXR_ERR_INVALID; }
     CompiledScene &cs = s->cs;
     if (cs.bvh_max_depth + 1 > 64) { set_error("BVH depth %d exceeds the 64-entry traversal stack (BVHAccel.cpp:661)", cs.bvh_max_depth); delete s; return GNXR_ERR_UNSUPPORTED; }
-    s->stack_size = cs.bvh_max_depth + 1 <= 24 ? 24 : (cs.bvh_max_depth + 1 <= 32 ? 32 : 64);
+    s->stack_size = cs.bvh_max_depth + 1 <= 32 ? 32 : 64;
+    s->wide_ok = cs.tris.size() < (1u << 24) && cs.stack4_need + 1 <= 128 && getenv("GNXR_BINARY_BVH") == nullptr;
+    for (const DNode &n : cs.nodes) if ((n.meta & 0xffffu) > 127) s->wide_ok = false;
 #define UP(field) if ((rc = s->field.upload(cs.field)) != GNXR_OK) { delete s; return rc; }
-    UP(nodes) UP(tris) UP(materials) UP(lights) UP(perms) UP(primes) UP(prime_sums) UP(prime_magic)
+    UP(nodes) UP(nodes4) UP(tris) UP(materials) UP(lights) UP(perms) UP(primes) UP(prime_sums) UP(prime_magic)
     UP(env_texels) UP(env_cond_func) UP(env_cond_cdf) UP(env_cond_int) UP(env_marg_func) UP(env_marg_cdf)
 #undef UP
     if ((rc = s->infinite.upload(cs.infinite_lights)) != GNXR_OK) { delete s; return rc; }
@@ -285,14 +292,17 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
             long long total = (long long)w.n_closest + 2ll * w.n_nee;
             if (total <= 0) return;
             (void)hipMemsetAsync(&dctr->cursor, 0, sizeof(unsigned int), stream);
-            int per_cu = s->stack_size == 24 ? 6 : (s->stack_size == 32 ? 5 : 2);
+            // LDS traversal stack: one column per lane, depth from the BVH (binary walk: depth + 1; 4-wide walk: stack4_need)
+            const bool wide = s->wide_ok && !counting;
+            int entries = wide ? s->cs.stack4_need + 1 : s->cs.bvh_max_depth + 2;
+            size_t lds = (size_t)entries * kBlock * sizeof(int);
+            int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
             // persistent waves: enough blocks to fill the chip, never more than the work needs
             int blocks = (int)std::min<long long>((long long)g_num_cus * per_cu, (total + kBlock - 1) / kBlock);
             if (timing) timer.begin(0, stream);
-#define GX_LAUNCH_TRACE(ST, CNT) hipLaunchKernelGGL((k_trace<ST, CNT>), dim3(blocks), dim3(kBlock), 0, stream, sc, pa, w, &dctr->cursor, dctr)
-            if (counting) { if (s->stack_size == 24) GX_LAUNCH_TRACE(24, true); else if (s->stack_size == 32) GX_LAUNCH_TRACE(32, true); else GX_LAUNCH_TRACE(64, true); }
-            else { if (s->stack_size == 24) GX_LAUNCH_TRACE(24, false); else if (s->stack_size == 32) GX_LAUNCH_TRACE(32, false); else GX_LAUNCH_TRACE(64, false); }
-#undef GX_LAUNCH_TRACE
+            if (counting) hipLaunchKernelGGL((k_trace<true, false>), dim3(blocks), dim3(kBlock), lds, stream, sc, pa, w, &dctr->cursor, dctr);
+            else if (wide) hipLaunchKernelGGL((k_trace<false, true>), dim3(blocks), dim3(kBlock), lds, stream, sc, pa, w, &dctr->cursor, dctr);
+            else hipLaunchKernelGGL((k_trace<false, false>), dim3(blocks), dim3(kBlock), lds, stream, sc, pa, w, &dctr->cursor, dctr);
             if (timing) timer.end(stream);
             rays_closest += (unsigned long long)w.n_closest + (unsigned long long)n_mis;
             rays_any += (unsigned long long)n_sh;

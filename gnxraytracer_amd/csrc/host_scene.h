@@ -38,6 +38,9 @@ bool read_rgbe(const char *path, std::vector<float> *rgb, int *w, int *h);  // w
 struct CompiledScene {
     // geometry
     std::vector<DNode> nodes;
+    std::vector<DNode4> nodes4;          // two-level collapse of `nodes` (same leaf visiting order)
+    int32_t root4 = 0;                   // root reference (a leaf ref when the scene has a single leaf)
+    int stack4_need = 1;                 // worst-case traversal stack entries for nodes4
     std::vector<DTri> tris;              // leaf order
     std::vector<int32_t> leaf_of_prim;   // authoring index -> leaf index
     int bvh_max_depth = 0;

@@ -50,6 +50,8 @@ struct Counters {
 
 struct DScene {
     const float4 *nodes;
+    const float4 *nodes4;   // DNode4[] as 8 float4 each
+    int root4;
     const DTri *tris;
     const DMaterial *materials;
     DLightTables lt;

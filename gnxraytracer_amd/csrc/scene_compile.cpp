@@ -106,6 +106,47 @@ static int flatten(const std::vector<BuildNode> &bn, int node, std::vector<DNode
     return me;
 }
 
+// ------------------------------------------------------------------ BVH4 collapse
+namespace {
+inline bool is_leaf(const DNode &n) { return (n.meta & 0xffffu) != 0; }
+inline int32_t leaf_ref(const DNode &n) { return ~(int32_t)((uint32_t)n.offset | ((n.meta & 0x7fu) << 24)); }
+
+// returns a child reference for binary node `bi`; interior nodes become DNode4s (pre-order)
+int32_t collapse(const std::vector<DNode> &bn, int bi, std::vector<DNode4> &out, int depthStack, int *needStack) {
+    const DNode &N = bn[bi];
+    if (is_leaf(N)) return leaf_ref(N);
+    int me = (int)out.size();
+    out.push_back(DNode4());
+    DNode4 d;
+    memset(&d, 0, sizeof(d));
+    for (int k = 0; k < 4; ++k) d.child[k] = kNode4Empty;
+    d.axis0 = (int)(N.meta >> 16);
+    int A = bi + 1, B = N.offset;
+    int grand[4] = {-1, -1, -1, -1};
+    auto group = [&](int X, int base, int *axisOut) {
+        const DNode &x = bn[X];
+        if (is_leaf(x)) { grand[base] = X; *axisOut = 0; }
+        else { grand[base] = X + 1; grand[base + 1] = x.offset; *axisOut = (int)(x.meta >> 16); }
+    };
+    group(A, 0, &d.axisA);
+    group(B, 2, &d.axisB);
+    int nchild = 0;
+    for (int k = 0; k < 4; ++k) if (grand[k] >= 0) ++nchild;
+    // a node can leave nchild-1 references on the stack while its first child is being traversed
+    int below = depthStack + nchild - 1;
+    *needStack = std::max(*needStack, below + 1);
+    for (int k = 0; k < 4; ++k) {
+        if (grand[k] < 0) continue;
+        const DNode &g = bn[grand[k]];
+        d.lox[k] = g.lo[0]; d.loy[k] = g.lo[1]; d.loz[k] = g.lo[2];
+        d.hix[k] = g.hi0; d.hiy[k] = g.hi1; d.hiz[k] = g.hi2;
+        d.child[k] = collapse(bn, grand[k], out, below, needStack);
+    }
+    out[me] = d;
+    return me;
+}
+}  // namespace
+
 // ------------------------------------------------------------------ materials -> lobes
 static inline float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
 static inline float roughness_to_alpha(float roughness) {  // MicroFacet.h:97-103
@@ -568,6 +609,10 @@ bool compile_scene(const gnxr_scene_desc *d, CompiledScene *cs) {
     cs->nodes.reserve(bb.nodes.size());
     cs->bvh_max_depth = 0;
     flatten(bb.nodes, root, cs->nodes, 0, &cs->bvh_max_depth);
+    cs->nodes4.clear();
+    cs->stack4_need = 1;
+    cs->root4 = collapse(cs->nodes, 0, cs->nodes4, 0, &cs->stack4_need);
+    if (cs->nodes4.empty()) cs->nodes4.push_back(DNode4());
     cs->world_bound.lo = Vec3(cs->nodes[0].lo[0], cs->nodes[0].lo[1], cs->nodes[0].lo[2]);
     cs->world_bound.hi = Vec3(cs->nodes[0].hi0, cs->nodes[0].hi1, cs->nodes[0].hi2);
     // ---- triangles in leaf order

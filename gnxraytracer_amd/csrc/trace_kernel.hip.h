@@ -27,10 +27,72 @@ struct TraceWork {
 };
 
 constexpr int kTraceChunk = 512;   // rays a wave takes per global atomic
+#ifndef GX_TRACE_LEAVE_MUL
+#define GX_TRACE_LEAVE_MUL 1
+#endif
+#ifndef GX_TRACE_LEAVE_DIV
+#define GX_TRACE_LEAVE_DIV 2
+#endif
+constexpr int kTraceLeaveMul = GX_TRACE_LEAVE_MUL, kTraceLeaveDiv = GX_TRACE_LEAVE_DIV;   // leave phase A when searching <= live * MUL / DIV
 
-template <int STACK, bool COUNT>
+// 4-wide step: test the four children of `node`, return the first one hit in the reference's visiting order and push
+// the others (in reverse order) on the lane's LDS stack.  Box test = Bounds3::IntersectP (Geometry.h:1380-1406).
+GX_DEV int bvh4_step(const float4 *__restrict__ n4, int node, V3 ro, V3 invDir, int neg0, int neg1, int neg2, float tMax, int *stack, int &toVisit) {
+    const float4 *q = n4 + 8 * (size_t)node;
+    float4 lox = q[0], loy = q[1], loz = q[2], hix = q[3], hiy = q[4], hiz = q[5];
+    float4 cf = q[6], mf = q[7];
+    const float k = 1 + 2 * GX_GAMMA(3);
+    const float L[4][6] = {{lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x}, {lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y},
+                           {lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z}, {lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w}};
+    const int child[4] = {__float_as_int(cf.x), __float_as_int(cf.y), __float_as_int(cf.z), __float_as_int(cf.w)};
+    unsigned hitMask = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float tMin = ((neg0 ? L[c][3] : L[c][0]) - ro.x) * invDir.x;
+        float tMx = ((neg0 ? L[c][0] : L[c][3]) - ro.x) * invDir.x;
+        float tyMin = ((neg1 ? L[c][4] : L[c][1]) - ro.y) * invDir.y;
+        float tyMax = ((neg1 ? L[c][1] : L[c][4]) - ro.y) * invDir.y;
+        tMx *= k; tyMax *= k;
+        bool ok = !(tMin > tyMax || tyMin > tMx);
+        if (tyMin > tMin) tMin = tyMin;
+        if (tyMax < tMx) tMx = tyMax;
+        float tzMin = ((neg2 ? L[c][5] : L[c][2]) - ro.z) * invDir.z;
+        float tzMax = ((neg2 ? L[c][2] : L[c][5]) - ro.z) * invDir.z;
+        tzMax *= k;
+        ok = ok && !(tMin > tzMax || tzMin > tMx);
+        if (tzMin > tMin) tMin = tzMin;
+        if (tzMax < tMx) tMx = tzMax;
+        ok = ok && (tMin < tMax) && (tMx > 0) && child[c] != kNode4Empty;
+        hitMask |= ok ? (1u << c) : 0u;
+    }
+    // visiting order of BVHAccel::Intersect over the two collapsed levels
+    int axis0 = __float_as_int(mf.x), axisA = __float_as_int(mf.y), axisB = __float_as_int(mf.z);
+    int n0 = axis0 == 0 ? neg0 : (axis0 == 1 ? neg1 : neg2);
+    int nA = axisA == 0 ? neg0 : (axisA == 1 ? neg1 : neg2);
+    int nB = axisB == 0 ? neg0 : (axisB == 1 ? neg1 : neg2);
+    int base0 = n0 ? 2 : 0, base1 = 2 - base0;
+    int sw0 = n0 ? nB : nA, sw1 = n0 ? nA : nB;
+    int order[4] = {base0 + sw0, base0 + 1 - sw0, base1 + sw1, base1 + 1 - sw1};
+    int next = kRefDone;
+    bool have = false;
+#pragma unroll
+    for (int kk = 3; kk >= 0; --kk) {
+        int sidx = order[kk];
+        if ((hitMask >> sidx) & 1u) {
+            if (have) stack[(toVisit++) * kBlock] = next;
+            next = sidx == 0 ? child[0] : (sidx == 1 ? child[1] : (sidx == 2 ? child[2] : child[3]));
+            have = true;
+        }
+    }
+    if (!have) next = (toVisit == 0) ? kRefDone : stack[(--toVisit) * kBlock];
+    return next;
+}
+
+// COUNT: count nodes / triangles (profiling).  WIDE: traverse the collapsed 4-wide tree (sc.nodes4) instead of the
+// reference's binary nodes; the counting runs use WIDE = false so that the counts are those of the reference traversal.
+template <bool COUNT, bool WIDE>
 __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, TraceWork w, unsigned int *cursor, Counters *ctr) {
-    __shared__ int stack_mem[STACK * kBlock];
+    extern __shared__ int stack_mem[];   // stackEntries * kBlock ints, sized by the host from the BVH depth
     int *stack = &stack_mem[threadIdx.x];
     const int lane = __lane_id();
     const unsigned total = (unsigned)w.n_closest + 2u * (unsigned)w.n_nee;
@@ -90,7 +152,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
                         ro = V3(o4.x, o4.y, o4.z); rd = V3(d4.x, d4.y, d4.z);
                         invDir = V3(1.f / rd.x, 1.f / rd.y, 1.f / rd.z);
                         neg0 = invDir.x < 0; neg1 = invDir.y < 0; neg2 = invDir.z < 0;
-                        cur = 0; toVisit = 0; leafN = 0; hitLeaf = -1;
+                        cur = WIDE ? sc.root4 : 0; toVisit = 0; leafN = 0; hitLeaf = -1;
                     }
                 }
                 poolBase += take; poolCount -= take;
@@ -102,34 +164,64 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
         }
 
         // ---------------- phase A: interior traversal until every active lane holds a leaf ----------------
+        // Leave the walk as soon as at most a quarter of the live lanes is still searching: waiting for the last
+        // straggler left ~3/4 of the wave idle (the stragglers simply resume in the next round).
+        const int nLive = __popcll(__ballot(item >= 0));
         while (true) {
+            if (WIDE && item >= 0 && leafN == 0 && cur < -1) {   // the next reference is a leaf: stage it, pre-pop its successor
+                int lr = ~cur;
+                leafOff = lr & 0xffffff; leafN = (lr >> 24) & 0x7f;
+                cur = (toVisit == 0) ? -1 : stack[(--toVisit) * kBlock];
+            }
             bool searching = item >= 0 && cur >= 0 && leafN == 0;
-            if (__ballot(searching) == 0) break;
+            int nSearching = __popcll(__ballot(searching));
+            if (nSearching * kTraceLeaveDiv <= nLive * kTraceLeaveMul && (nSearching == 0 || nSearching < nLive)) break;
             if (searching) {
-                float4 n0 = nodes[2 * cur], n1 = nodes[2 * cur + 1];
                 if (COUNT) cntNodes++;
-                int neg[3] = {neg0, neg1, neg2};
-                bool hitBox = slab_test(n0, n1, ro, invDir, neg, tMax);
-                int offset = __float_as_int(n1.z);
-                uint32_t meta = __float_as_uint(n1.w);
-                int nPrims = (int)(meta & 0xffffu);
-                int next;
-                if (hitBox && nPrims == 0) {
-                    int axis = (int)(meta >> 16);
-                    int ng = axis == 0 ? neg0 : (axis == 1 ? neg1 : neg2);
-                    int nearC = ng ? offset : cur + 1, farC = ng ? cur + 1 : offset;
-                    stack[(toVisit++) * kBlock] = farC;
-                    next = nearC;
+                if (WIDE) {
+                    int next = bvh4_step(sc.nodes4, cur, ro, invDir, neg0, neg1, neg2, tMax, stack, toVisit);
+                    cur = (next == kRefDone) ? -1 : next;   // interior index, leaf reference (< -1) or done
                 } else {
-                    if (hitBox) { leafOff = offset; leafN = nPrims; }
-                    next = (toVisit == 0) ? -1 : stack[(--toVisit) * kBlock];
+                    float4 n0 = nodes[2 * cur], n1 = nodes[2 * cur + 1];
+                    int neg[3] = {neg0, neg1, neg2};
+                    bool hitBox = slab_test(n0, n1, ro, invDir, neg, tMax);
+                    int offset = __float_as_int(n1.z);
+                    uint32_t meta = __float_as_uint(n1.w);
+                    int nPrims = (int)(meta & 0xffffu);
+                    int next;
+                    if (hitBox && nPrims == 0) {
+                        int axis = (int)(meta >> 16);
+                        int ng = axis == 0 ? neg0 : (axis == 1 ? neg1 : neg2);
+                        int nearC = ng ? offset : cur + 1, farC = ng ? cur + 1 : offset;
+                        stack[(toVisit++) * kBlock] = farC;
+                        next = nearC;
+                    } else {
+                        if (hitBox) { leafOff = offset; leafN = nPrims; }
+                        next = (toVisit == 0) ? -1 : stack[(--toVisit) * kBlock];
+                    }
+                    cur = next;
                 }
-                cur = next;
             }
         }
         // ---------------- phase B: triangle tests ----------------
         if (item >= 0 && leafN > 0) {
-            for (int i = 0; i < leafN; ++i) {
+            bool visit = true;
+            if (WIDE && hitLeaf >= 0) {   // tMax only ever shrinks after a hit: before the first hit the earlier test stands
+                // BVHAccel::Intersect tests a leaf's box when it pops it, i.e. against the CURRENT ray.tMax; the 4-wide
+                // step tested it earlier with an older tMax.  Re-test here so that exact ties (t == tMax on flat,
+                // axis-aligned boxes such as the Cornell walls) resolve as in the reference.  The leaf box is the
+                // union of its triangles' bounds (Triangle::WorldBound), recomputed exactly from the vertices.
+                V3 lo(GX_INF, GX_INF, GX_INF), hi(-GX_INF, -GX_INF, -GX_INF);
+                for (int i = 0; i < leafN; ++i) {
+                    V3 p0, p1, p2;
+                    load_tri(tris, leafOff + i, &p0, &p1, &p2);
+                    lo = V3(fminf(lo.x, fminf(p0.x, fminf(p1.x, p2.x))), fminf(lo.y, fminf(p0.y, fminf(p1.y, p2.y))), fminf(lo.z, fminf(p0.z, fminf(p1.z, p2.z))));
+                    hi = V3(fmaxf(hi.x, fmaxf(p0.x, fmaxf(p1.x, p2.x))), fmaxf(hi.y, fmaxf(p0.y, fmaxf(p1.y, p2.y))), fmaxf(hi.z, fmaxf(p0.z, fmaxf(p1.z, p2.z))));
+                }
+                int neg[3] = {neg0, neg1, neg2};
+                visit = slab_test(make_float4(lo.x, lo.y, lo.z, hi.x), make_float4(hi.y, hi.z, 0.f, 0.f), ro, invDir, neg, tMax);
+            }
+            for (int i = 0; visit && i < leafN; ++i) {
                 V3 p0, p1, p2;
                 load_tri(tris, leafOff + i, &p0, &p1, &p2);
                 if (COUNT) cntTris++;
@@ -143,7 +235,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
             leafN = 0;
         }
         // ---------------- phase C: retire finished rays ----------------
-        if (item >= 0 && cur < 0 && leafN == 0) {
+        if (item >= 0 && cur == -1 && leafN == 0) {
             if (kind == 0) {
                 pa.hit[path] = hitLeaf;
                 int cls = 0;   // misses and null materials only need the emission / pass-through code of class 0
