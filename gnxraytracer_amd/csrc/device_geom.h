@@ -14,19 +14,32 @@ struct TriHit {
     float t, b0, b1, b2;
 };
 
+// Ray-only part of the watertight test (Triangle.cpp:91-105): the permutation and the shear depend on the ray
+// direction alone, so k_trace computes them once per ray instead of once per triangle (three IEEE divisions and the
+// component permutation leave the per-triangle loop; the values are the ones the reference recomputes each time).
+struct RayShear {
+    int kx, ky, kz;
+    float Sx, Sy, Sz;
+};
+GX_DEV RayShear ray_shear(V3 rd) {
+    RayShear r;
+    V3 ad = vabs(rd);
+    r.kz = (ad.x > ad.y) ? ((ad.x > ad.z) ? 0 : 2) : ((ad.y > ad.z) ? 1 : 2);  // MaxDimension
+    r.kx = r.kz + 1; if (r.kx == 3) r.kx = 0;
+    r.ky = r.kx + 1; if (r.ky == 3) r.ky = 0;
+    V3 d(rd[r.kx], rd[r.ky], rd[r.kz]);
+    r.Sx = -d.x / d.z; r.Sy = -d.y / d.z; r.Sz = 1.f / d.z;
+    return r;
+}
+GX_DEV V3 permute3(V3 v, int kz) {   // (v[kx], v[ky], v[kz]) with kx = kz+1, ky = kz+2 (mod 3)
+    return kz == 0 ? V3(v.y, v.z, v.x) : (kz == 1 ? V3(v.z, v.x, v.y) : V3(v.x, v.y, v.z));
+}
+
 // The ray-space part of Triangle::Intersect (Triangle.cpp:82-168): returns true and fills `h` when the
 // ray hits within (0, tMax].  Identical arithmetic for Intersect and IntersectP.
-GX_DEV bool tri_test(V3 p0, V3 p1, V3 p2, V3 ro, V3 rd, float tMax, TriHit *h) {
-    V3 p0t = p0 - ro, p1t = p1 - ro, p2t = p2 - ro;
-    V3 ad = vabs(rd);
-    int kz = (ad.x > ad.y) ? ((ad.x > ad.z) ? 0 : 2) : ((ad.y > ad.z) ? 1 : 2);  // MaxDimension
-    int kx = kz + 1; if (kx == 3) kx = 0;
-    int ky = kx + 1; if (ky == 3) ky = 0;
-    V3 d(rd[kx], rd[ky], rd[kz]);
-    p0t = V3(p0t[kx], p0t[ky], p0t[kz]);
-    p1t = V3(p1t[kx], p1t[ky], p1t[kz]);
-    p2t = V3(p2t[kx], p2t[ky], p2t[kz]);
-    float Sx = -d.x / d.z, Sy = -d.y / d.z, Sz = 1.f / d.z;
+GX_DEV bool tri_test_sheared(V3 p0, V3 p1, V3 p2, V3 ro, const RayShear &rs, float tMax, TriHit *h) {
+    V3 p0t = permute3(p0 - ro, rs.kz), p1t = permute3(p1 - ro, rs.kz), p2t = permute3(p2 - ro, rs.kz);
+    const float Sx = rs.Sx, Sy = rs.Sy, Sz = rs.Sz;
     p0t.x += Sx * p0t.z; p0t.y += Sy * p0t.z;
     p1t.x += Sx * p1t.z; p1t.y += Sy * p1t.z;
     p2t.x += Sx * p2t.z; p2t.y += Sy * p2t.z;
@@ -66,6 +79,10 @@ GX_DEV bool tri_test(V3 p0, V3 p1, V3 p2, V3 ro, V3 rd, float tMax, TriHit *h) {
     if (t <= deltaT) return false;
     h->t = t; h->b0 = b0; h->b1 = b1; h->b2 = b2;
     return true;
+}
+GX_DEV bool tri_test(V3 p0, V3 p1, V3 p2, V3 ro, V3 rd, float tMax, TriHit *h) {
+    RayShear rs = ray_shear(rd);
+    return tri_test_sheared(p0, p1, p2, ro, rs, tMax, h);
 }
 
 GX_DEV void load_tri(const DTri *tris, int leaf, V3 *p0, V3 *p1, V3 *p2) {
