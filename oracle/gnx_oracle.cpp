@@ -64,6 +64,10 @@ int gnxo_render(gnxo_scene *s, const gnxr_render_params *p, float *rgba, gnxr_st
     camera.medium = scene.cameraMedium;
     Halton halton(p->spp, p->width, p->height, false);
     PathParams pp; pp.maxDepth = p->max_depth; pp.rrThreshold = p->rr_threshold;
+    VolContext vc;
+    vc.rc = &rc;
+    vc.media.Init(&scene);
+    rc.mediaSet = &vc;
     int sBegin = p->spp_begin, sEnd = p->spp_end > 0 ? p->spp_end : p->spp;
     int shardCount = std::max(1, p->shard_count), shardRows = std::max(1, p->shard_rows);
     scene.counters.nIntersect = 0; scene.counters.nIntersectP = 0; scene.counters.nNodes = 0; scene.counters.nTris = 0;
@@ -107,6 +111,7 @@ int gnxo_render(gnxo_scene *s, const gnxr_render_params *p, float *rgba, gnxr_st
     return 0;
 }
 void gnxo_set_count_traversal(gnxo_scene *s, int on) { s->scene.countTraversal = on != 0; }
+int gnxo_max_dimension(int reset) { int v = SampleStream::MaxDimensionSeen().load(); if (reset) SampleStream::MaxDimensionSeen().store(0); return v; }
 
 int gnxo_trace_closest(gnxo_scene *s, const gnxr_ray *rays, int64_t n, gnxr_hit *hits) {
     const Scene &scene = s->scene;

@@ -188,6 +188,27 @@ def main():
     img, cnt = render(cornell_path, 64, 64, 8, strat=1)
     imgs["cornell_uniform"], imgs["cornell_uniform_rays"], imgs["cornell_uniform_cfg"] = img, cnt, np.array([64, 64, 8, 8], np.int32)
     save("render.npz", **imgs)
+    # ---- 11: VolPathIntegrator (cfg 5).  The reference's density grid travels as a data fixture; the two volume
+    # scenes keep sigma_t small enough that no sample reaches Halton dimension 1000 (reference UB beyond).
+    v = scenes.read_volume_file("/root/reference/Resources/density_render.70.volume")
+    np.savez_compressed(os.path.join(G, "density_70.npz"), density=v["density"], nx=v["nx"], ny=v["ny"], nz=v["nz"],
+                        sigma_a=np.array(v["sigma_a"], np.float32), sigma_s=np.array(v["sigma_s"], np.float32))
+    vols = {}
+    for name, b in [("vol_synth", scenes.volume_cornell(sigma_a=(0.5,) * 3, sigma_s=(3.5,) * 3, g_grid=0.3)),
+                    ("vol_cfg5", scenes.volume_cornell_cfg5(sigma_scale=0.05, golden_dir=G))]:
+        path = scene_file(b, name)
+        W, H, spp = 64, 64, 16
+        raw = ol.run_ref(path, "render", None, [W, H, spp, 8, 1.0, 0, 0, 1])
+        vols[name] = np.frombuffer(raw[:W * H * 16], np.float32).reshape(H, W, 4).copy()
+        vols[name + "_rays"] = np.frombuffer(raw[W * H * 16:W * H * 16 + 16], np.uint64).copy()
+        vols[name + "_cfg"] = np.array([W, H, spp, 8], np.int32)
+        ol.olib().gnxo_max_dimension(1)
+        oimg, st = ol.OracleScene(b).render(gx.VolPathIntegrator(8, 1.0, "spatial"), W, H, spp)
+        maxdim = ol.olib().gnxo_max_dimension(1)
+        print(name, "rays", vols[name + "_rays"], "max dimension", maxdim)
+        assert maxdim < 1000, "fixture reaches the reference's undefined dimensions"
+        assert (oimg.view(np.uint32) == vols[name].view(np.uint32)).all()
+    save("render_vol.npz", **vols)
     # cfg 2 at full size: the counts the survey recorded from the COMPLETE reference
     img, cnt = render(cornell_path, 256, 256, 64)
     checksum = float(img[..., :3].astype(np.float64).sum())

@@ -27,6 +27,7 @@ struct RenderContext {
     std::vector<int> infiniteLights;       // indices of lights flagged Infinite (Scene ctor, Scene.h:20-27)
     std::vector<std::unique_ptr<InfiniteAreaLight>> envLights;  // per light index (null if not INFINITE)
     int lightStrategy = GNXR_LIGHTS_SPATIAL;
+    const void *mediaSet = nullptr;        // MediaSet (o_media.h), set by the render entry point for VolPath
     // light distributions
     Distribution1D uniformOrPower;
     int nVoxels[3] = {1, 1, 1};

@@ -1,8 +1,341 @@
 // ORACLE -- TEST INFRASTRUCTURE ONLY (see o_math.h header).
-// o_media.h: VolPathIntegrator / WhittedIntegrator restatements (filled in after the Path slice).
+//
+// o_media.h: CPU restatement of the participating-media path (BASELINE config 5):
+//   HomogeneousMedium::Tr / Sample                  media/HomogeneousMedium.cpp:11-43
+//   GridDensityMedium::Density / Sample / Tr        media/GridDensityMedium.cpp:14-87, GridDensityMedium.h:19-44
+//   HenyeyGreenstein::p / Sample_p, PhaseHG         core/Medium.cpp:164-189, core/Medium.h:34-38
+//   VisibilityTester::Tr                            core/Light.cpp:33-53
+//   Scene::IntersectTr                              core/Scene.cpp:26-40
+//   EstimateDirect (handleMedia = true)             core/Integrator.cpp:93-210
+//   VolPathIntegrator::Li                           integrators/VolPathIntegrator.cpp:24-159
+//   WhittedIntegrator::Li / SpecularReflect/Transmit integrators/WhittedIntegrator.cpp:14-68, core/Integrator.cpp:321-442
 #pragma once
 #include "o_integrator.h"
+
 namespace gnxo {
-inline Spec VolPathLi(const RenderContext &, const PathParams &, const Ray &, SampleStream &) { return Spec(0.f); }
+
+static constexpr Float MaxFloat = std::numeric_limits<Float>::max();
+inline Spec Exp(const Spec &s) { return Spec(std::exp(s.c[0]), std::exp(s.c[1]), std::exp(s.c[2])); }
+
+// core/Medium.h:34-38
+inline Float PhaseHG(Float cosTheta, Float g) {
+    Float denom = 1 + g * g + 2 * g * cosTheta;
+    return Inv4Pi * (1 - g * g) / (denom * std::sqrt(denom));
+}
+// core/Medium.cpp:164-189
+inline Float HG_p(Float g, const V3 &wo, const V3 &wi) { return PhaseHG(Dot(wo, wi), g); }
+inline Float HG_Sample_p(Float g, const V3 &wo, V3 *wi, const P2 &u) {
+    Float cosTheta;
+    if (std::abs(g) < 1e-3) cosTheta = 1 - 2 * u.x;
+    else {
+        Float sqrTerm = (1 - g * g) / (1 + g - 2 * g * u.x);
+        cosTheta = -(1 + g * g - sqrTerm * sqrTerm) / (2 * g);
+    }
+    Float sinTheta = std::sqrt(std::max((Float)0, 1 - cosTheta * cosTheta));
+    Float phi = 2 * Pi * u.y;
+    V3 v1, v2;
+    CoordinateSystem(wo, &v1, &v2);
+    // SphericalDirection(sinTheta, cosTheta, phi, x, y, z), Geometry.h
+    *wi = sinTheta * std::cos(phi) * v1 + sinTheta * std::sin(phi) * v2 + cosTheta * wo;
+    return PhaseHG(cosTheta, g);
+}
+
+struct MediumInteraction {
+    bool valid = false;
+    V3 p, wo;
+    int medium = -1;
+    Float g = 0;
+    Interaction AsInteraction() const {
+        Interaction it;
+        it.p = p; it.wo = wo; it.n = V3(); it.pError = V3();
+        it.mediumInside = it.mediumOutside = medium;
+        return it;
+    }
+};
+
+// Transform::operator()(Ray) with the error-bounded origin shift, Transform.h:230-244
+inline Ray XRay(const M44 &m, const Ray &r) {
+    V3 oError;
+    V3 o = XPointErr(m, r.o, &oError);
+    V3 d = XVector(m, r.d);
+    Float lengthSquared = d.LengthSquared();
+    Float tMax = r.tMax;
+    if (lengthSquared > 0) {
+        Float dt = Dot(Abs(d), oError) / lengthSquared;
+        o += d * dt;
+        tMax -= dt;
+    }
+    return Ray(o, d, tMax, r.medium);
+}
+
+struct MediaSet {
+    const Scene *scene = nullptr;
+    struct Grid { M44 worldToMedium; Float sigma_t, invMaxDensity; const float *d; int nx, ny, nz; };
+    std::vector<Grid> grids;  // per medium (valid for GRID)
+    void Init(const Scene *s) {
+        scene = s;
+        grids.resize(s->media.size());
+        for (size_t i = 0; i < s->media.size(); ++i) {
+            const gnxr_medium &m = s->media[i];
+            if (m.type != GNXR_MEDIUM_GRID) continue;
+            Grid &g = grids[i];
+            g.worldToMedium = Inverse(M44::FromRowMajor(m.medium_to_world));
+            g.nx = m.nx; g.ny = m.ny; g.nz = m.nz;
+            g.d = s->gridDensity.data() + m.density_offset;
+            g.sigma_t = (Spec(m.sigma_a[0], m.sigma_a[1], m.sigma_a[2]) + Spec(m.sigma_s[0], m.sigma_s[1], m.sigma_s[2]))[0];
+            Float maxDensity = 0;
+            for (int k = 0; k < m.nx * m.ny * m.nz; ++k) maxDensity = std::max(maxDensity, g.d[k]);
+            g.invMaxDensity = 1 / maxDensity;
+        }
+    }
+    // GridDensityMedium::D / Density
+    Float D(const Grid &g, int x, int y, int z) const {
+        if (x < 0 || y < 0 || z < 0 || x >= g.nx || y >= g.ny || z >= g.nz) return 0;
+        return g.d[(z * g.ny + y) * g.nx + x];
+    }
+    Float Density(const Grid &g, const V3 &p) const {
+        V3 ps(p.x * g.nx - .5f, p.y * g.ny - .5f, p.z * g.nz - .5f);
+        int px = (int)std::floor(ps.x), py = (int)std::floor(ps.y), pz = (int)std::floor(ps.z);
+        V3 d = ps - V3((Float)px, (Float)py, (Float)pz);
+        Float d00 = Lerp(d.x, D(g, px, py, pz), D(g, px + 1, py, pz));
+        Float d10 = Lerp(d.x, D(g, px, py + 1, pz), D(g, px + 1, py + 1, pz));
+        Float d01 = Lerp(d.x, D(g, px, py, pz + 1), D(g, px + 1, py, pz + 1));
+        Float d11 = Lerp(d.x, D(g, px, py + 1, pz + 1), D(g, px + 1, py + 1, pz + 1));
+        Float d0 = Lerp(d.y, d00, d10);
+        Float d1 = Lerp(d.y, d01, d11);
+        return Lerp(d.z, d0, d1);
+    }
+    Spec Tr(int mi, const Ray &ray, SampleStream &sampler) const {
+        const gnxr_medium &m = scene->media[mi];
+        if (m.type == GNXR_MEDIUM_HOMOGENEOUS) {  // HomogeneousMedium.cpp:11-15
+            Spec sigma_t = Spec(m.sigma_s[0], m.sigma_s[1], m.sigma_s[2]) + Spec(m.sigma_a[0], m.sigma_a[1], m.sigma_a[2]);
+            return Exp(-sigma_t * std::min(ray.tMax * ray.d.Length(), MaxFloat));
+        }
+        const Grid &g = grids[mi];  // GridDensityMedium.cpp:57-87 (ratio tracking)
+        Ray r = XRay(g.worldToMedium, Ray(ray.o, Normalize(ray.d), ray.tMax * ray.d.Length()));
+        Float tMin, tMax;
+        if (!BoundsIntersectP(Bounds3(V3(0, 0, 0), V3(1, 1, 1)), r, &tMin, &tMax)) return Spec(1.f);
+        Float Tr = 1, t = tMin;
+        while (true) {
+            t -= std::log(1 - sampler.Get1D()) * g.invMaxDensity / g.sigma_t;
+            if (t >= tMax) break;
+            Float density = Density(g, r(t));
+            Tr *= 1 - std::max((Float)0, density * g.invMaxDensity);
+            const Float rrThreshold = .1;
+            if (Tr < rrThreshold) {
+                Float q = std::max((Float).05, 1 - Tr);
+                if (sampler.Get1D() < q) return Spec(0.f);
+                Tr /= 1 - q;
+            }
+        }
+        return Spec(Tr);
+    }
+    Spec Sample(int mi, const Ray &ray, SampleStream &sampler, MediumInteraction *out) const {
+        const gnxr_medium &m = scene->media[mi];
+        if (m.type == GNXR_MEDIUM_HOMOGENEOUS) {  // HomogeneousMedium.cpp:17-43
+            Spec sigma_s(m.sigma_s[0], m.sigma_s[1], m.sigma_s[2]);
+            Spec sigma_t = sigma_s + Spec(m.sigma_a[0], m.sigma_a[1], m.sigma_a[2]);
+            int channel = std::min((int)(sampler.Get1D() * 3), 3 - 1);
+            Float dist = -std::log(1 - sampler.Get1D()) / sigma_t[channel];
+            Float t = std::min(dist / ray.d.Length(), ray.tMax);
+            bool sampledMedium = t < ray.tMax;
+            if (sampledMedium) { out->valid = true; out->p = ray(t); out->wo = -ray.d; out->medium = mi; out->g = m.g; }
+            Spec Tr = Exp(-sigma_t * std::min(t, MaxFloat) * ray.d.Length());
+            Spec density = sampledMedium ? (sigma_t * Tr) : Tr;
+            Float pdf = 0;
+            for (int i = 0; i < 3; ++i) pdf += density[i];
+            pdf *= 1 / (Float)3;
+            if (pdf == 0) pdf = 1;
+            return sampledMedium ? (Tr * sigma_s / pdf) : (Tr / pdf);
+        }
+        const Grid &g = grids[mi];  // GridDensityMedium.cpp:31-55 (delta tracking)
+        Ray r = XRay(g.worldToMedium, Ray(ray.o, Normalize(ray.d), ray.tMax * ray.d.Length()));
+        Float tMin, tMax;
+        if (!BoundsIntersectP(Bounds3(V3(0, 0, 0), V3(1, 1, 1)), r, &tMin, &tMax)) return Spec(1.f);
+        Float t = tMin;
+        while (true) {
+            t -= std::log(1 - sampler.Get1D()) * g.invMaxDensity / g.sigma_t;
+            if (t >= tMax) break;
+            if (Density(g, r(t)) * g.invMaxDensity > sampler.Get1D()) {
+                out->valid = true; out->p = ray(t); out->wo = -ray.d; out->medium = mi; out->g = m.g;
+                return Spec(m.sigma_s[0], m.sigma_s[1], m.sigma_s[2]) / g.sigma_t;
+            }
+        }
+        return Spec(1.f);
+    }
+};
+
+struct VolContext {
+    const RenderContext *rc;
+    MediaSet media;
+};
+
+// VisibilityTester::Tr, core/Light.cpp:33-53
+inline Spec VisibilityTr(const VolContext &vc, const Interaction &p0, const Interaction &p1, SampleStream &sampler) {
+    const Scene &scene = *vc.rc->scene;
+    Ray ray = p0.SpawnRayTo(p1);
+    Spec Tr(1.f);
+    while (true) {
+        SurfaceInteraction isect;
+        bool hitSurface = scene.Intersect(ray, &isect);
+        if (hitSurface && scene.triMaterial[isect.prim] >= 0 && scene.materials[scene.triMaterial[isect.prim]].type != GNXR_MAT_NONE) return Spec(0.0f);
+        if (ray.medium >= 0) Tr *= vc.media.Tr(ray.medium, ray, sampler);
+        if (!hitSurface) break;
+        ray = isect.SpawnRayTo(p1);
+    }
+    return Tr;
+}
+// Scene::IntersectTr, core/Scene.cpp:26-40
+inline bool IntersectTr(const VolContext &vc, Ray ray, SampleStream &sampler, SurfaceInteraction *isect, Spec *Tr) {
+    const Scene &scene = *vc.rc->scene;
+    *Tr = Spec(1.f);
+    while (true) {
+        bool hitSurface = scene.Intersect(ray, isect);
+        if (ray.medium >= 0) *Tr *= vc.media.Tr(ray.medium, ray, sampler);
+        if (!hitSurface) return false;
+        int mat = scene.triMaterial[isect->prim];
+        if (mat >= 0 && scene.materials[mat].type != GNXR_MAT_NONE) return true;
+        ray = isect->SpawnRay(ray.d);
+    }
+}
+
+// EstimateDirect with handleMedia = true for a surface (bsdf != nullptr) or medium (mi != nullptr) interaction
+inline Spec EstimateDirectMedia(const VolContext &vc, const Interaction &it, const SurfaceInteraction *isect, const BSDF *bsdf, const MediumInteraction *mi,
+                                const P2 &uScattering, int light, const P2 &uLight, SampleStream &sampler) {
+    const RenderContext &rc = *vc.rc;
+    int bsdfFlags = BSDF_ALL & ~BSDF_SPECULAR;
+    Spec Ld(0.f);
+    Float lightPdf = 0, scatteringPdf = 0;
+    LightSample ls = rc.Sample_Li(light, it, uLight);
+    V3 wi = ls.wi;
+    lightPdf = ls.pdf;
+    Spec Li = ls.Li;
+    if (lightPdf > 0 && !Li.IsBlack()) {
+        Spec f;
+        if (isect) {
+            f = bsdf->f(isect->wo, wi, bsdfFlags) * AbsDot(wi, isect->sn);
+            scatteringPdf = bsdf->Pdf(isect->wo, wi, bsdfFlags);
+        } else {
+            Float p = HG_p(mi->g, mi->wo, wi);
+            f = Spec(p);
+            scatteringPdf = p;
+        }
+        if (!f.IsBlack()) {
+            Li *= VisibilityTr(vc, it, ls.p1, sampler);
+            if (!Li.IsBlack()) {
+                Float weight = PowerHeuristic(1, lightPdf, 1, scatteringPdf);
+                Ld += f * Li * weight / lightPdf;
+            }
+        }
+    }
+    {
+        Spec f;
+        bool sampledSpecular = false;
+        if (isect) {
+            int sampledType = 0;
+            f = bsdf->Sample_f(isect->wo, &wi, uScattering, &scatteringPdf, bsdfFlags, &sampledType);
+            f *= AbsDot(wi, isect->sn);
+            sampledSpecular = (sampledType & BSDF_SPECULAR) != 0;
+        } else {
+            Float p = HG_Sample_p(mi->g, mi->wo, &wi, uScattering);
+            f = Spec(p);
+            scatteringPdf = p;
+        }
+        if (!f.IsBlack() && scatteringPdf > 0) {
+            Float weight = 1;
+            if (!sampledSpecular) {
+                lightPdf = rc.Pdf_Li(light, it, wi);
+                if (lightPdf == 0) return Ld;
+                weight = PowerHeuristic(1, scatteringPdf, 1, lightPdf);
+            }
+            SurfaceInteraction lightIsect;
+            Ray ray = it.SpawnRay(wi);
+            Spec Tr(1.f);
+            bool found = IntersectTr(vc, ray, sampler, &lightIsect, &Tr);
+            Spec Li2(0.f);
+            if (found) {
+                if (rc.scene->triLight[lightIsect.prim] == light) Li2 = rc.Le(lightIsect, -wi);
+            } else
+                Li2 = rc.LightLe(light, ray);
+            if (!Li2.IsBlack()) Ld += f * Li2 * Tr * weight / scatteringPdf;
+        }
+    }
+    return Ld;
+}
+
+inline Spec UniformSampleOneLightMedia(const VolContext &vc, const Interaction &it, const SurfaceInteraction *isect, const BSDF *bsdf, const MediumInteraction *mi,
+                                       SampleStream &sampler, const Distribution1D *lightDistrib) {
+    int nLights = (int)vc.rc->scene->lights.size();
+    if (nLights == 0) return Spec(0.f);
+    Float lightPdf;
+    int lightNum = lightDistrib->SampleDiscrete(sampler.Get1D(), &lightPdf);
+    if (lightPdf == 0) return Spec(0.f);
+    P2 uLight = sampler.Get2D();
+    P2 uScattering = sampler.Get2D();
+    return EstimateDirectMedia(vc, it, isect, bsdf, mi, uScattering, lightNum, uLight, sampler) / lightPdf;
+}
+
+// integrators/VolPathIntegrator.cpp:24-159
+inline Spec VolPathLi(const RenderContext &rc, const PathParams &pp, const Ray &r, SampleStream &sampler) {
+    const Scene &scene = *rc.scene;
+    const VolContext &vc = *static_cast<const VolContext *>(rc.mediaSet);
+    Spec L(0.f), beta(1.f);
+    Ray ray(r);
+    bool specularBounce = false;
+    int bounces;
+    Float etaScale = 1;
+    for (bounces = 0;; ++bounces) {
+        SurfaceInteraction isect;
+        bool foundIntersection = scene.Intersect(ray, &isect);
+        MediumInteraction mi;
+        if (ray.medium >= 0) beta *= vc.media.Sample(ray.medium, ray, sampler, &mi);
+        if (beta.IsBlack()) break;
+        if (mi.valid) {
+            if (bounces >= pp.maxDepth) break;
+            Interaction mit = mi.AsInteraction();
+            const Distribution1D *lightDistrib = rc.Lookup(mi.p);
+            L += beta * UniformSampleOneLightMedia(vc, mit, nullptr, nullptr, &mi, sampler, lightDistrib);
+            V3 wo = -ray.d, wi;
+            HG_Sample_p(mi.g, wo, &wi, sampler.Get2D());
+            ray = mit.SpawnRay(wi);
+            specularBounce = false;
+        } else {
+            if (bounces == 0 || specularBounce) {
+                if (foundIntersection) L += beta * rc.Le(isect, -ray.d);
+                else for (int light : rc.infiniteLights) L += beta * rc.LightLe(light, ray);
+            }
+            if (!foundIntersection || bounces >= pp.maxDepth) break;
+            BSDF bsdf;
+            if (!ComputeScatteringFunctions(scene, &isect, true, &bsdf)) {
+                ray = isect.SpawnRay(ray.d);
+                bounces--;
+                continue;
+            }
+            const Distribution1D *lightDistrib = rc.Lookup(isect.p);
+            L += beta * UniformSampleOneLightMedia(vc, isect, &isect, &bsdf, nullptr, sampler, lightDistrib);
+            V3 wo = -ray.d, wi;
+            Float pdf;
+            int flags = 0;
+            Spec f = bsdf.Sample_f(wo, &wi, sampler.Get2D(), &pdf, BSDF_ALL, &flags);
+            if (f.IsBlack() || pdf == 0.f) break;
+            beta *= f * AbsDot(wi, isect.sn) / pdf;
+            specularBounce = (flags & BSDF_SPECULAR) != 0;
+            if ((flags & BSDF_SPECULAR) && (flags & BSDF_TRANSMISSION)) {
+                Float eta = bsdf.eta;
+                etaScale *= (Dot(wo, isect.n) > 0) ? (eta * eta) : 1 / (eta * eta);
+            }
+            ray = isect.SpawnRay(wi);
+        }
+        Spec rrBeta = beta * etaScale;
+        if (rrBeta.MaxComponentValue() < pp.rrThreshold && bounces > 3) {
+            Float q = std::max((Float).05, 1 - rrBeta.MaxComponentValue());
+            if (sampler.Get1D() < q) break;
+            beta /= 1 - q;
+        }
+    }
+    return L;
+}
+
 inline Spec WhittedLi(const RenderContext &, const PathParams &, const Ray &, SampleStream &, int) { return Spec(0.f); }
+
 }  // namespace gnxo

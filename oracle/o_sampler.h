@@ -10,6 +10,7 @@
 // The 1000-entry Primes / PrimeSums tables (LowDiscrepancy.cpp:9,93) are regenerated with a
 // sieve instead of being copied.
 #pragma once
+#include <atomic>
 #include <vector>
 
 #include "o_math.h"
@@ -225,6 +226,11 @@ struct SampleStream {
     int64_t index;
     int dimension;
     SampleStream(const Halton *h, int px, int py, int64_t s) : h(h), index(h->IndexForSample(px, py, s)), dimension(0) {}
+    ~SampleStream() {  // highest dimension any sample used: fixtures must stay below PrimeTableSize (reference UB beyond)
+        int cur = MaxDimensionSeen().load(std::memory_order_relaxed);
+        while (dimension > cur && !MaxDimensionSeen().compare_exchange_weak(cur, dimension)) {}
+    }
+    static std::atomic<int> &MaxDimensionSeen() { static std::atomic<int> m{0}; return m; }
     Float Get1D() { return h->SampleDimension(index, dimension++); }
     P2 Get2D() {
         P2 p(h->SampleDimension(index, dimension), h->SampleDimension(index, dimension + 1));

@@ -41,6 +41,8 @@
 #include "materials/MetalMaterial.h"
 #include "materials/MirrorMaterial.h"
 #include "materials/PlasticMaterial.h"
+#include "media/GridDensityMedium.h"
+#include "media/HomogeneousMedium.h"
 #include "samplers/HaltonSampler.h"
 #include "samplers/LowDiscrepancy.h"
 #include "shape/Triangle.h"
@@ -136,6 +138,7 @@ struct RefScene {
     std::vector<std::shared_ptr<TriangleMesh>> meshes;
     std::vector<std::shared_ptr<Shape>> shapes;
     std::vector<std::shared_ptr<Material>> materials;
+    std::vector<std::shared_ptr<Medium>> media;
     std::vector<std::shared_ptr<Light>> lights;
     std::vector<std::shared_ptr<Primitive>> prims;
     std::unordered_map<const Primitive *, int> primIndex;
@@ -145,6 +148,14 @@ struct RefScene {
 
     void build() {
         for (auto &m : sf.mats) materials.push_back(makeMaterial(m));
+        for (auto &m : sf.media) {
+            if (m.type == GNXR_MEDIUM_HOMOGENEOUS) media.push_back(std::make_shared<HomogeneousMedium>(S3(m.sigma_a), S3(m.sigma_s), m.g));
+            else {
+                Matrix4x4 mm;
+                memcpy(mm.m, m.medium_to_world, 64);
+                media.push_back(std::make_shared<GridDensityMedium>(S3(m.sigma_a), S3(m.sigma_s), m.g, m.nx, m.ny, m.nz, Transform(mm), sf.density.data() + m.density_offset));
+            }
+        }
         // one single-triangle mesh per triangle, identity transform: world-space vertices pass through
         // TriangleMesh's ObjectToWorld(P[i]) unchanged (1*x + 0*y + 0*z + 0, wp == 1)
         lights.resize(sf.nl);
@@ -167,7 +178,8 @@ struct RefScene {
                 lights[li] = area;
             }
             std::shared_ptr<Material> mat = sf.triMat[t] >= 0 ? materials[sf.triMat[t]] : nullptr;
-            auto prim = std::make_shared<GeometricPrimitive>(tri, mat, area, MediumInterface());
+            MediumInterface mif(sf.medIn[t] >= 0 ? media[sf.medIn[t]].get() : nullptr, sf.medOut[t] >= 0 ? media[sf.medOut[t]].get() : nullptr);
+            auto prim = std::make_shared<GeometricPrimitive>(tri, mat, area, mif);
             primIndex[prim.get()] = t;
             prims.push_back(prim);
         }
@@ -372,6 +384,137 @@ Spectrum refPathLi(const RayDifferential &r, const Scene &scene, Sampler &sample
             etaScale *= (Dot(wo, isect.n) > 0) ? (eta * eta) : 1 / (eta * eta);
         }
         ray = isect.SpawnRay(wi);
+        Spectrum rrBeta = beta * etaScale;
+        if (rrBeta.MaxComponentValue() < rrThreshold && bounces > 3) {
+            Float q = std::max((Float).05, 1 - rrBeta.MaxComponentValue());
+            if (sampler.Get1D() < q) break;
+            beta /= 1 - q;
+        }
+    }
+    return L;
+}
+
+// ---- restated EstimateDirect (handleMedia = true) / VolPathIntegrator::Li over pbr classes ----
+Spectrum refEstimateDirectMedia(const Interaction &it, const Point2f &uScattering, const Light &light, const Point2f &uLight, const Scene &scene,
+                                Sampler &sampler) {
+    BxDFType bsdfFlags = BxDFType(BSDF_ALL & ~BSDF_SPECULAR);
+    Spectrum Ld(0.f);
+    Vector3f wi;
+    Float lightPdf = 0, scatteringPdf = 0;
+    VisibilityTester visibility;
+    Spectrum Li = light.Sample_Li(it, uLight, &wi, &lightPdf, &visibility);
+    if (lightPdf > 0 && !Li.IsBlack()) {
+        Spectrum f;
+        if (it.IsSurfaceInteraction()) {
+            const SurfaceInteraction &isect = (const SurfaceInteraction &)it;
+            f = isect.bsdf->f(isect.wo, wi, bsdfFlags) * AbsDot(wi, isect.shading.n);
+            scatteringPdf = isect.bsdf->Pdf(isect.wo, wi, bsdfFlags);
+        } else {
+            const MediumInteraction &mi = (const MediumInteraction &)it;
+            Float p = mi.phase->p(mi.wo, wi);
+            f = Spectrum(p);
+            scatteringPdf = p;
+        }
+        if (!f.IsBlack()) {
+            Li *= visibility.Tr(scene, sampler);
+            if (!Li.IsBlack()) {
+                Float weight = PowerHeuristic(1, lightPdf, 1, scatteringPdf);
+                Ld += f * Li * weight / lightPdf;
+            }
+        }
+    }
+    if (!IsDeltaLight(light.flags)) {
+        Spectrum f;
+        bool sampledSpecular = false;
+        if (it.IsSurfaceInteraction()) {
+            BxDFType sampledType;
+            const SurfaceInteraction &isect = (const SurfaceInteraction &)it;
+            f = isect.bsdf->Sample_f(isect.wo, &wi, uScattering, &scatteringPdf, bsdfFlags, &sampledType);
+            f *= AbsDot(wi, isect.shading.n);
+            sampledSpecular = (sampledType & BSDF_SPECULAR) != 0;
+        } else {
+            const MediumInteraction &mi = (const MediumInteraction &)it;
+            Float p = mi.phase->Sample_p(mi.wo, &wi, uScattering);
+            f = Spectrum(p);
+            scatteringPdf = p;
+        }
+        if (!f.IsBlack() && scatteringPdf > 0) {
+            Float weight = 1;
+            if (!sampledSpecular) {
+                lightPdf = light.Pdf_Li(it, wi);
+                if (lightPdf == 0) return Ld;
+                weight = PowerHeuristic(1, scatteringPdf, 1, lightPdf);
+            }
+            SurfaceInteraction lightIsect;
+            Ray ray = it.SpawnRay(wi);
+            Spectrum Tr(1.f);
+            bool found = scene.IntersectTr(ray, sampler, &lightIsect, &Tr);
+            Spectrum Li2(0.f);
+            if (found) {
+                if (lightIsect.primitive->GetAreaLight() == &light) Li2 = lightIsect.Le(-wi);
+            } else
+                Li2 = light.Le(ray);
+            if (!Li2.IsBlack()) Ld += f * Li2 * Tr * weight / scatteringPdf;
+        }
+    }
+    return Ld;
+}
+
+Spectrum refOneLightMedia(const Interaction &it, const Scene &scene, Sampler &sampler, const Distribution1D *distrib) {
+    int nLights = int(scene.lights.size());
+    if (nLights == 0) return Spectrum(0.f);
+    Float lightPdf;
+    int lightNum = distrib->SampleDiscrete(sampler.Get1D(), &lightPdf);
+    if (lightPdf == 0) return Spectrum(0.f);
+    const std::shared_ptr<Light> &light = scene.lights[lightNum];
+    Point2f uLight = sampler.Get2D();
+    Point2f uScattering = sampler.Get2D();
+    return refEstimateDirectMedia(it, uScattering, *light, uLight, scene, sampler) / lightPdf;
+}
+
+Spectrum refVolPathLi(const RayDifferential &r, const Scene &scene, Sampler &sampler, MemoryArena &arena, RefLightDistribution &ld, int maxDepth, Float rrThreshold) {
+    Spectrum L(0.f), beta(1.f);
+    RayDifferential ray(r);
+    bool specularBounce = false;
+    int bounces;
+    Float etaScale = 1;
+    for (bounces = 0;; ++bounces) {
+        SurfaceInteraction isect;
+        bool foundIntersection = scene.Intersect(ray, &isect);
+        MediumInteraction mi;
+        if (ray.medium) beta *= ray.medium->Sample(ray, sampler, arena, &mi);
+        if (beta.IsBlack()) break;
+        if (mi.IsValid()) {
+            if (bounces >= maxDepth) break;
+            const Distribution1D *distrib = ld.Lookup(mi.p);
+            L += beta * refOneLightMedia(mi, scene, sampler, distrib);
+            Vector3f wo = -ray.d, wi;
+            mi.phase->Sample_p(wo, &wi, sampler.Get2D());
+            ray = mi.SpawnRay(wi);
+            specularBounce = false;
+        } else {
+            if (bounces == 0 || specularBounce) {
+                if (foundIntersection) L += beta * isect.Le(-ray.d);
+                else for (const auto &light : scene.infiniteLights) L += beta * light->Le(ray);
+            }
+            if (!foundIntersection || bounces >= maxDepth) break;
+            isect.ComputeScatteringFunctions(ray, arena, true);
+            if (!isect.bsdf) { ray = isect.SpawnRay(ray.d); bounces--; continue; }
+            const Distribution1D *distrib = ld.Lookup(isect.p);
+            L += beta * refOneLightMedia(isect, scene, sampler, distrib);
+            Vector3f wo = -ray.d, wi;
+            Float pdf;
+            BxDFType flags;
+            Spectrum f = isect.bsdf->Sample_f(wo, &wi, sampler.Get2D(), &pdf, BSDF_ALL, &flags);
+            if (f.IsBlack() || pdf == 0.f) break;
+            beta *= f * AbsDot(wi, isect.shading.n) / pdf;
+            specularBounce = (flags & BSDF_SPECULAR) != 0;
+            if ((flags & BSDF_SPECULAR) && (flags & BSDF_TRANSMISSION)) {
+                Float eta = isect.bsdf->eta;
+                etaScale *= (Dot(wo, isect.n) > 0) ? (eta * eta) : 1 / (eta * eta);
+            }
+            ray = isect.SpawnRay(wi);
+        }
         Spectrum rrBeta = beta * etaScale;
         if (rrBeta.MaxComponentValue() < rrThreshold && bounces > 3) {
             Float q = std::max((Float).05, 1 - rrBeta.MaxComponentValue());
@@ -613,7 +756,8 @@ int main(int argc, char **argv) {
         int W = atoi(argv[5]), H = atoi(argv[6]), spp = atoi(argv[7]), maxDepth = atoi(argv[8]);
         Float rr = (Float)atof(argv[9]);
         int strat = atoi(argv[10]);
-        if (argc > 11) omp_set_num_threads(atoi(argv[11]));
+        if (argc > 11 && atoi(argv[11]) > 0) omp_set_num_threads(atoi(argv[11]));
+        const bool volpath = argc > 12 && atoi(argv[12]) == 1;
         const gnxr_camera &c = rs.sf.cam;
         Transform lookat = LookAt(Point3f(c.eye[0], c.eye[1], c.eye[2]), Point3f(c.look[0], c.look[1], c.look[2]), Vector3f(c.up[0], c.up[1], c.up[2]));
         Transform c2w = Inverse(lookat), c2wEnd = c2w;
@@ -637,7 +781,7 @@ int main(int argc, char **argv) {
                     RayDifferential ray;
                     cam->GenerateRayDifferential(cs, &ray);
                     ray.ScaleDifferentials(1 / std::sqrt((Float)ps->samplesPerPixel));
-                    col += refPathLi(ray, scene, *ps, arena, ld, maxDepth, rr);
+                    col += volpath ? refVolPathLi(ray, scene, *ps, arena, ld, maxDepth, rr) : refPathLi(ray, scene, *ps, arena, ld, maxDepth, rr);
                 } while (ps->StartNextSample());
                 col = col / ps->samplesPerPixel;
                 size_t o = ((size_t)i + (size_t)j * W) * 4;

@@ -112,3 +112,87 @@ def random_rays(n, seed=0, inside=2.4, tmax=np.inf):
     d = rng.normal(size=(n, 3)).astype(np.float32)
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     return gx.make_rays(o, d.astype(np.float32), tmax)
+
+
+def box_mesh(lo, hi):
+    """12 triangles with outward geometric normals (n = Cross(p0-p2, p1-p2), shape/Triangle.cpp:223)."""
+    x0, y0, z0 = lo
+    x1, y1, z1 = hi
+    v = np.array([[x0, y0, z0], [x1, y0, z0], [x1, y1, z0], [x0, y1, z0], [x0, y0, z1], [x1, y0, z1], [x1, y1, z1], [x0, y1, z1]], np.float32)
+    quads = [(0, 3, 2, 1), (4, 5, 6, 7), (0, 1, 5, 4), (2, 3, 7, 6), (1, 2, 6, 5), (0, 4, 7, 3)]   # -z +z -y +y +x -x, CCW from outside
+    idx = []
+    for a, b, c, d in quads:
+        idx += [[a, b, c], [a, c, d]]
+    return v, np.array(idx, np.int32)
+
+
+def synthetic_density(nx=24, ny=24, nz=12, seed=3):
+    """Smooth seeded smoke-like density in [0, 1] (stand-in for Resources/density_render.70.volume in tests)."""
+    z, y, x = np.mgrid[0:nz, 0:ny, 0:nx].astype(np.float32)
+    x, y, z = (x + 0.5) / nx, (y + 0.5) / ny, (z + 0.5) / nz
+    rng = np.random.default_rng(seed)
+    d = np.zeros_like(x)
+    for _ in range(5):
+        c = rng.random(3)
+        r = 0.15 + 0.2 * rng.random()
+        d += np.exp(-((x - c[0]) ** 2 + (y - c[1]) ** 2 + (z - c[2]) ** 2) / (r * r))
+    d = (d / d.max()).astype(np.float32)
+    return np.ascontiguousarray(d)   # [nz, ny, nx]: density[(z*ny + y)*nx + x], GridDensityMedium.h:34-38
+
+
+def read_volume_file(path):
+    """Resources/density_render.70.volume: `nx N ny N nz N / p0 / p1 / sigma_a / sigma_s` then nx*ny*nz floats (CRLF)."""
+    toks = open(path).read().split()
+    nx, ny, nz = int(toks[1]), int(toks[3]), int(toks[5])
+    p0 = [float(t) for t in toks[7:10]]
+    p1 = [float(t) for t in toks[11:14]]
+    sa = [float(t) for t in toks[15:18]]
+    ss = [float(t) for t in toks[19:22]]
+    d = np.array(toks[22:22 + nx * ny * nz], np.float32)
+    return dict(nx=nx, ny=ny, nz=nz, p0=p0, p1=p1, sigma_a=sa, sigma_s=ss, density=d)
+
+
+def volume_cornell(density=None, sigma_a=(10, 10, 10), sigma_s=(90, 90, 90), g_grid=0.0, grid_lo=(-1.6, -2.4, -1.2), grid_hi=(0.2, -0.6, 0.4)):
+    """cfg 5: Cornell + a null-material box filled with a GridDensityMedium + a second null-material box with the
+    HomogeneousMedium(2.4, 1.4, 0.5) of ui/RenderThread.cpp:107.  mediumToWorld = Translate(lo) * Scale(hi - lo)."""
+    b = cornell()
+    if density is None:
+        density = synthetic_density()
+    nz, ny, nx = density.shape
+    lo, hi = np.array(grid_lo, np.float32), np.array(grid_hi, np.float32)
+    m2w = np.eye(4, dtype=np.float32)
+    m2w[0, 0], m2w[1, 1], m2w[2, 2] = hi - lo
+    m2w[0:3, 3] = lo
+    grid = gx.Medium()
+    grid.type = gx._abi.MEDIUM_GRID
+    grid.nx, grid.ny, grid.nz = nx, ny, nz
+    grid.sigma_a[:] = sigma_a
+    grid.sigma_s[:] = sigma_s
+    grid.g = g_grid
+    grid.medium_to_world[:] = m2w.reshape(16)
+    mg = b.add_medium(grid, density)
+    hom = gx.Medium()
+    hom.type = gx._abi.MEDIUM_HOMOGENEOUS
+    hom.sigma_a[:] = (2.4, 2.4, 2.4)
+    hom.sigma_s[:] = (1.4, 1.4, 1.4)
+    hom.g = 0.5
+    mh = b.add_medium(hom)
+    v, i = box_mesh(grid_lo, grid_hi)
+    b.add_mesh(v, i, -1, medium_inside=mg, medium_outside=-1)
+    v, i = box_mesh((0.6, -2.4, -0.8), (1.9, -0.9, 0.6))
+    b.add_mesh(v, i, -1, medium_inside=mh, medium_outside=-1)
+    return b
+
+
+def reference_density(golden_dir=None):
+    """The reference's own density grid (Resources/density_render.70.volume, 100x100x40), kept as a data fixture."""
+    g = np.load(os.path.join(golden_dir or os.path.join(ROOT, "tests", "golden"), "density_70.npz"))
+    return np.ascontiguousarray(g["density"].reshape(int(g["nz"]), int(g["ny"]), int(g["nx"])))
+
+
+def volume_cornell_cfg5(sigma_scale=1.0, golden_dir=None):
+    """cfg 5 with the reference's density grid (sigma_a 10, sigma_s 90 from the file header) in a 2 x 2 x 0.8 box.
+    sigma_scale < 1 keeps the delta-tracking loops below Halton dimension 1000, past which the reference reads
+    PrimeSums out of bounds (undefined there; this build wraps, device_sampler.h)."""
+    return volume_cornell(reference_density(golden_dir), sigma_a=(10 * sigma_scale,) * 3, sigma_s=(90 * sigma_scale,) * 3,
+                          grid_lo=(-1.9, -2.4, -0.4), grid_hi=(0.1, -0.4, 0.4))

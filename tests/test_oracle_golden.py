@@ -134,6 +134,20 @@ def test_render_images(name, gx):
     assert biteq(img, g[name])
 
 
+@pytest.mark.parametrize("name", ["vol_synth", "vol_cfg5"])
+def test_volpath_images(name, gx):
+    """VolPathIntegrator::Li + GridDensityMedium / HomogeneousMedium / HenyeyGreenstein (cfg 5): the restated loop
+    running on the reference's own Medium, BSDF, Light and BVH classes produced these images and ray counts."""
+    g = golden("render_vol.npz")
+    W, H, spp, depth = (int(v) for v in g[name + "_cfg"])
+    b = scenes.volume_cornell(sigma_a=(0.5,) * 3, sigma_s=(3.5,) * 3, g_grid=0.3) if name == "vol_synth" else scenes.volume_cornell_cfg5(0.05)
+    ol.olib().gnxo_max_dimension(1)
+    img, st = ol.OracleScene(b).render(gx.VolPathIntegrator(depth, 1.0, "spatial"), W, H, spp)
+    assert ol.olib().gnxo_max_dimension(1) < 1000       # beyond this the reference indexes PrimeSums out of bounds
+    assert (st["rays_closest"], st["rays_any"]) == tuple(int(v) for v in g[name + "_rays"])
+    assert biteq(img, g[name])
+
+
 def test_cfg2_reproduces_the_recorded_reference_run(gx):
     """the complete reference traced 16 058 662 closest-hit and 12 329 468 any-hit rays
     for cfg 2 and its image summed to 78538.576918.  This pins the restated Render / Li / EstimateDirect /
