@@ -11,6 +11,7 @@
 
 #include "host_scene.h"
 #include "kernels.hip.h"
+#include "vol_kernel.hip.h"
 
 using namespace gnxr;
 
@@ -115,6 +116,9 @@ struct gnxr_scene {
     DevBuf<uint32_t> prime_magic;
     DevBuf<float> env_texels, env_cond_func, env_cond_cdf, env_cond_int, env_marg_func, env_marg_cdf;
     DevBuf<float> grid_table;
+    DevBuf<DMedium> dmedia;
+    DevBuf<float> grid_density;
+    DevBuf<int32_t> tri_media;
     DLightGrid grid;
     int grid_strategy = -1;
     // per-render state (grown on demand)
@@ -123,6 +127,8 @@ struct gnxr_scene {
     DevBuf<int> hit, queue_a, queue_b, queue_nee, queue_c0, queue_c1, queue_c2;
     DevBuf<unsigned char> pflags, pclass;
     DevBuf<unsigned int> tile_counts;
+    DevBuf<float4> vol_n1, vol_f, vol_Li, vol_Tr, vol_Ld;   // VolPath light-estimate records (vol_kernel.hip.h)
+    DevBuf<int4> vol_vs;
     DevBuf<Counters> counters;
     Counters *h_counters = nullptr;  // pinned
     int stack_size = 32;
@@ -152,6 +158,13 @@ struct gnxr_scene {
         d.st.perms = perms.p; d.st.primes = primes.p; d.st.prime_sums = prime_sums.p; d.st.prime_magic = prime_magic.p;
         d.st.h = make_halton(W, H);
         return d;
+    }
+    DMediaTables media_tables() {
+        DMediaTables m;
+        m.media = dmedia.p;
+        m.density = grid_density.p;
+        m.tri_media = cs.tri_media.empty() ? nullptr : reinterpret_cast<const int2 *>(tri_media.p);
+        return m;
     }
     int ensure_grid(int strategy) {
         if (grid_strategy == strategy) return GNXR_OK;
@@ -192,6 +205,7 @@ int gnxr_scene_create(const gnxr_scene_desc *desc, gnxr_scene **out) {
     for (const DNode &n : cs.nodes) if ((n.meta & 0xffffu) > 127) s->wide_ok = false;
 #define UP(field) if ((rc = s->field.upload(cs.field)) != GNXR_OK) { delete s; return rc; }
     UP(nodes) UP(nodes4) UP(tris) UP(materials) UP(lights) UP(perms) UP(primes) UP(prime_sums) UP(prime_magic)
+    UP(dmedia) UP(grid_density) UP(tri_media)
     UP(env_texels) UP(env_cond_func) UP(env_cond_cdf) UP(env_cond_int) UP(env_marg_func) UP(env_marg_cdf)
 #undef UP
     if ((rc = s->infinite.upload(cs.infinite_lights)) != GNXR_OK) { delete s; return rc; }
@@ -228,7 +242,11 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
         set_error("invalid render parameters");
         return GNXR_ERR_INVALID;
     }
-    if (p.integrator != GNXR_INTEGRATOR_PATH) { set_error("integrator %d has no device implementation yet", p.integrator); return GNXR_ERR_UNSUPPORTED; }
+    if (p.integrator != GNXR_INTEGRATOR_PATH && p.integrator != GNXR_INTEGRATOR_VOLPATH) {
+        set_error("integrator %d has no device implementation (Whitted is the reference's CPU-only config 1)", p.integrator);
+        return GNXR_ERR_UNSUPPORTED;
+    }
+    const bool volpath = p.integrator == GNXR_INTEGRATOR_VOLPATH;
     std::lock_guard<std::mutex> lock(s->render_mutex);
     auto t_start = std::chrono::steady_clock::now();
     hipStream_t stream = (hipStream_t)hip_stream;
@@ -257,12 +275,21 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
 #define AL(f) if ((rc = s->f.alloc(cap)) != GNXR_OK) return rc;
     AL(ray_o) AL(ray_d) AL(beta) AL(L) AL(sh_o) AL(sh_d) AL(sh_X) AL(mis_o) AL(mis_d) AL(mis_Y) AL(nbeta) AL(meta) AL(hit) AL(queue_a) AL(queue_b) AL(queue_nee) AL(queue_c0) AL(queue_c1) AL(queue_c2) AL(pflags) AL(pclass)
 #undef AL
+    if (volpath) {
+#define AL(f) if ((rc = s->f.alloc(cap)) != GNXR_OK) return rc;
+        AL(vol_n1) AL(vol_f) AL(vol_Li) AL(vol_Tr) AL(vol_Ld) AL(vol_vs)
+#undef AL
+    }
     if ((rc = s->accum.alloc(r.npix)) != GNXR_OK) return rc;
     const int max_tiles = (int)((cap + kCompactBlock - 1) / kCompactBlock);
     if ((rc = s->tile_counts.alloc((size_t)4 * max_tiles)) != GNXR_OK) return rc;
     PathArrays pa;
     pa.ray_o = s->ray_o.p; pa.ray_d = s->ray_d.p; pa.beta = s->beta.p; pa.L = s->L.p; pa.meta = s->meta.p; pa.hit = s->hit.p; pa.pflags = s->pflags.p; pa.pclass = s->pclass.p;
     pa.sh_o = s->sh_o.p; pa.sh_d = s->sh_d.p; pa.sh_X = s->sh_X.p; pa.mis_o = s->mis_o.p; pa.mis_d = s->mis_d.p; pa.mis_Y = s->mis_Y.p; pa.nbeta = s->nbeta.p;
+    VolArrays va;
+    va.vs = s->vol_vs.p; va.sv_o = s->sh_o.p; va.sv_d = s->sh_d.p; va.p1 = s->sh_X.p; va.p1e = s->nbeta.p; va.n1 = s->vol_n1.p; va.f = s->vol_f.p;
+    va.Li = s->vol_Li.p; va.Tr = s->vol_Tr.p; va.Ld = s->vol_Ld.p; va.mis_o = s->mis_o.p; va.mis_d = s->mis_d.p; va.mis_Y = s->mis_Y.p;
+    DMediaTables mt = s->media_tables();
 
     HIP_TRY(hipMemsetAsync(s->accum.p, 0, sizeof(float4) * r.npix, stream));
     HIP_TRY(hipMemsetAsync(s->counters.p, 0, sizeof(Counters), stream));
@@ -320,7 +347,26 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
             else hipLaunchKernelGGL((k_compact_scatter<COMPACT_CLASS, 3>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, (const unsigned int *)s->tile_counts.p, tiles, o0, o1, o2);
             launches += 3;
         };
-        launch_trace(TraceWork{nullptr, n, nullptr, 0}, 0, 0);   // camera rays
+        if (volpath) {
+            // one closest-hit ray per live path and round: k_trace -> k_vol_step -> compaction (vol_kernel.hip.h)
+            hipLaunchKernelGGL(k_vol_init, dim3(grid_for(n_paths)), dim3(kBlock), 0, stream, pa, va, n_paths);
+            ++launches;
+            while (n > 0) {
+                launch_trace(TraceWork{q_in, n, nullptr, 0}, 0, 0);
+                if (timing) timer.begin(2, stream);
+                if (area_only) hipLaunchKernelGGL((k_vol_step<LT_AREA>), dim3(grid_for(n)), dim3(kBlock), 0, stream, sc, mt, r, pa, va, q_in, n);
+                else hipLaunchKernelGGL((k_vol_step<LT_ALL>), dim3(grid_for(n)), dim3(kBlock), 0, stream, sc, mt, r, pa, va, q_in, n);
+                ++launches;
+                compact(COMPACT_FLAGS, q_in, n, s->pflags.p, 4, 2, &dctr->q_next, q_cur, s->queue_nee.p, nullptr);
+                if (timing) timer.end(stream);
+                HIP_TRY(hipMemcpyAsync(s->h_counters, dctr, sizeof(Counters), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                n = (int)s->h_counters->q_next;
+                q_in = q_cur;
+                std::swap(q_cur, q_other);
+                if (++guard > (1 << 20)) { set_error("path loop did not terminate"); return GNXR_ERR_INVALID; }
+            }
+        } else launch_trace(TraceWork{nullptr, n, nullptr, 0}, 0, 0);   // camera rays
         while (n > 0) {
             if (timing) timer.begin(2, stream);
             // bin the paths by the shade specialisation of the material they hit (pclass written by k_trace)

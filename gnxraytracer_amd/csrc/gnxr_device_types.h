@@ -107,6 +107,18 @@ struct DEnv {         // InfiniteAreaLight tables
     float marg_func_int;
 };
 
+// Medium (media/HomogeneousMedium.h, media/GridDensityMedium.h): coefficients + the grid's WorldToMedium
+struct DMedium {
+    int32_t type;            // gnxr_medium_type
+    int32_t nx, ny, nz;
+    float sigma_a[3]; float g;
+    float sigma_s[3]; float sigma_t;          // GRID: (sigma_a + sigma_s)[0], GridDensityMedium.h:27
+    float w2m[16];                            // Inverse(mediumToWorld), row-major
+    float inv_max_density;
+    int32_t density_offset;
+    int32_t _pad[2];
+};
+
 struct DLightGrid {
     int32_t nvox[3];
     int32_t n_lights;

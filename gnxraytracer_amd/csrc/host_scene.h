@@ -61,7 +61,9 @@ struct CompiledScene {
     std::vector<float> env_marg_func, env_marg_cdf;
     // media
     std::vector<gnxr_medium> media;
+    std::vector<DMedium> dmedia;
     std::vector<float> grid_density;
+    std::vector<int32_t> tri_media;      // leaf order, (inside, outside) per triangle; empty when no triangle is a medium boundary
     // camera description (matrices depend on the render resolution)
     gnxr_camera camera;
     int camera_medium = -1;

@@ -625,6 +625,7 @@ bool compile_scene(const gnxr_scene_desc *d, CompiledScene *cs) {
         Vec3 p0 = vert(d->indices[3 * prim]), p1 = vert(d->indices[3 * prim + 1]), p2 = vert(d->indices[3 * prim + 2]);
         t.p0[0] = p0.x; t.p0[1] = p0.y; t.p0[2] = p0.z; t.prim = prim;
         t.p1[0] = p1.x; t.p1[1] = p1.y; t.p1[2] = p1.z; t.material = d->tri_material[prim];
+        if (t.material >= 0 && d->materials[t.material].type == GNXR_MAT_NONE) t.material = -1;   // no BSDF: medium boundary
         t.p2[0] = p2.x; t.p2[1] = p2.y; t.p2[2] = p2.z; t.light = d->tri_light[prim];
     }
     // ---- materials
@@ -673,6 +674,38 @@ bool compile_scene(const gnxr_scene_desc *d, CompiledScene *cs) {
         int64_t total = 0;
         for (auto &m : cs->media) if (m.type == GNXR_MEDIUM_GRID) total = std::max<int64_t>(total, m.density_offset + (int64_t)m.nx * m.ny * m.nz);
         if (total > 0) cs->grid_density.assign(d->grid_density, d->grid_density + total);
+    }
+    cs->dmedia.assign(std::max<size_t>(1, cs->media.size()), DMedium());
+    for (size_t i = 0; i < cs->media.size(); ++i) {
+        const gnxr_medium &m = cs->media[i];
+        DMedium &dm = cs->dmedia[i];
+        memset(&dm, 0, sizeof(dm));
+        dm.type = m.type; dm.nx = m.nx; dm.ny = m.ny; dm.nz = m.nz; dm.g = m.g;
+        memcpy(dm.sigma_a, m.sigma_a, 12); memcpy(dm.sigma_s, m.sigma_s, 12);
+        dm.sigma_t = m.sigma_a[0] + m.sigma_s[0];
+        if (m.type == GNXR_MEDIUM_GRID) {
+            if (m.nx <= 0 || m.ny <= 0 || m.nz <= 0) { set_error("medium %d: empty density grid", (int)i); return false; }
+            Mat4 m2w;
+            for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) m2w.m[r][c] = m.medium_to_world[4 * r + c];
+            Mat4 inv = inverse(m2w);   // Transform(Matrix4x4) -> mInv = Inverse(m), Transform.h:110-112
+            for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) dm.w2m[4 * r + c] = inv.m[r][c];
+            float maxDensity = 0;   // GridDensityMedium.h:28-31
+            const float *dd = cs->grid_density.data() + m.density_offset;
+            for (int64_t k = 0; k < (int64_t)m.nx * m.ny * m.nz; ++k) maxDensity = std::max(maxDensity, dd[k]);
+            dm.inv_max_density = 1 / maxDensity;
+            if (m.density_offset + (int64_t)m.nx * m.ny * m.nz >= (1ll << 31)) { set_error("medium %d: density grid too large", (int)i); return false; }
+            dm.density_offset = (int32_t)m.density_offset;
+        } else if (m.type != GNXR_MEDIUM_HOMOGENEOUS) { set_error("medium %d: unknown type %d", (int)i, m.type); return false; }
+    }
+    cs->tri_media.clear();
+    if (d->tri_medium_inside && d->tri_medium_outside) {
+        cs->tri_media.resize(2 * (size_t)d->n_triangles);
+        for (int li = 0; li < d->n_triangles; ++li) {
+            int prim = cs->tris[li].prim;
+            int mi = d->tri_medium_inside[prim], mo = d->tri_medium_outside[prim];
+            if (mi >= d->n_media || mo >= d->n_media) { set_error("medium index out of range"); return false; }
+            cs->tri_media[2 * li] = mi; cs->tri_media[2 * li + 1] = mo;
+        }
     }
     cs->camera = d->camera;
     cs->camera_medium = d->camera_medium;

@@ -1,0 +1,397 @@
+// vol_kernel.hip.h -- VolPathIntegrator::Li (integrators/VolPathIntegrator.cpp:24-159) as a wavefront state machine.
+//
+// In a scene with media every ray of a path vertex is a closest-hit ray (VisibilityTester::Tr and Scene::IntersectTr
+// walk through null-material boundaries with Scene::Intersect, core/Light.cpp:33-53, core/Scene.cpp:26-40), and the
+// delta / ratio tracking loops of each segment draw from the path's own Halton stream.  The number of dimensions a
+// segment consumes depends on what the previous segment hit, so the rays of one path are strictly sequential.  Each
+// path therefore has exactly ONE ray in flight; a round is
+//
+//     k_trace (closest hit for every live path)  ->  k_vol_step (advance every live path to its next ray)
+//
+// and a path is in one of three states:
+//   VS_MAIN    the ray is the path's main ray: medium sampling, Le, null-boundary pass-through, then the vertex
+//              (surface or medium interaction) sets up UniformSampleOneLight (core/Integrator.cpp:57-79, 93-210)
+//   VS_SHADOW  the ray is one segment of VisibilityTester::Tr towards the sampled light point
+//   VS_MIS     the ray is one segment of Scene::IntersectTr along the BSDF- / phase-sampled direction
+// After the light estimate is complete the vertex is re-established from its saved main ray (same arithmetic, same
+// bits) and the continuation direction is sampled at the stream position the transmittance loops left behind.
+#pragma once
+#include "device_media.h"
+
+namespace gnxr {
+
+enum : int { VS_MAIN = 0, VS_SHADOW = 1, VS_MIS = 2 };
+
+struct VolArrays {
+    int4 *vs;        // x: state, y: Halton dimension, z: hit leaf of the saved vertex, w: (unused)
+    float4 *sv_o;    // saved main ray of the vertex: o.xyz, tMax
+    float4 *sv_d;    // d.xyz, medium (int bits)
+    float4 *p1;      // light sample point p1.xyz, w: light-selection pdf
+    float4 *p1e;     // p1Error.xyz, w: light pdf (Sample_Li)
+    float4 *n1;      // n1.xyz, w: MIS weight of the light sample
+    float4 *f;       // f.xyz of the light sample (|cos| included), w: flags (bit0 light-sample part, bit1 scattering part, bit2 Li2 != 0)
+    float4 *Li;      // Li.xyz, w: leaf the scattering ray must reach (int bits; -1 == must escape)
+    float4 *Tr;      // transmittance accumulated along the current NEE ray, w: t of the medium interaction (-1: surface vertex)
+    float4 *Ld;      // direct lighting accumulated so far, w: MIS weight of the scattering sample
+    float4 *mis_o;   // scattering ray origin, w: medium (int bits)
+    float4 *mis_d;   // scattering ray direction, w: scattering pdf
+    float4 *mis_Y;   // f * Li2
+};
+
+__global__ void __launch_bounds__(kBlock) k_vol_init(PathArrays pa, VolArrays va, int n_paths) {
+    for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_paths; slot += gridDim.x * blockDim.x) {
+        uint2 m = pa.meta[slot];
+        va.vs[slot] = make_int4(VS_MAIN, (int)m.y, -1, 0);
+        pa.meta[slot] = make_uint2(m.x, 0u);   // y: bounces << 16 | specularBounce << 31
+    }
+}
+
+// Interaction::GetMedium(w) for a surface hit: GeometricPrimitive::Intersect (core/Primitive.cpp:32-46) keeps the
+// primitive's MediumInterface when it is a transition and the ray's medium otherwise.
+GX_DEV int hit_medium(const DMediaTables &mt, int leaf, int rayMedium, V3 n, V3 w) {
+    int mi = rayMedium, mo = rayMedium;
+    if (mt.tri_media) {
+        int2 tm = mt.tri_media[leaf];
+        if (tm.x != tm.y) { mi = tm.x; mo = tm.y; }
+    }
+    return dot(w, n) > 0 ? mo : mi;
+}
+
+template <int LT>
+__global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt, DRender r, PathArrays pa, VolArrays va, const int *__restrict__ queue, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int path = queue ? queue[i] : i;
+        int4 vs = va.vs[path];
+        uint2 meta = pa.meta[path];
+        const uint32_t index = meta.x;
+        int bounces = (int)((meta.y >> 16) & 0xffu);
+        bool specularBounce = (meta.y >> 31) != 0;
+        SampleStream ss(sc.st, index, vs.y);
+        float4 o4 = pa.ray_o[path], d4 = pa.ray_d[path];
+        V3 ro(o4.x, o4.y, o4.z), rd(d4.x, d4.y, d4.z);
+        int rayMedium = __float_as_int(d4.w);
+        const int leaf = pa.hit[path];
+        bool survive = false;      // the path has a ray in flight after this step
+        bool vertexNew = false;    // phase 2 established a vertex at this step
+        bool vertexDone = false;   // the light estimate of the saved vertex is complete
+        float miT = -1.f;
+        Spec beta, L;
+        float etaScale = 1;
+
+        // the traced ray's hit, shared by all three states
+        bool found = leaf >= 0;
+        V3 p0, p1, p2;
+        int triMat = -1, triLight = -1;
+        TriHit h;
+        if (found) {
+            const float4 *q = reinterpret_cast<const float4 *>(sc.tris + leaf);
+            float4 a = q[0], b = q[1], c = q[2];
+            p0 = V3(a.x, a.y, a.z); p1 = V3(b.x, b.y, b.z); p2 = V3(c.x, c.y, c.z);
+            triMat = __float_as_int(b.w); triLight = __float_as_int(c.w);
+            found = tri_test(p0, p1, p2, ro, rd, o4.w, &h);   // same arithmetic as the traversal
+        }
+
+        if (vs.x != VS_MAIN) {
+            // ---------------- phase 1: one segment of the light-sample ray or of the scattering ray ----------------
+            float4 T4 = va.Tr[path], Ld4 = va.Ld[path], f4 = va.f[path];
+            Spec Tr(T4.x, T4.y, T4.z), Ld(Ld4.x, Ld4.y, Ld4.z);
+            const int nflags = __float_as_int(f4.w);
+            SurfacePoint sp;
+            sp.valid = false;
+            if (found) { sp = surface_point(p0, p1, p2, h, false); found = sp.valid; }
+            const float tSeg = found ? h.t : o4.w;
+            bool segDone = false;
+            if (vs.x == VS_SHADOW) {   // VisibilityTester::Tr, Light.cpp:33-53
+                if (found && triMat >= 0) {
+                    segDone = true;    // blocked: Tr = 0, Li becomes black, nothing is added
+                } else {
+                    if (rayMedium >= 0) Tr = Tr * medium_tr(mt, rayMedium, ro, rd, tSeg, ss);
+                    if (!found) {
+                        segDone = true;
+                        float4 Li4 = va.Li[path];
+                        Spec Li = Spec(Li4.x, Li4.y, Li4.z) * Tr;
+                        if (!Li.is_black()) Ld = Ld + Spec(f4.x, f4.y, f4.z) * Li * va.n1[path].w / va.p1e[path].w;
+                    } else {           // ray = isect.SpawnRayTo(p1)
+                        float4 q1 = va.p1[path], q1e = va.p1e[path], qn1 = va.n1[path];
+                        V3 so, sd;
+                        spawn_ray_to(sp.p, sp.pError, sp.n, V3(q1.x, q1.y, q1.z), V3(q1e.x, q1e.y, q1e.z), V3(qn1.x, qn1.y, qn1.z), &so, &sd);
+                        pa.ray_o[path] = make_float4(so.x, so.y, so.z, 1 - GX_SHADOW_EPS);
+                        pa.ray_d[path] = make_float4(sd.x, sd.y, sd.z, __int_as_float(hit_medium(mt, leaf, rayMedium, sp.n, sd)));
+                    }
+                }
+                if (segDone && (nflags & 2)) {   // go on with the scattering ray: it.SpawnRay(wi), Integrator.cpp:193
+                    float4 mo = va.mis_o[path], md = va.mis_d[path];
+                    pa.ray_o[path] = make_float4(mo.x, mo.y, mo.z, GX_INF);
+                    pa.ray_d[path] = make_float4(md.x, md.y, md.z, mo.w);
+                    Tr = Spec(1.f);
+                    vs.x = VS_MIS;
+                    segDone = false;
+                }
+            } else {                   // Scene::IntersectTr, Scene.cpp:26-40
+                if (rayMedium >= 0) Tr = Tr * medium_tr(mt, rayMedium, ro, rd, tSeg, ss);
+                if (found && triMat < 0) {   // ray = isect->SpawnRay(ray.d)
+                    V3 o2 = offset_ray_origin(sp.p, sp.pError, sp.n, rd);
+                    pa.ray_o[path] = make_float4(o2.x, o2.y, o2.z, GX_INF);
+                    pa.ray_d[path] = make_float4(rd.x, rd.y, rd.z, __int_as_float(hit_medium(mt, leaf, rayMedium, sp.n, rd)));
+                } else {
+                    segDone = true;
+                    const int expect = __float_as_int(va.Li[path].w);
+                    bool ok = found ? (leaf == expect) : (expect < 0);
+                    if (ok && (nflags & 4)) {
+                        float4 Y4 = va.mis_Y[path];
+                        Ld = Ld + Spec(Y4.x, Y4.y, Y4.z) * Tr * Ld4.w / va.mis_d[path].w;
+                    }
+                }
+            }
+            if (!segDone) {
+                va.Tr[path] = make_float4(Tr.r, Tr.g, Tr.b, T4.w);
+                va.Ld[path] = make_float4(Ld.r, Ld.g, Ld.b, Ld4.w);
+                vs.y = ss.dim;
+                va.vs[path] = vs;
+                pa.pflags[path] = 1;
+                continue;
+            }
+            // light estimate complete: L += beta * (Ld / lightPdf), Integrator.cpp:78 + VolPathIntegrator.cpp:55/99
+            float4 b4 = pa.beta[path], L4 = pa.L[path];
+            beta = Spec(b4.x, b4.y, b4.z); etaScale = b4.w;
+            L = Spec(L4.x, L4.y, L4.z) + beta * (Ld / va.p1[path].w);
+            vertexDone = true;
+            // re-establish the vertex from its saved main ray
+            o4 = va.sv_o[path]; d4 = va.sv_d[path];
+            ro = V3(o4.x, o4.y, o4.z); rd = V3(d4.x, d4.y, d4.z);
+            rayMedium = __float_as_int(d4.w);
+            miT = T4.w;
+        } else {
+            // ---------------- phase 2: the main ray, VolPathIntegrator.cpp:36-80 ----------------
+            float4 b4 = pa.beta[path], L4 = pa.L[path];
+            beta = Spec(b4.x, b4.y, b4.z); etaScale = b4.w;
+            L = Spec(L4.x, L4.y, L4.z);
+            SurfacePoint sp0;
+            sp0.valid = false;
+            if (found) { sp0 = surface_point(p0, p1, p2, h, false); found = sp0.valid; }
+            const float tSeg = found ? h.t : o4.w;
+            bool miValid = false;
+            if (rayMedium >= 0) beta = beta * medium_sample(mt, rayMedium, ro, rd, tSeg, ss, &miValid, &miT);
+            bool alive = !beta.is_black();
+            if (alive && miValid) {
+                if (bounces >= r.max_depth) alive = false;
+                else vertexNew = true;
+            } else if (alive) {
+                miT = -1.f;
+                if (bounces == 0 || specularBounce) {
+                    if (found) {
+                        if (triLight >= 0) L = L + beta * area_L(sc.lt.lights[triLight], sp0.n, -rd);
+                    } else {
+                        for (int k = 0; k < sc.lt.n_infinite; ++k) L = L + beta * light_Le<LT>(sc.lt, sc.lt.infinite[k], ro, rd);
+                    }
+                }
+                if (!found || bounces >= r.max_depth) alive = false;
+                else if (triMat < 0) {
+                    // no BSDF: ray = isect.SpawnRay(ray.d); bounces--; continue  (VolPathIntegrator.cpp:88-92)
+                    V3 o2 = offset_ray_origin(sp0.p, sp0.pError, sp0.n, rd);
+                    pa.ray_o[path] = make_float4(o2.x, o2.y, o2.z, GX_INF);
+                    pa.ray_d[path] = make_float4(rd.x, rd.y, rd.z, __int_as_float(hit_medium(mt, leaf, rayMedium, sp0.n, rd)));
+                    pa.beta[path] = make_float4(beta.r, beta.g, beta.b, etaScale);
+                    pa.L[path] = make_float4(L.r, L.g, L.b, 0.f);
+                    vs.y = ss.dim;
+                    va.vs[path] = vs;
+                    pa.pflags[path] = 1;
+                    continue;
+                } else vertexNew = true;
+            }
+            if (!alive) {
+                pa.L[path] = make_float4(L.r, L.g, L.b, 0.f);
+                pa.pflags[path] = 0;
+                continue;
+            }
+        }
+
+        // ---------------- phase 3: the vertex (fresh, or re-established after its light estimate) ----------------
+        const bool isMedium = miT >= 0.f;
+        int vleaf = vertexDone ? vs.z : leaf;
+        SurfacePoint sp;
+        sp.valid = true;
+        const DMaterial *mat = nullptr;
+        Bsdf<LM_ALL> bsdf;
+        V3 itP, itPError, itN;
+        int medIn = rayMedium, medOut = rayMedium;
+        float g = 0;
+        if (isMedium) {
+            itP = ro + rd * miT;    // mi.p = ray(t)
+            g = mt.media[rayMedium].g;
+        } else {
+            const float4 *q = reinterpret_cast<const float4 *>(sc.tris + vleaf);
+            float4 a = q[0], b = q[1], c = q[2];
+            p0 = V3(a.x, a.y, a.z); p1 = V3(b.x, b.y, b.z); p2 = V3(c.x, c.y, c.z);
+            triMat = __float_as_int(b.w);
+            (void)tri_test(p0, p1, p2, ro, rd, o4.w, &h);
+            mat = sc.materials + triMat;
+            sp = surface_point(p0, p1, p2, h, mat->has_bump != 0);
+            bsdf.mat = mat; bsdf.ns = sp.ns; bsdf.ng = sp.n; bsdf.ss = sp.ss; bsdf.ts = sp.ts;
+            itP = sp.p; itPError = sp.pError; itN = sp.n;
+            if (mt.tri_media) {
+                int2 tm = mt.tri_media[vleaf];
+                if (tm.x != tm.y) { medIn = tm.x; medOut = tm.y; }
+            }
+        }
+        const V3 woN = normalize(-rd);   // SurfaceInteraction::wo
+        const V3 woM = -rd;              // MediumInteraction::wo
+
+        if (vertexNew && sc.lt.n_lights > 0) {
+            // ---- UniformSampleOneLight + EstimateDirect(handleMedia = true), Integrator.cpp:57-79, 93-210
+            float lightPdfSel;
+            int lightNum = light_select(sc.lt, itP, ss.get1d(), &lightPdfSel);
+            if (lightPdfSel != 0) {
+                float ul0, ul1, us0, us1;
+                ss.get2d(&ul0, &ul1);
+                ss.get2d(&us0, &us1);
+                const int bsdfFlags = BSDF_ALL & ~BSDF_SPECULAR;
+                int nflags = 0;
+                V3 so, sd, mo, wi2;
+                Spec fX(0.f), Y(0.f);
+                float weightX = 0, weightY = 0, scatPdf2 = 0;
+                int expect = -1, shMedium = -1, misMedium = -1;
+                LightSample ls = light_sample<LT>(sc.lt, lightNum, itP, ul0, ul1);
+                if (ls.pdf > 0 && !ls.Li.is_black()) {
+                    float scatteringPdf;
+                    if (isMedium) {
+                        float p = phase_hg(dot(woM, ls.wi), g);
+                        fX = Spec(p); scatteringPdf = p;
+                    } else {
+                        fX = bsdf.f(woN, ls.wi, bsdfFlags) * absdot(ls.wi, sp.ns);
+                        scatteringPdf = bsdf.pdf(woN, ls.wi, bsdfFlags);
+                    }
+                    if (!fX.is_black()) {
+                        spawn_ray_to(itP, itPError, itN, ls.p1, ls.p1Error, ls.n1, &so, &sd);
+                        shMedium = dot(sd, itN) > 0 ? medOut : medIn;
+                        weightX = power_heuristic(ls.pdf, scatteringPdf);
+                        nflags |= 1;
+                    }
+                }
+                {
+                    Spec f2;
+                    bool sampledSpecular = false;
+                    if (isMedium) {
+                        float p = hg_sample_p(g, woM, &wi2, us0, us1);
+                        f2 = Spec(p); scatPdf2 = p;
+                    } else {
+                        int sampledType;
+                        f2 = bsdf.sample_f(woN, &wi2, us0, us1, &scatPdf2, bsdfFlags, &sampledType);
+                        f2 = f2 * absdot(wi2, sp.ns);
+                        sampledSpecular = (sampledType & BSDF_SPECULAR) != 0;
+                    }
+                    if (!f2.is_black() && scatPdf2 > 0) {
+                        weightY = 1;
+                        bool skip = false;
+                        if (!sampledSpecular) {
+                            float lightPdf = light_pdf<LT>(sc.lt, lightNum, itP, itPError, itN, wi2);
+                            if (lightPdf == 0) skip = true;
+                            else weightY = power_heuristic(scatPdf2, lightPdf);
+                        }
+                        if (!skip) {
+                            const DLight &lt = sc.lt.lights[lightNum];
+                            mo = offset_ray_origin(itP, itPError, itN, wi2);
+                            misMedium = dot(wi2, itN) > 0 ? medOut : medIn;
+                            Spec Li2;
+                            if (LT == LT_AREA || lt.type == GNXR_LIGHT_AREA_TRI) {
+                                V3 lp0(lt.p0[0], lt.p0[1], lt.p0[2]), lp1(lt.p1[0], lt.p1[1], lt.p1[2]), lp2(lt.p2[0], lt.p2[1], lt.p2[2]);
+                                V3 ln = normalize(cross(lp0 - lp2, lp1 - lp2));
+                                Li2 = area_L(lt, ln, -wi2);
+                                expect = lt.tri_leaf;
+                            } else {
+                                Li2 = light_Le<LT>(sc.lt, lightNum, mo, wi2);
+                                expect = -1;
+                            }
+                            if (!Li2.is_black()) { Y = f2 * Li2; nflags |= 4; }
+                            nflags |= 2;
+                        }
+                    }
+                }
+                if (nflags & 3) {
+                    va.sv_o[path] = o4;
+                    va.sv_d[path] = d4;
+                    va.p1[path] = make_float4(ls.p1.x, ls.p1.y, ls.p1.z, lightPdfSel);
+                    va.p1e[path] = make_float4(ls.p1Error.x, ls.p1Error.y, ls.p1Error.z, ls.pdf);
+                    va.n1[path] = make_float4(ls.n1.x, ls.n1.y, ls.n1.z, weightX);
+                    va.f[path] = make_float4(fX.r, fX.g, fX.b, __int_as_float(nflags));
+                    va.Li[path] = make_float4(ls.Li.r, ls.Li.g, ls.Li.b, __int_as_float(expect));
+                    va.Tr[path] = make_float4(1.f, 1.f, 1.f, miT);
+                    va.Ld[path] = make_float4(0.f, 0.f, 0.f, weightY);
+                    if (nflags & 2) {
+                        va.mis_o[path] = make_float4(mo.x, mo.y, mo.z, __int_as_float(misMedium));
+                        va.mis_d[path] = make_float4(wi2.x, wi2.y, wi2.z, scatPdf2);
+                        va.mis_Y[path] = make_float4(Y.r, Y.g, Y.b, 0.f);
+                    }
+                    if (nflags & 1) {
+                        pa.ray_o[path] = make_float4(so.x, so.y, so.z, 1 - GX_SHADOW_EPS);
+                        pa.ray_d[path] = make_float4(sd.x, sd.y, sd.z, __int_as_float(shMedium));
+                        vs.x = VS_SHADOW;
+                    } else {
+                        pa.ray_o[path] = make_float4(mo.x, mo.y, mo.z, GX_INF);
+                        pa.ray_d[path] = make_float4(wi2.x, wi2.y, wi2.z, __int_as_float(misMedium));
+                        vs.x = VS_MIS;
+                    }
+                    vs.y = ss.dim;
+                    vs.z = leaf;
+                    va.vs[path] = vs;
+                    pa.beta[path] = make_float4(beta.r, beta.g, beta.b, etaScale);
+                    pa.L[path] = make_float4(L.r, L.g, L.b, 0.f);
+                    pa.pflags[path] = 1;
+                    continue;
+                }
+            }
+        }
+
+        // ---- continuation: phase function / BSDF sampling, VolPathIntegrator.cpp:58-64, 104-127; Russian roulette 131-140
+        {
+            V3 wo = -rd, wi, o2;
+            int nextMedium;
+            float u0, u1;
+            ss.get2d(&u0, &u1);
+            bool ok = true;
+            if (isMedium) {
+                (void)hg_sample_p(g, wo, &wi, u0, u1);
+                o2 = itP;                       // mi.SpawnRay(wi): n == 0, so the origin is not offset
+                nextMedium = rayMedium;
+                specularBounce = false;
+            } else {
+                float pdf;
+                int flags;
+                Spec f = bsdf.sample_f(wo, &wi, u0, u1, &pdf, BSDF_ALL, &flags);
+                if (f.is_black() || pdf == 0.f) ok = false;
+                else {
+                    beta = beta * (f * absdot(wi, sp.ns) / pdf);
+                    specularBounce = (flags & BSDF_SPECULAR) != 0;
+                    if ((flags & BSDF_SPECULAR) && (flags & BSDF_TRANSMISSION)) {
+                        float eta = mat->eta;
+                        etaScale *= (dot(wo, sp.n) > 0) ? (eta * eta) : 1 / (eta * eta);
+                    }
+                    o2 = offset_ray_origin(sp.p, sp.pError, sp.n, wi);
+                    nextMedium = dot(wi, sp.n) > 0 ? medOut : medIn;
+                }
+            }
+            if (ok) {
+                Spec rrBeta = beta * etaScale;
+                survive = true;
+                if (rrBeta.max_value() < r.rr_threshold && bounces > 3) {
+                    float q = fmaxf(.05f, 1 - rrBeta.max_value());
+                    if (ss.get1d() < q) survive = false;
+                    else beta = beta / (1 - q);
+                }
+                if (survive) {
+                    pa.ray_o[path] = make_float4(o2.x, o2.y, o2.z, GX_INF);
+                    pa.ray_d[path] = make_float4(wi.x, wi.y, wi.z, __int_as_float(nextMedium));
+                    pa.beta[path] = make_float4(beta.r, beta.g, beta.b, etaScale);
+                    pa.meta[path] = make_uint2(index, ((uint32_t)(bounces + 1) << 16) | (specularBounce ? 0x80000000u : 0u));
+                    vs.x = VS_MAIN;
+                    vs.y = ss.dim;
+                    va.vs[path] = vs;
+                }
+            }
+        }
+        pa.L[path] = make_float4(L.r, L.g, L.b, 0.f);
+        pa.pflags[path] = survive ? 1 : 0;
+    }
+}
+
+}  // namespace gnxr

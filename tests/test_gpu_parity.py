@@ -172,6 +172,51 @@ def test_dragon_scene_against_oracle(gpu):
     assert abs(st["rays_any"] - ost["rays_any"]) <= RAYS_TOL * ost["rays_any"]
 
 
+@pytest.mark.parametrize("name", ["vol_synth", "vol_cfg5"])
+def test_volpath_matches_reference_images(gpu, name):
+    """cfg 5 (VolPathIntegrator + GridDensityMedium + HomogeneousMedium): images and ray counts produced by the
+    restated VolPath loop on the reference's own classes (tests/golden/render_vol.npz)."""
+    g = golden("render_vol.npz")
+    W, H, spp, depth = (int(v) for v in g[name + "_cfg"])
+    b = scenes.volume_cornell(sigma_a=(0.5,) * 3, sigma_s=(3.5,) * 3, g_grid=0.3) if name == "vol_synth" else scenes.volume_cornell_cfg5(0.05)
+    img, st = gpu.VolPathIntegrator(depth, 1.0, "spatial").Render(gpu.Scene(b), W, H, spp)
+    r, mx = rmse(img, g[name])
+    assert r < RMSE_TOL and mx < MAXABS_TOL, (r, mx)
+    ref_rays = int(g[name + "_rays"][0])
+    assert abs(st["rays_closest"] - ref_rays) <= RAYS_TOL * ref_rays and st["rays_any"] == 0
+    assert (img[..., :3].view(np.uint32) == g[name][..., :3].view(np.uint32)).mean() > 0.9
+
+
+def test_volpath_cfg5_density_against_oracle(gpu):
+    """cfg 5 at the volume file's own sigma_a = 10, sigma_s = 90: the delta-tracking loops run past Halton
+    dimension 1000, where the reference indexes PrimeSums out of bounds (undefined); this build and the oracle
+    wrap (device_sampler.h), so the oracle is the only comparison available -- parity unpinned beyond dimension 1000."""
+    b = scenes.volume_cornell_cfg5(1.0)
+    integ = gpu.VolPathIntegrator(8, 1.0, "spatial")
+    img, st = integ.Render(gpu.Scene(b), 96, 96, 256, spp_begin=0, spp_end=8)
+    oimg, ost = ol.OracleScene(b).render(integ, 96, 96, 256, spp_begin=0, spp_end=8)
+    r, mx = rmse(img, oimg)
+    assert r < 1e-3, (r, mx)          # north-star bar; a diverged tracking loop changes a whole sample
+    assert abs(st["rays_closest"] - ost["rays_closest"]) <= RAYS_TOL * ost["rays_closest"]
+    # sharded and sample-range renders recombine exactly
+    acc = np.zeros_like(img)
+    for rk in range(2):
+        part, _ = integ.Render(gpu.Scene(b), 96, 96, 256, spp_begin=0, spp_end=8, shard_index=rk, shard_count=2, shard_rows=4)
+        acc += part
+    assert (acc.view(np.uint32) == img.view(np.uint32)).all()
+
+
+def test_path_integrator_passes_through_medium_boundaries(gpu):
+    """PathIntegrator on the volume scene: null-material boundaries are skipped (PathIntegrator.cpp:121-126)."""
+    b = scenes.volume_cornell(sigma_a=(0.5,) * 3, sigma_s=(3.5,) * 3)
+    integ = gpu.PathIntegrator(8, 1.0, "spatial")
+    img, st = integ.Render(gpu.Scene(b), 64, 64, 16)
+    oimg, ost = ol.OracleScene(b).render(integ, 64, 64, 16)
+    r, mx = rmse(img, oimg)
+    assert r < RMSE_TOL and mx < MAXABS_TOL, (r, mx)
+    assert abs(st["rays_closest"] - ost["rays_closest"]) <= RAYS_TOL * ost["rays_closest"]
+
+
 def test_edge_cases(gpu):
     scene = gpu.Scene(scenes.cornell())
     img, st = gpu.PathIntegrator(0).Render(scene, 8, 8, 2)               # maxDepth 0
