@@ -44,7 +44,16 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--save-image", type=str, default="")
-    return ap.parse_args()
+    ap.add_argument("--workload", choices=["cfg3", "cfg5"], default="cfg3",
+                    help="cfg3 (default, the headline metric) or cfg5: VolPathIntegrator + GridDensityMedium + HomogeneousMedium 512x512 @256spp")
+    args = ap.parse_args()
+    if args.workload == "cfg5":   # BASELINE.json configs[4]; explicit flags still win
+        d = ap.parse_args([])
+        if args.width == d.width and args.height == d.height: args.width, args.height = 512, 512
+        if args.spp == d.spp: args.spp = 256
+        if args.spp_per_step == d.spp_per_step: args.spp_per_step = 16
+        if args.steps == d.steps: args.steps = args.spp // args.spp_per_step
+    return args
 
 
 def cpu_baseline(builder, args):
@@ -54,8 +63,9 @@ def cpu_baseline(builder, args):
     import oracle_lib as ol
 
     osc = ol.OracleScene(builder)
-    integ = gx.PathIntegrator(args.max_depth, 1.0, "spatial")
-    w, h, spp = 960, 540, 8            # same scene / camera / sampler, 1/4 of the pixels, first 8 of 1024 samples (~15-25 s of CPU work)
+    integ = (gx.VolPathIntegrator if args.workload == "cfg5" else gx.PathIntegrator)(args.max_depth, 1.0, "spatial")
+    w, h, spp = (args.width // 2, args.height // 2, 8) if args.workload == "cfg5" else (960, 540, 8)
+    # same scene / camera / sampler, 1/4 of the pixels, first 8 samples of the Halton sequence (~15-25 s of CPU work for cfg 3)
     # a 1-GPU box gives this job a 16-core share of the host (more OpenMP threads only oversubscribe it)
     cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     osc.render(integ, 64, 36, args.spp, threads=cores, spp_begin=0, spp_end=1)   # touch the tables once
@@ -89,13 +99,17 @@ def main():
     W, H = args.width, args.height
     # every rank builds the same scene (replicated: ~12 MB of tables); rank 0 writes the mesh file once
     mesh_path = os.path.join(ROOT, "gpurun_out", "_meshes", f"synthetic_dragon_{args.tris}_1.3d")
-    if rank == 0:
+    if rank == 0 and args.workload == "cfg3":
         scenes.synthetic_mesh_path(args.tris)
     if world > 1:
         dist.barrier()
-    builder = scenes.dragon_cornell(args.tris, "glass+metal", mesh_path=mesh_path)
+    if args.workload == "cfg5":
+        builder = scenes.volume_cornell_cfg5(1.0)
+        integ = gx.VolPathIntegrator(args.max_depth, 1.0, "spatial")
+    else:
+        builder = scenes.dragon_cornell(args.tris, "glass+metal", mesh_path=mesh_path)
+        integ = gx.PathIntegrator(args.max_depth, 1.0, "spatial")
     scene = gx.Scene(builder)
-    integ = gx.PathIntegrator(args.max_depth, 1.0, "spatial")
     shard = dict(shard_index=rank, shard_count=world, shard_rows=1)
     out = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     acc = torch.zeros_like(out)
@@ -158,7 +172,7 @@ def main():
 
     spp_done = min(args.steps * sps, args.spp)
     result = {
-        "metric": "Mrays/s (path tracing, closest-hit + shadow + MIS rays), dragon-stand-in Cornell 1920x1080",
+        "metric": "Mrays/s (path tracing, closest-hit + shadow + MIS rays), " + ("volume Cornell 512x512 (cfg 5)" if args.workload == "cfg5" else "dragon-stand-in Cornell 1920x1080"),
         "value": rays_all / dt_max / 1e6,
         "unit": "Mrays/s",
         "n_gpus": world,
@@ -170,11 +184,14 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"cfg3: Cornell + synthetic {args.tris}-tri mesh (stand-in for absent dragon.3d), Glass+Metal, "
+        "config": {"workload": f"cfg5: Cornell + GridDensityMedium (reference density grid 100x100x40, sigma_a 10 sigma_s 90) + HomogeneousMedium, "
+                               f"VolPathIntegrator maxDepth {args.max_depth} rr 1 spatial, Halton({args.spp}), {W}x{H}" if args.workload == "cfg5" else
+                               f"cfg3: Cornell + synthetic {args.tris}-tri mesh (stand-in for absent dragon.3d), Glass+Metal, "
                                f"PathIntegrator maxDepth {args.max_depth} rr 1 spatial, Halton({args.spp}), {W}x{H}",
                    "spp_per_step": sps, "spp_rendered": spp_done, "sharding": f"rows y % {world} == rank" if world > 1 else "none",
                    "gather": "RCCL gather of row shards to rank 0 (in timed region)" if world > 1 else "n/a"},
         "wall_to_1024spp_s": dt_max * (1024.0 / spp_done),
+        "wall_to_full_spp_s": dt_max * (float(args.spp) / spp_done),
         "wall_measured_s": dt_max,
         "rays": {"closest": tot["rays_closest"], "any": tot["rays_any"], "per_camera_sample": rays / max(1, tot["camera_samples"])},
     }

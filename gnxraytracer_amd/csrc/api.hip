@@ -127,7 +127,7 @@ struct gnxr_scene {
     DevBuf<int> hit, queue_a, queue_b, queue_nee, queue_c0, queue_c1, queue_c2;
     DevBuf<unsigned char> pflags, pclass;
     DevBuf<unsigned int> tile_counts;
-    DevBuf<float4> vol_n1, vol_f, vol_Li, vol_Tr, vol_Ld;   // VolPath light-estimate records (vol_kernel.hip.h)
+    DevBuf<float4> vol_n1, vol_f, vol_Li, vol_Tr, vol_Ld, vol_mres;   // VolPath light-estimate records (vol_kernel.hip.h)
     DevBuf<int4> vol_vs;
     DevBuf<Counters> counters;
     Counters *h_counters = nullptr;  // pinned
@@ -277,7 +277,7 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
 #undef AL
     if (volpath) {
 #define AL(f) if ((rc = s->f.alloc(cap)) != GNXR_OK) return rc;
-        AL(vol_n1) AL(vol_f) AL(vol_Li) AL(vol_Tr) AL(vol_Ld) AL(vol_vs)
+        AL(vol_n1) AL(vol_f) AL(vol_Li) AL(vol_Tr) AL(vol_Ld) AL(vol_mres) AL(vol_vs)
 #undef AL
     }
     if ((rc = s->accum.alloc(r.npix)) != GNXR_OK) return rc;
@@ -288,7 +288,7 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     pa.sh_o = s->sh_o.p; pa.sh_d = s->sh_d.p; pa.sh_X = s->sh_X.p; pa.mis_o = s->mis_o.p; pa.mis_d = s->mis_d.p; pa.mis_Y = s->mis_Y.p; pa.nbeta = s->nbeta.p;
     VolArrays va;
     va.vs = s->vol_vs.p; va.sv_o = s->sh_o.p; va.sv_d = s->sh_d.p; va.p1 = s->sh_X.p; va.p1e = s->nbeta.p; va.n1 = s->vol_n1.p; va.f = s->vol_f.p;
-    va.Li = s->vol_Li.p; va.Tr = s->vol_Tr.p; va.Ld = s->vol_Ld.p; va.mis_o = s->mis_o.p; va.mis_d = s->mis_d.p; va.mis_Y = s->mis_Y.p;
+    va.Li = s->vol_Li.p; va.Tr = s->vol_Tr.p; va.Ld = s->vol_Ld.p; va.mis_o = s->mis_o.p; va.mis_d = s->mis_d.p; va.mis_Y = s->mis_Y.p; va.mres = s->vol_mres.p;
     DMediaTables mt = s->media_tables();
 
     HIP_TRY(hipMemsetAsync(s->accum.p, 0, sizeof(float4) * r.npix, stream));
@@ -351,8 +351,18 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
             // one closest-hit ray per live path and round: k_trace -> k_vol_step -> compaction (vol_kernel.hip.h)
             hipLaunchKernelGGL(k_vol_init, dim3(grid_for(n_paths)), dim3(kBlock), 0, stream, pa, va, n_paths);
             ++launches;
+            int n_media = r.cam.medium >= 0 ? n : 0;      // paths whose ray in flight travels inside a medium
+            const int *q_media = nullptr;
             while (n > 0) {
                 launch_trace(TraceWork{q_in, n, nullptr, 0}, 0, 0);
+                if (n_media > 0) {
+                    (void)hipMemsetAsync(&dctr->cursor, 0, sizeof(unsigned int), stream);
+                    int blocks = (int)std::min<long long>((long long)g_num_cus * 8, ((long long)n_media + kBlock - 1) / kBlock);
+                    if (timing) timer.begin(1, stream);
+                    hipLaunchKernelGGL(k_vol_media, dim3(blocks), dim3(kBlock), 0, stream, sc, mt, pa, va, q_media, n_media, &dctr->cursor);
+                    if (timing) timer.end(stream);
+                    ++launches;
+                }
                 if (timing) timer.begin(2, stream);
                 if (area_only) hipLaunchKernelGGL((k_vol_step<LT_AREA>), dim3(grid_for(n)), dim3(kBlock), 0, stream, sc, mt, r, pa, va, q_in, n);
                 else hipLaunchKernelGGL((k_vol_step<LT_ALL>), dim3(grid_for(n)), dim3(kBlock), 0, stream, sc, mt, r, pa, va, q_in, n);
@@ -362,6 +372,8 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
                 HIP_TRY(hipMemcpyAsync(s->h_counters, dctr, sizeof(Counters), hipMemcpyDeviceToHost, stream));
                 HIP_TRY(hipStreamSynchronize(stream));
                 n = (int)s->h_counters->q_next;
+                n_media = (int)s->h_counters->q_nee;
+                q_media = s->queue_nee.p;
                 q_in = q_cur;
                 std::swap(q_cur, q_other);
                 if (++guard > (1 << 20)) { set_error("path loop did not terminate"); return GNXR_ERR_INVALID; }

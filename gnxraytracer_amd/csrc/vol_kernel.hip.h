@@ -6,7 +6,15 @@
 // segment consumes depends on what the previous segment hit, so the rays of one path are strictly sequential.  Each
 // path therefore has exactly ONE ray in flight; a round is
 //
-//     k_trace (closest hit for every live path)  ->  k_vol_step (advance every live path to its next ray)
+//     k_trace      closest hit for every live path
+//     k_vol_media  Medium::Sample / Medium::Tr for the paths whose ray travels inside a medium (delta / ratio tracking)
+//     k_vol_step   advance every live path to its next ray
+//
+// The tracking loops are the bulk of the work of config 5 (hundreds of null collisions per segment at sigma_t = 100)
+// and their length varies from 0 to ~1000 iterations between neighbouring paths, so they run in their own lean kernel:
+// persistent waves whose lanes pull the next path as soon as their loop ends (the same pool scheme as k_trace), a few
+// dozen VGPRs instead of the 256 the BSDF code needs, 8 waves per SIMD to hide the latency of the permutation-table
+// and density loads.
 //
 // and a path is in one of three states:
 //   VS_MAIN    the ray is the path's main ray: medium sampling, Le, null-boundary pass-through, then the vertex
@@ -36,6 +44,7 @@ struct VolArrays {
     float4 *mis_o;   // scattering ray origin, w: medium (int bits)
     float4 *mis_d;   // scattering ray direction, w: scattering pdf
     float4 *mis_Y;   // f * Li2
+    float4 *mres;    // k_vol_media result for the ray in flight: Medium::Sample weight / Medium::Tr (rgb), w: t of the sampled interaction or -1
 };
 
 __global__ void __launch_bounds__(kBlock) k_vol_init(PathArrays pa, VolArrays va, int n_paths) {
@@ -55,6 +64,148 @@ GX_DEV int hit_medium(const DMediaTables &mt, int leaf, int rayMedium, V3 n, V3 
         if (tm.x != tm.y) { mi = tm.x; mo = tm.y; }
     }
     return dot(w, n) > 0 ? mo : mi;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Medium::Sample (state VS_MAIN) / Medium::Tr (VS_SHADOW, VS_MIS) for the rays that travel inside a medium.
+// `queue` lists those paths (pflags bit1 of the previous step, compacted).  Persistent waves; a lane runs one tracking
+// loop and refills from the wave's pool when it ends.  Results: va.mres[path], and the path's stream position va.vs[path].y.
+constexpr int kMediaChunk = 256;   // paths a wave takes per global atomic
+
+__global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt, PathArrays pa, VolArrays va, const int *__restrict__ queue, int n, unsigned int *cursor) {
+    const int lane = __lane_id();
+    const unsigned total = (unsigned)n;
+    unsigned poolBase = 0, poolCount = 0;
+    bool exhausted = false;
+    // per-lane tracking state (grid media; homogeneous media are closed-form and finish at set-up)
+    int path = -1, dim = 0, nx = 0, ny = 0, nz = 0, medium = -1;
+    bool sampleMode = false;
+    uint32_t index = 0;
+    V3 o, d;
+    float t = 0, tMax = 0, Tr = 1, invMaxDensity = 0, stepScale = 0;
+    const float *__restrict__ dens = nullptr;
+
+    while (true) {
+        bool need = path < 0;
+        unsigned long long needMask = __ballot(need);
+        if (needMask) {
+            if (poolCount == 0 && !exhausted) {
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(cursor, (unsigned)kMediaChunk);
+                base = __shfl(base, 0);
+                if (base >= total) exhausted = true;
+                else { poolBase = base; poolCount = min((unsigned)kMediaChunk, total - base); }
+            }
+            if (poolCount > 0) {
+                unsigned rank = (unsigned)__popcll(needMask & ((1ull << lane) - 1ull));
+                unsigned take = min(poolCount, (unsigned)__popcll(needMask));
+                if (need && rank < take) {
+                    const int p = queue ? queue[poolBase + rank] : (int)(poolBase + rank);
+                    int4 vs = va.vs[p];
+                    float4 o4 = pa.ray_o[p], d4 = pa.ray_d[p];
+                    V3 ro(o4.x, o4.y, o4.z), rd(d4.x, d4.y, d4.z);
+                    const int med = __float_as_int(d4.w);
+                    const int leaf = pa.hit[p];
+                    bool found = leaf >= 0;
+                    int triMat = -1;
+                    TriHit h;
+                    if (found) {
+                        const float4 *q = reinterpret_cast<const float4 *>(sc.tris + leaf);
+                        float4 a = q[0], b = q[1], c = q[2];
+                        triMat = __float_as_int(b.w);
+                        found = tri_test(V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), ro, rd, o4.w, &h);
+                    }
+                    // VisibilityTester::Tr returns 0 at an opaque hit before it evaluates the segment's transmittance
+                    const bool skip = med < 0 || (vs.x == VS_SHADOW && found && triMat >= 0);
+                    if (!skip) {
+                        const float tSeg = found ? h.t : o4.w;
+                        const DMedium &m = mt.media[med];
+                        SampleStream ss(sc.st, pa.meta[p].x, vs.y);
+                        if (m.type == GNXR_MEDIUM_HOMOGENEOUS) {
+                            float4 res;
+                            if (vs.x == VS_MAIN) {
+                                bool valid; float tt = -1.f;
+                                Spec w = medium_sample(mt, med, ro, rd, tSeg, ss, &valid, &tt);
+                                res = make_float4(w.r, w.g, w.b, valid ? tt : -1.f);
+                            } else {
+                                Spec w = medium_tr(mt, med, ro, rd, tSeg, ss);
+                                res = make_float4(w.r, w.g, w.b, -1.f);
+                            }
+                            va.mres[p] = res;
+                            reinterpret_cast<int *>(&va.vs[p])[1] = ss.dim;
+                        } else {
+                            // GridDensityMedium::Sample / Tr set-up, GridDensityMedium.cpp:33-40, 59-66
+                            float rtMax, tMin, tEnd;
+                            V3 oo, dd;
+                            xform_ray(m.w2m, ro, normalize(rd), tSeg * length(rd), &oo, &dd, &rtMax);
+                            if (!unit_box_intersect(oo, dd, rtMax, &tMin, &tEnd)) {
+                                va.mres[p] = make_float4(1.f, 1.f, 1.f, -1.f);
+                            } else {
+                                path = p; medium = med; sampleMode = vs.x == VS_MAIN;
+                                index = ss.index; dim = ss.dim;
+                                o = oo; d = dd; t = tMin; tMax = tEnd; Tr = 1;
+                                nx = m.nx; ny = m.ny; nz = m.nz;
+                                invMaxDensity = m.inv_max_density;
+                                stepScale = m.sigma_t;
+                                dens = mt.density + m.density_offset;
+                            }
+                        }
+                    }
+                }
+                poolBase += take; poolCount -= take;
+            }
+        }
+        if (__ballot(path >= 0) == 0) {
+            if (exhausted && poolCount == 0) break;
+            continue;
+        }
+        // ---------------- one tracking iteration for every active lane ----------------
+        if (path >= 0) {
+            bool done = false;
+            float resW = 1.f, resT = -1.f;
+            bool resSigma = false;
+            t -= gx_log(1 - halton_sample(sc.st, index, dim++)) * invMaxDensity / stepScale;
+            if (t >= tMax) { done = true; resW = sampleMode ? 1.f : Tr; }
+            else {
+                // GridDensityMedium::Density, GridDensityMedium.cpp:14-29
+                V3 pp = o + d * t;
+                V3 ps(pp.x * (float)nx - .5f, pp.y * (float)ny - .5f, pp.z * (float)nz - .5f);
+                int px = (int)floorf(ps.x), py = (int)floorf(ps.y), pz = (int)floorf(ps.z);
+                V3 dl = ps - V3((float)px, (float)py, (float)pz);
+                auto D = [&](int x, int y, int z) -> float {
+                    if (x < 0 || y < 0 || z < 0 || x >= nx || y >= ny || z >= nz) return 0.f;
+                    return dens[(z * ny + y) * nx + x];
+                };
+                float d00 = lerpf(dl.x, D(px, py, pz), D(px + 1, py, pz));
+                float d10 = lerpf(dl.x, D(px, py + 1, pz), D(px + 1, py + 1, pz));
+                float d01 = lerpf(dl.x, D(px, py, pz + 1), D(px + 1, py, pz + 1));
+                float d11 = lerpf(dl.x, D(px, py + 1, pz + 1), D(px + 1, py + 1, pz + 1));
+                float density = lerpf(dl.z, lerpf(dl.y, d00, d10), lerpf(dl.y, d01, d11));
+                if (sampleMode) {
+                    if (density * invMaxDensity > halton_sample(sc.st, index, dim++)) { done = true; resSigma = true; resT = t; }
+                } else {
+                    Tr *= 1 - fmaxf(0.f, density * invMaxDensity);
+                    const float rrThreshold = .1f;
+                    if (Tr < rrThreshold) {
+                        float q = fmaxf(.05f, 1 - Tr);
+                        if (halton_sample(sc.st, index, dim++) < q) { done = true; resW = 0.f; }
+                        else Tr /= 1 - q;
+                    }
+                }
+            }
+            if (done) {
+                float4 res = make_float4(resW, resW, resW, resT);
+                if (resSigma) {
+                    const DMedium &m = mt.media[medium];
+                    Spec w = spec3(m.sigma_s) / m.sigma_t;
+                    res = make_float4(w.r, w.g, w.b, resT);
+                }
+                va.mres[path] = res;
+                reinterpret_cast<int *>(&va.vs[path])[1] = dim;
+                path = -1;
+            }
+        }
+    }
 }
 
 template <int LT>
@@ -99,13 +250,13 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
             SurfacePoint sp;
             sp.valid = false;
             if (found) { sp = surface_point(p0, p1, p2, h, false); found = sp.valid; }
-            const float tSeg = found ? h.t : o4.w;
             bool segDone = false;
+            int segMedium = -1;        // medium of the next segment's ray
             if (vs.x == VS_SHADOW) {   // VisibilityTester::Tr, Light.cpp:33-53
                 if (found && triMat >= 0) {
                     segDone = true;    // blocked: Tr = 0, Li becomes black, nothing is added
                 } else {
-                    if (rayMedium >= 0) Tr = Tr * medium_tr(mt, rayMedium, ro, rd, tSeg, ss);
+                    if (rayMedium >= 0) { float4 w = va.mres[path]; Tr = Tr * Spec(w.x, w.y, w.z); }
                     if (!found) {
                         segDone = true;
                         float4 Li4 = va.Li[path];
@@ -115,24 +266,27 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
                         float4 q1 = va.p1[path], q1e = va.p1e[path], qn1 = va.n1[path];
                         V3 so, sd;
                         spawn_ray_to(sp.p, sp.pError, sp.n, V3(q1.x, q1.y, q1.z), V3(q1e.x, q1e.y, q1e.z), V3(qn1.x, qn1.y, qn1.z), &so, &sd);
+                        segMedium = hit_medium(mt, leaf, rayMedium, sp.n, sd);
                         pa.ray_o[path] = make_float4(so.x, so.y, so.z, 1 - GX_SHADOW_EPS);
-                        pa.ray_d[path] = make_float4(sd.x, sd.y, sd.z, __int_as_float(hit_medium(mt, leaf, rayMedium, sp.n, sd)));
+                        pa.ray_d[path] = make_float4(sd.x, sd.y, sd.z, __int_as_float(segMedium));
                     }
                 }
                 if (segDone && (nflags & 2)) {   // go on with the scattering ray: it.SpawnRay(wi), Integrator.cpp:193
                     float4 mo = va.mis_o[path], md = va.mis_d[path];
                     pa.ray_o[path] = make_float4(mo.x, mo.y, mo.z, GX_INF);
                     pa.ray_d[path] = make_float4(md.x, md.y, md.z, mo.w);
+                    segMedium = __float_as_int(mo.w);
                     Tr = Spec(1.f);
                     vs.x = VS_MIS;
                     segDone = false;
                 }
             } else {                   // Scene::IntersectTr, Scene.cpp:26-40
-                if (rayMedium >= 0) Tr = Tr * medium_tr(mt, rayMedium, ro, rd, tSeg, ss);
+                if (rayMedium >= 0) { float4 w = va.mres[path]; Tr = Tr * Spec(w.x, w.y, w.z); }
                 if (found && triMat < 0) {   // ray = isect->SpawnRay(ray.d)
                     V3 o2 = offset_ray_origin(sp.p, sp.pError, sp.n, rd);
+                    segMedium = hit_medium(mt, leaf, rayMedium, sp.n, rd);
                     pa.ray_o[path] = make_float4(o2.x, o2.y, o2.z, GX_INF);
-                    pa.ray_d[path] = make_float4(rd.x, rd.y, rd.z, __int_as_float(hit_medium(mt, leaf, rayMedium, sp.n, rd)));
+                    pa.ray_d[path] = make_float4(rd.x, rd.y, rd.z, __int_as_float(segMedium));
                 } else {
                     segDone = true;
                     const int expect = __float_as_int(va.Li[path].w);
@@ -148,7 +302,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
                 va.Ld[path] = make_float4(Ld.r, Ld.g, Ld.b, Ld4.w);
                 vs.y = ss.dim;
                 va.vs[path] = vs;
-                pa.pflags[path] = 1;
+                pa.pflags[path] = (unsigned char)(1 | (segMedium >= 0 ? 2 : 0));
                 continue;
             }
             // light estimate complete: L += beta * (Ld / lightPdf), Integrator.cpp:78 + VolPathIntegrator.cpp:55/99
@@ -169,9 +323,13 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
             SurfacePoint sp0;
             sp0.valid = false;
             if (found) { sp0 = surface_point(p0, p1, p2, h, false); found = sp0.valid; }
-            const float tSeg = found ? h.t : o4.w;
             bool miValid = false;
-            if (rayMedium >= 0) beta = beta * medium_sample(mt, rayMedium, ro, rd, tSeg, ss, &miValid, &miT);
+            if (rayMedium >= 0) {   // beta *= ray.medium->Sample(ray, sampler, arena, &mi), evaluated by k_vol_media
+                float4 w = va.mres[path];
+                beta = beta * Spec(w.x, w.y, w.z);
+                miValid = w.w >= 0.f;
+                miT = w.w;
+            }
             bool alive = !beta.is_black();
             if (alive && miValid) {
                 if (bounces >= r.max_depth) alive = false;
@@ -189,13 +347,14 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
                 else if (triMat < 0) {
                     // no BSDF: ray = isect.SpawnRay(ray.d); bounces--; continue  (VolPathIntegrator.cpp:88-92)
                     V3 o2 = offset_ray_origin(sp0.p, sp0.pError, sp0.n, rd);
+                    const int nm = hit_medium(mt, leaf, rayMedium, sp0.n, rd);
                     pa.ray_o[path] = make_float4(o2.x, o2.y, o2.z, GX_INF);
-                    pa.ray_d[path] = make_float4(rd.x, rd.y, rd.z, __int_as_float(hit_medium(mt, leaf, rayMedium, sp0.n, rd)));
+                    pa.ray_d[path] = make_float4(rd.x, rd.y, rd.z, __int_as_float(nm));
                     pa.beta[path] = make_float4(beta.r, beta.g, beta.b, etaScale);
                     pa.L[path] = make_float4(L.r, L.g, L.b, 0.f);
                     vs.y = ss.dim;
                     va.vs[path] = vs;
-                    pa.pflags[path] = 1;
+                    pa.pflags[path] = (unsigned char)(1 | (nm >= 0 ? 2 : 0));
                     continue;
                 } else vertexNew = true;
             }
@@ -336,16 +495,16 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
                     va.vs[path] = vs;
                     pa.beta[path] = make_float4(beta.r, beta.g, beta.b, etaScale);
                     pa.L[path] = make_float4(L.r, L.g, L.b, 0.f);
-                    pa.pflags[path] = 1;
+                    pa.pflags[path] = (unsigned char)(1 | (((nflags & 1) ? shMedium : misMedium) >= 0 ? 2 : 0));
                     continue;
                 }
             }
         }
 
         // ---- continuation: phase function / BSDF sampling, VolPathIntegrator.cpp:58-64, 104-127; Russian roulette 131-140
+        int nextMedium = -1;
         {
             V3 wo = -rd, wi, o2;
-            int nextMedium;
             float u0, u1;
             ss.get2d(&u0, &u1);
             bool ok = true;
@@ -390,7 +549,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
             }
         }
         pa.L[path] = make_float4(L.r, L.g, L.b, 0.f);
-        pa.pflags[path] = survive ? 1 : 0;
+        pa.pflags[path] = (unsigned char)(survive ? (1 | (nextMedium >= 0 ? 2 : 0)) : 0);
     }
 }
 
