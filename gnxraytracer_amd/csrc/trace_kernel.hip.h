@@ -37,39 +37,26 @@ constexpr int kTraceLeaveMul = GX_TRACE_LEAVE_MUL, kTraceLeaveDiv = GX_TRACE_LEA
 
 // 4-wide step: test the four children of `node`, return the first one hit in the reference's visiting order and push
 // the others (in reverse order) on the lane's LDS stack.  Box test = Bounds3::IntersectP (Geometry.h:1380-1406).
-typedef float gx_f2 __attribute__((ext_vector_type(2)));
-
-// Slab test of two child boxes at once (Bounds3::IntersectP, Geometry.h:1380-1406): every arithmetic step is an
-// element-wise IEEE op on a float2, which hipcc maps to gfx950's packed-fp32 VALU ops (v_pk_mul_f32 / v_pk_add_f32),
-// halving the instruction count of the box tests without changing a single bit of the result.
-GX_DEV unsigned slab2(gx_f2 lox, gx_f2 loy, gx_f2 loz, gx_f2 hix, gx_f2 hiy, gx_f2 hiz, V3 ro, V3 invDir, int neg0, int neg1, int neg2, float tMaxRay) {
+// Slab test of one child box (Bounds3::IntersectP, Geometry.h:1380-1406), scalar fp32.  (A packed-fp32 float2 version
+// made hipcc round-trip the ray origin through scratch memory to build register pairs and was no faster.)
+GX_DEV bool slab1(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 ro, V3 invDir, int neg0, int neg1, int neg2, float tMaxRay) {
     const float k = 1 + 2 * GX_GAMMA(3);
-    gx_f2 nx = neg0 ? hix : lox, fx = neg0 ? lox : hix;
-    gx_f2 ny = neg1 ? hiy : loy, fy = neg1 ? loy : hiy;
-    gx_f2 nz = neg2 ? hiz : loz, fz = neg2 ? loz : hiz;
-    gx_f2 tMin = (nx - ro.x) * invDir.x;
-    gx_f2 tMax = (fx - ro.x) * invDir.x;
-    gx_f2 tyMin = (ny - ro.y) * invDir.y;
-    gx_f2 tyMax = (fy - ro.y) * invDir.y;
-    tMax = tMax * k;
-    tyMax = tyMax * k;
-    gx_f2 tzMin = (nz - ro.z) * invDir.z;
-    gx_f2 tzMax = (fz - ro.z) * invDir.z;
-    tzMax = tzMax * k;
-    unsigned m = 0;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        float a = tMin[c], b = tMax[c];
-        bool ok = !(a > tyMax[c] || tyMin[c] > b);
-        if (tyMin[c] > a) a = tyMin[c];
-        if (tyMax[c] < b) b = tyMax[c];
-        ok = ok && !(a > tzMax[c] || tzMin[c] > b);
-        if (tzMin[c] > a) a = tzMin[c];
-        if (tzMax[c] < b) b = tzMax[c];
-        ok = ok && (a < tMaxRay) && (b > 0);
-        m |= ok ? (1u << c) : 0u;
-    }
-    return m;
+    float tMin = ((neg0 ? hix : lox) - ro.x) * invDir.x;
+    float tMax = ((neg0 ? lox : hix) - ro.x) * invDir.x;
+    float tyMin = ((neg1 ? hiy : loy) - ro.y) * invDir.y;
+    float tyMax = ((neg1 ? loy : hiy) - ro.y) * invDir.y;
+    tMax *= k;
+    tyMax *= k;
+    if (tMin > tyMax || tyMin > tMax) return false;
+    if (tyMin > tMin) tMin = tyMin;
+    if (tyMax < tMax) tMax = tyMax;
+    float tzMin = ((neg2 ? hiz : loz) - ro.z) * invDir.z;
+    float tzMax = ((neg2 ? loz : hiz) - ro.z) * invDir.z;
+    tzMax *= k;
+    if (tMin > tzMax || tzMin > tMax) return false;
+    if (tzMin > tMin) tMin = tzMin;
+    if (tzMax < tMax) tMax = tzMax;
+    return (tMin < tMaxRay) && (tMax > 0);
 }
 
 // 4-wide step: test the four children of `node`, return the first one hit in the reference's visiting order and push
@@ -79,10 +66,10 @@ GX_DEV int bvh4_step(const float4 *__restrict__ n4, int node, V3 ro, V3 invDir, 
     float4 lox = q[0], loy = q[1], loz = q[2], hix = q[3], hiy = q[4], hiz = q[5];
     float4 cf = q[6], mf = q[7];
     const int child[4] = {__float_as_int(cf.x), __float_as_int(cf.y), __float_as_int(cf.z), __float_as_int(cf.w)};
-    unsigned hitMask = slab2(gx_f2{lox.x, lox.y}, gx_f2{loy.x, loy.y}, gx_f2{loz.x, loz.y}, gx_f2{hix.x, hix.y}, gx_f2{hiy.x, hiy.y}, gx_f2{hiz.x, hiz.y}, ro, invDir,
-                             neg0, neg1, neg2, tMax) |
-                       (slab2(gx_f2{lox.z, lox.w}, gx_f2{loy.z, loy.w}, gx_f2{loz.z, loz.w}, gx_f2{hix.z, hix.w}, gx_f2{hiy.z, hiy.w}, gx_f2{hiz.z, hiz.w}, ro, invDir,
-                              neg0, neg1, neg2, tMax) << 2);
+    unsigned hitMask = (slab1(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, ro, invDir, neg0, neg1, neg2, tMax) ? 1u : 0u) |
+                       (slab1(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, ro, invDir, neg0, neg1, neg2, tMax) ? 2u : 0u) |
+                       (slab1(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, ro, invDir, neg0, neg1, neg2, tMax) ? 4u : 0u) |
+                       (slab1(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, ro, invDir, neg0, neg1, neg2, tMax) ? 8u : 0u);
 #pragma unroll
     for (int c = 0; c < 4; ++c) if (child[c] == kNode4Empty) hitMask &= ~(1u << c);
     // visiting order of BVHAccel::Intersect over the two collapsed levels
