@@ -29,6 +29,7 @@ namespace {
 int g_device = -1;
 int g_num_cus = 256;
 int g_profiling = 0;
+int g_trace_blocks_per_cu = 6;   // GNXR_TRACE_BLOCKS_PER_CU overrides (tuning)
 
 // Per-kernel timing with HIP events on the render stream.  Events are recycled from a pool and resolved
 // after the stream has been synchronised.
@@ -68,6 +69,7 @@ int ensure_device() {
     HIP_TRY(hipGetDeviceProperties(&prop, dev));
     g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     g_device = dev;
+    if (const char *e = getenv("GNXR_TRACE_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) g_trace_blocks_per_cu = v; }
     return GNXR_OK;
 }
 
@@ -127,6 +129,7 @@ struct gnxr_scene {
     DevBuf<int> hit, queue_a, queue_b, queue_nee, queue_c0, queue_c1, queue_c2;
     DevBuf<unsigned char> pflags, pclass;
     DevBuf<unsigned int> tile_counts;
+    DevBuf<int> trace_spill;   // global part of k_trace's per-lane traversal stacks
     DevBuf<float4> vol_n1, vol_f, vol_Li, vol_Tr, vol_Ld, vol_mres;   // VolPath light-estimate records (vol_kernel.hip.h)
     DevBuf<int4> vol_vs;
     DevBuf<Counters> counters;
@@ -190,6 +193,14 @@ int gnxr_init(int device_id) {
 }
 void gnxr_shutdown(void) { g_device = -1; }
 int gnxr_set_profiling(int flags) { g_profiling = flags; return GNXR_OK; }
+#ifdef GX_TRACE_STATS
+// development builds only (-DGX_TRACE_STATS): wave-level occupancy statistics of k_trace
+int gnxr_debug_trace_stats(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_trace_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return GNXR_ERR_INVALID;
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_stats), z, sizeof(z)); }
+    return GNXR_OK;
+}
+#endif
 
 int gnxr_scene_create(const gnxr_scene_desc *desc, gnxr_scene **out) {
     if (!desc || !out) { set_error("null argument"); return GNXR_ERR_INVALID; }
@@ -211,6 +222,9 @@ int gnxr_scene_create(const gnxr_scene_desc *desc, gnxr_scene **out) {
     if ((rc = s->infinite.upload(cs.infinite_lights)) != GNXR_OK) { delete s; return rc; }
     if ((rc = s->counters.alloc(1)) != GNXR_OK) { delete s; return rc; }
     if (hipHostMalloc((void **)&s->h_counters, sizeof(Counters)) != hipSuccess) { set_error("hipHostMalloc failed"); delete s; return GNXR_ERR_OOM; }
+    if (getenv("GNXR_VERBOSE"))
+        fprintf(stderr, "[gnxr] scene: %zu tris, %zu nodes (depth %d), %zu 4-wide nodes (stack %d), wide=%d\n", cs.tris.size(), cs.nodes.size(), cs.bvh_max_depth,
+                cs.nodes4.size(), cs.stack4_need, (int)s->wide_ok);
     *out = s;
     return GNXR_OK;
 }
@@ -322,14 +336,18 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
             // LDS traversal stack: one column per lane, depth from the BVH (binary walk: depth + 1; 4-wide walk: stack4_need)
             const bool wide = s->wide_ok && !counting;
             int entries = wide ? s->cs.stack4_need + 1 : s->cs.bvh_max_depth + 2;
-            size_t lds = (size_t)entries * kBlock * sizeof(int);
-            int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
+            // k_trace needs ~80 VGPRs -> 6 waves per SIMD = 6 blocks of 4 waves per CU; keep the LDS part of the stack small
+            // enough for that (160 KB / 6 blocks / 1 KB per level = 26 levels), deeper levels spill to global memory
+            const int per_cu = g_trace_blocks_per_cu;
+            int lds_entries = std::min(entries, std::max(4, (int)((160 * 1024) / per_cu / (kBlock * sizeof(int))) - 1));
+            size_t lds = (size_t)lds_entries * kBlock * sizeof(int);
             // persistent waves: enough blocks to fill the chip, never more than the work needs
             int blocks = (int)std::min<long long>((long long)g_num_cus * per_cu, (total + kBlock - 1) / kBlock);
+            if (s->trace_spill.alloc((size_t)g_num_cus * per_cu * kBlock * (size_t)std::max(1, entries - lds_entries)) != GNXR_OK) return;
             if (timing) timer.begin(0, stream);
-            if (counting) hipLaunchKernelGGL((k_trace<true, false>), dim3(blocks), dim3(kBlock), lds, stream, sc, pa, w, &dctr->cursor, dctr);
-            else if (wide) hipLaunchKernelGGL((k_trace<false, true>), dim3(blocks), dim3(kBlock), lds, stream, sc, pa, w, &dctr->cursor, dctr);
-            else hipLaunchKernelGGL((k_trace<false, false>), dim3(blocks), dim3(kBlock), lds, stream, sc, pa, w, &dctr->cursor, dctr);
+            if (counting) hipLaunchKernelGGL((k_trace<true, false>), dim3(blocks), dim3(kBlock), lds, stream, sc, pa, w, &dctr->cursor, dctr, lds_entries, s->trace_spill.p);
+            else if (wide) hipLaunchKernelGGL((k_trace<false, true>), dim3(blocks), dim3(kBlock), lds, stream, sc, pa, w, &dctr->cursor, dctr, lds_entries, s->trace_spill.p);
+            else hipLaunchKernelGGL((k_trace<false, false>), dim3(blocks), dim3(kBlock), lds, stream, sc, pa, w, &dctr->cursor, dctr, lds_entries, s->trace_spill.p);
             if (timing) timer.end(stream);
             rays_closest += (unsigned long long)w.n_closest + (unsigned long long)n_mis;
             rays_any += (unsigned long long)n_sh;

@@ -15,7 +15,9 @@
 //     if-if version was 13 %, profiles/r01_b_*);
 //   * leaves are still visited in the reference's order and tMax shrinks the same way, so hit records stay
 //     bit-identical (ties resolve as in BVHAccel::Intersect);
-//   * per-lane stack column in LDS: stack[depth * 256 + tid], bank == lane.
+//   * per-lane stack column in LDS: stack[depth * 256 + tid], bank == lane.  Only the first `lds_entries` levels live in
+//     LDS (the host picks them so that LDS does not cap the occupancy below what the VGPR budget allows); the rare
+//     deeper levels spill to a per-lane column in global memory.
 #pragma once
 #include "device_geom.h"
 
@@ -33,6 +35,14 @@ constexpr int kTraceChunk = 512;   // rays a wave takes per global atomic
 #ifndef GX_TRACE_LEAVE_DIV
 #define GX_TRACE_LEAVE_DIV 2
 #endif
+#ifndef GX_REFILL_MIN
+#define GX_REFILL_MIN 1
+#endif
+#ifndef GX_SPECULATE
+#define GX_SPECULATE 1
+#endif
+constexpr bool kSpeculate = GX_SPECULATE != 0;
+constexpr int kRefillMin = GX_REFILL_MIN;   // refill only when at least this many lanes are idle (or none is live)
 constexpr int kTraceLeaveMul = GX_TRACE_LEAVE_MUL, kTraceLeaveDiv = GX_TRACE_LEAVE_DIV;   // leave phase A when searching <= live * MUL / DIV
 
 // 4-wide step: test the four children of `node`, return the first one hit in the reference's visiting order and push
@@ -59,9 +69,26 @@ GX_DEV bool slab1(float lox, float loy, float loz, float hix, float hiy, float h
     return (tMin < tMaxRay) && (tMax > 0);
 }
 
+// Traversal stack of one lane: levels [0, K) in LDS, deeper levels in global memory (coalesced across the wave).
+struct LaneStack {
+    int *lds;
+    int *spill;
+    int K;
+    size_t stride;
+    GX_DEV void push(int &n, int v) const {
+        if (n < K) lds[n * kBlock] = v;
+        else spill[(size_t)(n - K) * stride] = v;
+        ++n;
+    }
+    GX_DEV int pop(int &n) const {
+        --n;
+        return n < K ? lds[n * kBlock] : spill[(size_t)(n - K) * stride];
+    }
+};
+
 // 4-wide step: test the four children of `node`, return the first one hit in the reference's visiting order and push
-// the others (in reverse order) on the lane's LDS stack.
-GX_DEV int bvh4_step(const float4 *__restrict__ n4, int node, V3 ro, V3 invDir, int neg0, int neg1, int neg2, float tMax, int *stack, int &toVisit) {
+// the others (in reverse order) on the lane's stack.
+GX_DEV int bvh4_step(const float4 *__restrict__ n4, int node, V3 ro, V3 invDir, int neg0, int neg1, int neg2, float tMax, const LaneStack &stack, int &toVisit) {
     const float4 *q = n4 + 8 * (size_t)node;
     float4 lox = q[0], loy = q[1], loz = q[2], hix = q[3], hiy = q[4], hiz = q[5];
     float4 cf = q[6], mf = q[7];
@@ -86,21 +113,32 @@ GX_DEV int bvh4_step(const float4 *__restrict__ n4, int node, V3 ro, V3 invDir, 
     for (int kk = 3; kk >= 0; --kk) {
         int sidx = order[kk];
         if ((hitMask >> sidx) & 1u) {
-            if (have) stack[(toVisit++) * kBlock] = next;
+            if (have) stack.push(toVisit, next);
             next = sidx == 0 ? child[0] : (sidx == 1 ? child[1] : (sidx == 2 ? child[2] : child[3]));
             have = true;
         }
     }
-    if (!have) next = (toVisit == 0) ? kRefDone : stack[(--toVisit) * kBlock];
+    if (!have) next = (toVisit == 0) ? kRefDone : stack.pop(toVisit);
     return next;
 }
+
+#ifdef GX_TRACE_STATS
+__device__ unsigned long long g_trace_stats[16];
+#define GX_STAT(i, v) do { if (lane == 0) st_[i] += (unsigned long long)(v); } while (0)
+#else
+#define GX_STAT(i, v) do {} while (0)
+#endif
 
 // COUNT: count nodes / triangles (profiling).  WIDE: traverse the collapsed 4-wide tree (sc.nodes4) instead of the
 // reference's binary nodes; the counting runs use WIDE = false so that the counts are those of the reference traversal.
 template <bool COUNT, bool WIDE>
-__global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, TraceWork w, unsigned int *cursor, Counters *ctr) {
-    extern __shared__ int stack_mem[];   // stackEntries * kBlock ints, sized by the host from the BVH depth
-    int *stack = &stack_mem[threadIdx.x];
+__global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, TraceWork w, unsigned int *cursor, Counters *ctr, int lds_entries, int *spill) {
+    extern __shared__ int stack_mem[];   // lds_entries * kBlock ints
+    LaneStack stack;
+    stack.lds = &stack_mem[threadIdx.x];
+    stack.K = lds_entries;
+    stack.stride = (size_t)gridDim.x * kBlock;
+    stack.spill = spill + (size_t)blockIdx.x * kBlock + threadIdx.x;
     const int lane = __lane_id();
     const unsigned total = (unsigned)w.n_closest + 2u * (unsigned)w.n_nee;
     const float4 *__restrict__ nodes = sc.nodes;
@@ -117,12 +155,19 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
     int neg0 = 0, neg1 = 0, neg2 = 0;
     int cur = -1, toVisit = 0, leafOff = 0, leafN = 0, hitLeaf = -1, expect = -1;
     uint32_t cntNodes = 0, cntTris = 0;
+#ifdef GX_TRACE_STATS
+    unsigned long long st_[16] = {0};
+#endif
 
     while (true) {
+        GX_STAT(0, 1);
         // ---------------- refill idle lanes from the wave pool ----------------
         bool need = item < 0;
         unsigned long long needMask = __ballot(need);
+        if (kRefillMin > 1 && __popcll(needMask) < kRefillMin && needMask != ~0ull) needMask = 0;   // batch the refills
         if (needMask) {
+            GX_STAT(7, 1);
+            GX_STAT(8, __popcll(needMask));
             if (poolCount == 0 && !exhausted) {
                 unsigned base = 0;
                 if (lane == 0) base = atomicAdd(cursor, (unsigned)kTraceChunk);
@@ -176,15 +221,22 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
         // Leave the walk as soon as at most a quarter of the live lanes is still searching: waiting for the last
         // straggler left ~3/4 of the wave idle (the stragglers simply resume in the next round).
         const int nLive = __popcll(__ballot(item >= 0));
+        GX_STAT(9, nLive);
         while (true) {
             if (WIDE && item >= 0 && leafN == 0 && cur < -1) {   // the next reference is a leaf: stage it, pre-pop its successor
                 int lr = ~cur;
                 leafOff = lr & 0xffffff; leafN = (lr >> 24) & 0x7f;
-                cur = (toVisit == 0) ? -1 : stack[(--toVisit) * kBlock];
+                cur = (toVisit == 0) ? -1 : stack.pop(toVisit);
             }
-            bool searching = item >= 0 && cur >= 0 && leafN == 0;
-            int nSearching = __popcll(__ballot(searching));
+            // A lane that already holds a leaf keeps walking (speculatively, with the tMax it has) until it reaches a second
+            // leaf: every node it visits is one the reference visits or a superset of them (tMax only shrinks), and each
+            // leaf is re-tested against the current tMax before its triangles are (phase B), so results do not change.
+            bool searching = item >= 0 && cur >= 0 && (kSpeculate && WIDE ? true : leafN == 0);
+            bool hungry = searching && leafN == 0;
+            int nSearching = __popcll(__ballot(hungry));
             if (nSearching * kTraceLeaveDiv <= nLive * kTraceLeaveMul && (nSearching == 0 || nSearching < nLive)) break;
+            GX_STAT(1, 1);
+            GX_STAT(2, __popcll(__ballot(searching)));
             if (searching) {
                 if (COUNT) cntNodes++;
                 if (WIDE) {
@@ -202,17 +254,33 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
                         int axis = (int)(meta >> 16);
                         int ng = axis == 0 ? neg0 : (axis == 1 ? neg1 : neg2);
                         int nearC = ng ? offset : cur + 1, farC = ng ? cur + 1 : offset;
-                        stack[(toVisit++) * kBlock] = farC;
+                        stack.push(toVisit, farC);
                         next = nearC;
                     } else {
                         if (hitBox) { leafOff = offset; leafN = nPrims; }
-                        next = (toVisit == 0) ? -1 : stack[(--toVisit) * kBlock];
+                        next = (toVisit == 0) ? -1 : stack.pop(toVisit);
                     }
                     cur = next;
                 }
             }
         }
         // ---------------- phase B: triangle tests ----------------
+#ifdef GX_TRACE_STATS
+        {
+            unsigned long long lm = __ballot(item >= 0 && leafN > 0);
+            if (lm) {
+                GX_STAT(3, 1);
+                GX_STAT(4, __popcll(lm));
+                int mx = leafN;
+                for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+                int sm = (item >= 0) ? leafN : 0;
+                for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+                GX_STAT(5, mx);
+                GX_STAT(6, sm);
+                GX_STAT(10, __popcll(__ballot(item >= 0 && leafN > 0 && hitLeaf >= 0)));
+            }
+        }
+#endif
         if (item >= 0 && leafN > 0) {
             bool visit = true;
             if (WIDE && hitLeaf >= 0) {   // tMax only ever shrinks after a hit: before the first hit the earlier test stands
@@ -259,6 +327,9 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
             item = -1;
         }
     }
+#ifdef GX_TRACE_STATS
+    if (lane == 0) for (int i = 0; i < 16; ++i) if (st_[i]) atomicAdd(&g_trace_stats[i], st_[i]);
+#endif
     if (COUNT) {
         atomicAdd(&ctr->nodes, (unsigned long long)cntNodes);
         atomicAdd(&ctr->tris, (unsigned long long)cntTris);

@@ -1,0 +1,31 @@
+"""k_trace wave statistics (dev tool; needs a -DGX_TRACE_STATS build): GNXR_LIB=ab_libs/lib_stats.so python tests/dev_stats.py"""
+import os, sys, json, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import gnxraytracer_amd as gx, scenes
+gx.init(0)
+b = scenes.dragon_cornell(100000, "glass+metal")
+scene = gx.Scene(b); integ = gx.PathIntegrator(8, 1.0, "spatial")
+out = torch.zeros((1080, 1920, 4), device="cuda")
+lib = C.CDLL(gx.LIB_PATH)
+buf = (C.c_ulonglong * 16)()
+integ.RenderDevice(scene, out.data_ptr(), 1920, 1080, 1024, spp_begin=0, spp_end=8, samples_per_pass=8)
+lib.gnxr_debug_trace_stats(buf, 1)
+st = integ.RenderDevice(scene, out.data_ptr(), 1920, 1080, 1024, spp_begin=8, spp_end=16, samples_per_pass=8)
+lib.gnxr_debug_trace_stats(buf, 1)
+v = list(buf)
+rays = st["rays_closest"] + st["rays_any"]
+names = ["loop_trips", "A_wave_iters", "A_lane_iters", "B_wave_entries", "B_lanes", "B_wave_tri_iters(max leafN)", "B_lane_tris", "refill_events", "refill_lanes", "live_lanes_sum", "B_lanes_retest"]
+d = {n: v[i] for i, n in enumerate(names)}
+d["rays"] = rays
+d["A_util"] = v[2] / max(1, v[1]) / 64
+d["B_util_lanes"] = v[4] / max(1, v[3]) / 64
+d["B_util_tris"] = v[6] / max(1, v[5]) / 64
+d["live_frac"] = v[9] / max(1, v[0]) / 64
+d["A_wave_iters_per_ray"] = v[1] * 64 / rays
+d["A_lane_iters_per_ray"] = v[2] / rays
+d["B_wave_tri_iters_per_ray"] = v[5] * 64 / rays
+d["B_lane_tris_per_ray"] = v[6] / rays
+d["refill_events_per_ray_x64"] = v[7] * 64 / rays
+print(json.dumps(d, indent=1))
