@@ -126,8 +126,10 @@ GX_DEV void tr_sample11(float cosTheta, float U1, float U2, float *slope_x, floa
         // unqualified sqrt/cos/sin bind to the double versions in the reference (MicroFacet.cpp:220-223)
         float r = (float)sqrt((double)(U1 / (1 - U1)));
         float phi = (float)(6.28318530718 * (double)U2);
-        *slope_x = (float)((double)r * cos((double)phi));
-        *slope_y = (float)((double)r * sin((double)phi));
+        double sphi, cphi;
+        sincos((double)phi, &sphi, &cphi);
+        *slope_x = (float)((double)r * cphi);
+        *slope_y = (float)((double)r * sphi);
         return;
     }
     float sinTheta = gx_sqrt(fmaxf(0.f, 1.f - cosTheta * cosTheta));
@@ -367,7 +369,9 @@ GX_DEV Spec lobe_sample(const DLobe &l, V3 wo, V3 *wi, float u0, float u1, float
         float cosTheta = gx_sqrt(fmaxf(0.f, (1 - gx_pow(alpha2, 1 - u0)) / (1 - alpha2)));
         float sinTheta = gx_sqrt(fmaxf(0.f, 1 - cosTheta * cosTheta));
         float phi = 2 * GX_PI * u1;
-        V3 wh(sinTheta * gx_cos(phi), sinTheta * gx_sin(phi), cosTheta);
+        float sinPhi, cosPhi;
+        gx_sincos(phi, &sinPhi, &cosPhi);
+        V3 wh(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
         if (!same_hemisphere(wo, wh)) wh = -wh;
         *wi = reflect(wo, wh);
         if (!same_hemisphere(wo, *wi)) return Spec(0.f);

@@ -147,8 +147,9 @@ GX_DEV LightSample light_sample(const DLightTables &t, int li, V3 refP, float u0
         float mapPdf = pdfs0 * pdfs1;
         if (mapPdf == 0) return s;
         float theta = d1 * GX_PI, phi = d0 * 2 * GX_PI;
-        float cosTheta = gx_cos(theta), sinTheta = gx_sin(theta);
-        float sinPhi = gx_sin(phi), cosPhi = gx_cos(phi);
+        float cosTheta, sinTheta, sinPhi, cosPhi;
+        gx_sincos(theta, &sinTheta, &cosTheta);
+        gx_sincos(phi, &sinPhi, &cosPhi);
         s.wi = xform_vector(e.l2w, V3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta));
         s.pdf = mapPdf / (2 * GX_PI * GX_PI * sinTheta);
         if (sinTheta == 0) s.pdf = 0;
@@ -158,8 +159,9 @@ GX_DEV LightSample light_sample(const DLightTables &t, int li, V3 refP, float u0
         return s;
     } else if (LT & LT_SKY) {  // SkyBoxLight::Sample_Li, SkyBoxLight.cpp:43-53: black, pdf 1/4pi
         float theta = u1 * GX_PI, phi = u0 * 2 * GX_PI;
-        float cosTheta = gx_cos(theta), sinTheta = gx_sin(theta);
-        float sinPhi = gx_sin(phi), cosPhi = gx_cos(phi);
+        float cosTheta, sinTheta, sinPhi, cosPhi;
+        gx_sincos(theta, &sinTheta, &cosTheta);
+        gx_sincos(phi, &sinPhi, &cosPhi);
         s.wi = V3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
         s.pdf = 1.f / (4 * GX_PI);
         s.p1 = refP + s.wi * (2 * l.radius);

@@ -29,6 +29,8 @@ static constexpr float GX_SHADOW_EPS = 0.0001f;
 // ---- libm through double (see header comment) ----
 GX_DEV float gx_sin(float x) { return (float)sin((double)x); }
 GX_DEV float gx_cos(float x) { return (float)cos((double)x); }
+// sin and cos of the same angle share OCML's argument reduction (same polynomials, same values as the two separate calls)
+GX_DEV void gx_sincos(float x, float *s, float *c) { double ds, dc; sincos((double)x, &ds, &dc); *s = (float)ds; *c = (float)dc; }
 GX_DEV float gx_tan(float x) { return (float)tan((double)x); }
 GX_DEV float gx_acos(float x) { return (float)acos((double)x); }
 GX_DEV float gx_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }

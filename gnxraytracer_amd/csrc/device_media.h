@@ -39,7 +39,9 @@ GX_DEV float hg_sample_p(float g, V3 wo, V3 *wi, float u0, float u1) {
     float phi = 2 * GX_PI * u1;
     V3 v1, v2;
     coordinate_system(wo, &v1, &v2);
-    *wi = sinTheta * gx_cos(phi) * v1 + sinTheta * gx_sin(phi) * v2 + cosTheta * wo;
+    float sinPhi, cosPhi;
+    gx_sincos(phi, &sinPhi, &cosPhi);
+    *wi = sinTheta * cosPhi * v1 + sinTheta * sinPhi * v2 + cosTheta * wo;
     return phase_hg(cosTheta, g);
 }
 

@@ -24,8 +24,10 @@ static_assert(sizeof(DNode) == 32, "DNode must be 32 bytes");
 // records bit-identical while halving the number of dependent memory round trips per ray.  128 B = 8 dwordx4.
 struct DNode4 {
     float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
-    int32_t child[4];     // >= 0: DNode4 index; < 0: leaf, ~ref = first triangle | nPrims << 24; kNode4Empty: no child
-    int32_t axis0, axisA, axisB, _pad;
+    int32_t child[4];     // >= 0: DNode4 index; < 0: leaf, ~ref = first triangle | nPrims << 24; kNode4Empty: no child (box inverted)
+    uint32_t order_lo, order_hi;   // visiting order per ray octant (neg0 | neg1 << 1 | neg2 << 2): byte o = 4 x 2-bit child slots, nearest first
+    int32_t axes;                  // axis0 | axisA << 2 | axisB << 4 (kept for inspection)
+    int32_t _pad;
 };
 static_assert(sizeof(DNode4) == 128, "DNode4 must be 128 bytes");
 constexpr int32_t kNode4Empty = 0x7ffffffe;

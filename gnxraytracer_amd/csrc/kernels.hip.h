@@ -146,8 +146,13 @@ __global__ void __launch_bounds__(kBlock) k_raygen(DScene sc, DRender r, PathArr
 // ------------------------------------------------------------------------------------------------
 // One specialisation per (lobe set LM, light-type set LT): device_bsdf.h LM_*, device_lights.h LT_*.  `n_dev`
 // points at the fill count of `queue` written by k_compact_scan (device-side, no host round trip).
+#ifdef GX_SHADE_WAVES
+#define GX_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(GX_SHADE_WAVES, GX_SHADE_WAVES)))
+#else
+#define GX_SHADE_ATTR
+#endif
 template <uint32_t LM, int LT>
-__global__ void __launch_bounds__(kBlock) k_shade(DScene sc, DRender r, PathArrays pa, const int *__restrict__ queue, const unsigned int *n_dev) {
+__global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRender r, PathArrays pa, const int *__restrict__ queue, const unsigned int *n_dev) {
     const int n = (int)*n_dev;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         bool survive = false, wantNee = false, wantShadow = false, wantMis = false;

@@ -120,7 +120,7 @@ int32_t collapse(const std::vector<DNode> &bn, int bi, std::vector<DNode4> &out,
     DNode4 d;
     memset(&d, 0, sizeof(d));
     for (int k = 0; k < 4; ++k) d.child[k] = kNode4Empty;
-    d.axis0 = (int)(N.meta >> 16);
+    int axis0 = (int)(N.meta >> 16), axisA = 0, axisB = 0;
     int A = bi + 1, B = N.offset;
     int grand[4] = {-1, -1, -1, -1};
     auto group = [&](int X, int base, int *axisOut) {
@@ -128,8 +128,26 @@ int32_t collapse(const std::vector<DNode> &bn, int bi, std::vector<DNode4> &out,
         if (is_leaf(x)) { grand[base] = X; *axisOut = 0; }
         else { grand[base] = X + 1; grand[base + 1] = x.offset; *axisOut = (int)(x.meta >> 16); }
     };
-    group(A, 0, &d.axisA);
-    group(B, 2, &d.axisB);
+    group(A, 0, &axisA);
+    group(B, 2, &axisB);
+    // order in which BVHAccel::Intersect reaches the four grandchildren for each ray octant: the near child of N first
+    // (dirIsNeg[axis0]), inside each half the near grandchild first (dirIsNeg[axisA] / dirIsNeg[axisB])
+    uint64_t table = 0;
+    for (int oct = 0; oct < 8; ++oct) {
+        int neg[3] = {oct & 1, (oct >> 1) & 1, (oct >> 2) & 1};
+        int n0 = neg[axis0], nA = neg[axisA], nB = neg[axisB];
+        int base0 = n0 ? 2 : 0, base1 = 2 - base0;
+        int sw0 = n0 ? nB : nA, sw1 = n0 ? nA : nB;
+        int order[4] = {base0 + sw0, base0 + 1 - sw0, base1 + sw1, base1 + 1 - sw1};
+        uint64_t byte = (uint64_t)(order[0] | (order[1] << 2) | (order[2] << 4) | (order[3] << 6));
+        table |= byte << (8 * oct);
+    }
+    d.order_lo = (uint32_t)table; d.order_hi = (uint32_t)(table >> 32);
+    d.axes = axis0 | (axisA << 2) | (axisB << 4);
+    for (int k = 0; k < 4; ++k) {   // absent children: inverted boxes, which fail every slab test
+        d.lox[k] = d.loy[k] = d.loz[k] = std::numeric_limits<float>::infinity();
+        d.hix[k] = d.hiy[k] = d.hiz[k] = -std::numeric_limits<float>::infinity();
+    }
     int nchild = 0;
     for (int k = 0; k < 4; ++k) if (grand[k] >= 0) ++nchild;
     // a node can leave nchild-1 references on the stack while its first child is being traversed

@@ -45,80 +45,81 @@ constexpr bool kSpeculate = GX_SPECULATE != 0;
 constexpr int kRefillMin = GX_REFILL_MIN;   // refill only when at least this many lanes are idle (or none is live)
 constexpr int kTraceLeaveMul = GX_TRACE_LEAVE_MUL, kTraceLeaveDiv = GX_TRACE_LEAVE_DIV;   // leave phase A when searching <= live * MUL / DIV
 
-// 4-wide step: test the four children of `node`, return the first one hit in the reference's visiting order and push
-// the others (in reverse order) on the lane's LDS stack.  Box test = Bounds3::IntersectP (Geometry.h:1380-1406).
-// Slab test of one child box (Bounds3::IntersectP, Geometry.h:1380-1406), scalar fp32.  (A packed-fp32 float2 version
-// made hipcc round-trip the ray origin through scratch memory to build register pairs and was no faster.)
-GX_DEV bool slab1(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 ro, V3 invDir, int neg0, int neg1, int neg2, float tMaxRay) {
-    const float k = 1 + 2 * GX_GAMMA(3);
-    float tMin = ((neg0 ? hix : lox) - ro.x) * invDir.x;
-    float tMax = ((neg0 ? lox : hix) - ro.x) * invDir.x;
-    float tyMin = ((neg1 ? hiy : loy) - ro.y) * invDir.y;
-    float tyMax = ((neg1 ? loy : hiy) - ro.y) * invDir.y;
-    tMax *= k;
-    tyMax *= k;
-    if (tMin > tyMax || tyMin > tMax) return false;
-    if (tyMin > tMin) tMin = tyMin;
-    if (tyMax < tMax) tMax = tyMax;
-    float tzMin = ((neg2 ? hiz : loz) - ro.z) * invDir.z;
-    float tzMax = ((neg2 ? loz : hiz) - ro.z) * invDir.z;
-    tzMax *= k;
-    if (tMin > tzMax || tzMin > tMax) return false;
-    if (tzMin > tMin) tMin = tzMin;
-    if (tzMax < tMax) tMax = tzMax;
-    return (tMin < tMaxRay) && (tMax > 0);
-}
-
 // Traversal stack of one lane: levels [0, K) in LDS, deeper levels in global memory (coalesced across the wave).
 struct LaneStack {
     int *lds;
     int *spill;
     int K;
-    size_t stride;
+    int stride;   // lanes in the grid (< 2^21), so (n - K) * stride fits 32 bits
     GX_DEV void push(int &n, int v) const {
         if (n < K) lds[n * kBlock] = v;
-        else spill[(size_t)(n - K) * stride] = v;
+        else spill[(n - K) * stride] = v;
         ++n;
     }
     GX_DEV int pop(int &n) const {
         --n;
-        return n < K ? lds[n * kBlock] : spill[(size_t)(n - K) * stride];
+        return n < K ? lds[n * kBlock] : spill[(n - K) * stride];
     }
 };
 
-// 4-wide step: test the four children of `node`, return the first one hit in the reference's visiting order and push
-// the others (in reverse order) on the lane's stack.
-GX_DEV int bvh4_step(const float4 *__restrict__ n4, int node, V3 ro, V3 invDir, int neg0, int neg1, int neg2, float tMax, const LaneStack &stack, int &toVisit) {
+// Per-ray constants of the 4-wide walk: which float4 of a DNode4 holds the near / far plane of each axis for this ray's
+// direction signs (the reference selects them per box with dirIsNeg, Geometry.h:1384-1400 -- here the selection is an
+// address), and the shift that picks this octant's byte of the node's visiting-order table.
+struct RayOctant {
+    int nx, fx, ny, fy, nz, fz;   // float4 indices into the node: lox 0 loy 1 loz 2 hix 3 hiy 4 hiz 5
+    int shift;                    // 8 * (neg0 | neg1 << 1 | neg2 << 2)
+};
+GX_DEV RayOctant ray_octant(int neg0, int neg1, int neg2) {
+    RayOctant r;
+    r.nx = neg0 ? 3 : 0; r.fx = 3 - r.nx;
+    r.ny = neg1 ? 4 : 1; r.fy = 5 - r.ny;
+    r.nz = neg2 ? 5 : 2; r.fz = 7 - r.nz;
+    r.shift = 8 * (neg0 | (neg1 << 1) | (neg2 << 2));
+    return r;
+}
+
+// 4-wide step: test the four children of `node` (Bounds3::IntersectP, Geometry.h:1380-1406, same operations in the same
+// order for each box), return the first one hit in the reference's visiting order and push the others, farthest first.
+// Straight-line code: absent children carry inverted boxes that fail the test, the order comes from the node's table.
+GX_DEV int bvh4_step(const float4 *__restrict__ n4, int node, V3 ro, V3 invDir, const RayOctant &oc, float tMaxRay, const LaneStack &stack, int &toVisit) {
     const float4 *q = n4 + 8 * (size_t)node;
-    float4 lox = q[0], loy = q[1], loz = q[2], hix = q[3], hiy = q[4], hiz = q[5];
-    float4 cf = q[6], mf = q[7];
-    const int child[4] = {__float_as_int(cf.x), __float_as_int(cf.y), __float_as_int(cf.z), __float_as_int(cf.w)};
-    unsigned hitMask = (slab1(lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x, ro, invDir, neg0, neg1, neg2, tMax) ? 1u : 0u) |
-                       (slab1(lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y, ro, invDir, neg0, neg1, neg2, tMax) ? 2u : 0u) |
-                       (slab1(lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z, ro, invDir, neg0, neg1, neg2, tMax) ? 4u : 0u) |
-                       (slab1(lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w, ro, invDir, neg0, neg1, neg2, tMax) ? 8u : 0u);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) if (child[c] == kNode4Empty) hitMask &= ~(1u << c);
-    // visiting order of BVHAccel::Intersect over the two collapsed levels
-    int axis0 = __float_as_int(mf.x), axisA = __float_as_int(mf.y), axisB = __float_as_int(mf.z);
-    int n0 = axis0 == 0 ? neg0 : (axis0 == 1 ? neg1 : neg2);
-    int nA = axisA == 0 ? neg0 : (axisA == 1 ? neg1 : neg2);
-    int nB = axisB == 0 ? neg0 : (axisB == 1 ? neg1 : neg2);
-    int base0 = n0 ? 2 : 0, base1 = 2 - base0;
-    int sw0 = n0 ? nB : nA, sw1 = n0 ? nA : nB;
-    int order[4] = {base0 + sw0, base0 + 1 - sw0, base1 + sw1, base1 + 1 - sw1};
+    const float4 nX = q[oc.nx], fX = q[oc.fx], nY = q[oc.ny], fY = q[oc.fy], nZ = q[oc.nz], fZ = q[oc.fz];
+    const float4 cf = q[6], mf = q[7];
+    const float k = 1 + 2 * GX_GAMMA(3);
+    unsigned hitMask = 0;
+#define GX_SLAB(C, BIT)                                                                   \
+    {                                                                                     \
+        float tMin = (nX.C - ro.x) * invDir.x, tMax = (fX.C - ro.x) * invDir.x;           \
+        float tyMin = (nY.C - ro.y) * invDir.y, tyMax = (fY.C - ro.y) * invDir.y;         \
+        tMax *= k; tyMax *= k;                                                            \
+        bool ok = !(tMin > tyMax || tyMin > tMax);                                        \
+        if (tyMin > tMin) tMin = tyMin;                                                   \
+        if (tyMax < tMax) tMax = tyMax;                                                   \
+        float tzMin = (nZ.C - ro.z) * invDir.z, tzMax = (fZ.C - ro.z) * invDir.z;         \
+        tzMax *= k;                                                                       \
+        ok = ok && !(tMin > tzMax || tzMin > tMax);                                       \
+        if (tzMin > tMin) tMin = tzMin;                                                   \
+        if (tzMax < tMax) tMax = tzMax;                                                   \
+        ok = ok && (tMin < tMaxRay) && (tMax > 0);                                        \
+        hitMask |= ok ? (BIT) : 0u;                                                       \
+    }
+    GX_SLAB(x, 1u) GX_SLAB(y, 2u) GX_SLAB(z, 4u) GX_SLAB(w, 8u)
+#undef GX_SLAB
+    if (hitMask == 0) return (toVisit == 0) ? kRefDone : stack.pop(toVisit);
+    const unsigned long long table = ((unsigned long long)__float_as_uint(mf.y) << 32) | __float_as_uint(mf.x);
+    const unsigned ord = (unsigned)(table >> oc.shift);
+    const int c0 = __float_as_int(cf.x), c1 = __float_as_int(cf.y), c2 = __float_as_int(cf.z), c3 = __float_as_int(cf.w);
     int next = kRefDone;
     bool have = false;
 #pragma unroll
     for (int kk = 3; kk >= 0; --kk) {
-        int sidx = order[kk];
-        if ((hitMask >> sidx) & 1u) {
+        const unsigned slot = (ord >> (2 * kk)) & 3u;
+        if ((hitMask >> slot) & 1u) {
             if (have) stack.push(toVisit, next);
-            next = sidx == 0 ? child[0] : (sidx == 1 ? child[1] : (sidx == 2 ? child[2] : child[3]));
+            next = slot == 0 ? c0 : (slot == 1 ? c1 : (slot == 2 ? c2 : c3));
             have = true;
         }
     }
-    if (!have) next = (toVisit == 0) ? kRefDone : stack.pop(toVisit);
     return next;
 }
 
@@ -137,7 +138,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
     LaneStack stack;
     stack.lds = &stack_mem[threadIdx.x];
     stack.K = lds_entries;
-    stack.stride = (size_t)gridDim.x * kBlock;
+    stack.stride = (int)gridDim.x * kBlock;
     stack.spill = spill + (size_t)blockIdx.x * kBlock + threadIdx.x;
     const int lane = __lane_id();
     const unsigned total = (unsigned)w.n_closest + 2u * (unsigned)w.n_nee;
@@ -151,6 +152,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
     int item = -1, kind = 0, path = -1;
     V3 ro, rd, invDir;
     RayShear shear;
+    RayOctant oct = ray_octant(0, 0, 0);
     float tMax = 0;
     int neg0 = 0, neg1 = 0, neg2 = 0;
     int cur = -1, toVisit = 0, leafOff = 0, leafN = 0, hitLeaf = -1, expect = -1;
@@ -206,6 +208,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
                         invDir = V3(1.f / rd.x, 1.f / rd.y, 1.f / rd.z);
                         shear = ray_shear(rd);
                         neg0 = invDir.x < 0; neg1 = invDir.y < 0; neg2 = invDir.z < 0;
+                        if (WIDE) oct = ray_octant(neg0, neg1, neg2);
                         cur = WIDE ? sc.root4 : 0; toVisit = 0; leafN = 0; hitLeaf = -1;
                     }
                 }
@@ -240,7 +243,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
             if (searching) {
                 if (COUNT) cntNodes++;
                 if (WIDE) {
-                    int next = bvh4_step(sc.nodes4, cur, ro, invDir, neg0, neg1, neg2, tMax, stack, toVisit);
+                    int next = bvh4_step(sc.nodes4, cur, ro, invDir, oct, tMax, stack, toVisit);
                     cur = (next == kRefDone) ? -1 : next;   // interior index, leaf reference (< -1) or done
                 } else {
                     float4 n0 = nodes[2 * cur], n1 = nodes[2 * cur + 1];
