@@ -46,9 +46,11 @@ constexpr int kRefillMin = GX_REFILL_MIN;   // refill only when at least this ma
 constexpr int kTraceLeaveMul = GX_TRACE_LEAVE_MUL, kTraceLeaveDiv = GX_TRACE_LEAVE_DIV;   // leave phase A when searching <= live * MUL / DIV
 
 // Traversal stack of one lane: levels [0, K) in LDS, deeper levels in global memory (coalesced across the wave).
+typedef __attribute__((address_space(3))) int lds_int;
+typedef __attribute__((address_space(1))) int global_int;
 struct LaneStack {
-    int *lds;
-    int *spill;
+    lds_int *lds;        // explicit address spaces: keeps the two paths as ds_* / global_* instructions (no flat pointer select)
+    global_int *spill;
     int K;
     int stride;   // lanes in the grid (< 2^21), so (n - K) * stride fits 32 bits
     GX_DEV void push(int &n, int v) const {
@@ -136,10 +138,10 @@ template <bool COUNT, bool WIDE>
 __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, TraceWork w, unsigned int *cursor, Counters *ctr, int lds_entries, int *spill) {
     extern __shared__ int stack_mem[];   // lds_entries * kBlock ints
     LaneStack stack;
-    stack.lds = &stack_mem[threadIdx.x];
+    stack.lds = (lds_int *)&stack_mem[threadIdx.x];
     stack.K = lds_entries;
     stack.stride = (int)gridDim.x * kBlock;
-    stack.spill = spill + (size_t)blockIdx.x * kBlock + threadIdx.x;
+    stack.spill = (global_int *)(spill + (size_t)blockIdx.x * kBlock + threadIdx.x);
     const int lane = __lane_id();
     const unsigned total = (unsigned)w.n_closest + 2u * (unsigned)w.n_nee;
     const float4 *__restrict__ nodes = sc.nodes;
