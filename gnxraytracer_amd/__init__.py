@@ -289,6 +289,15 @@ def camera_rays(camera, width, height, px, py, s):
     return o, d
 
 
+def eval_libm(fn, x):
+    """Test hook: the device's logf / expf / sinf / cosf (fn = "log" | "exp" | "sin" | "cos") on the array x."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros_like(x)
+    _check(lib().gnxr_eval_libm({"log": 0, "exp": 1, "sin": 2, "cos": 3, "sincos.sin": 4, "sincos.cos": 5}[fn], x.ctypes.data_as(C.POINTER(C.c_float)), x.size,
+                                out.ctypes.data_as(C.POINTER(C.c_float))))
+    return out
+
+
 def framebuffer_update(running_mean, frame, frame_count):
     """FrameBuffer::update_f_u_c (ui/FrameBuffer.h:127-149): running mean + 1-exp(-4x) tone map to RGBA8."""
     h, w = frame.shape[:2]

@@ -574,6 +574,19 @@ int gnxr_camera_rays(const gnxr_camera *cam, int32_t width, int32_t height, cons
     return GNXR_OK;
 }
 
+int gnxr_eval_libm(int32_t fn, const float *x, int64_t n, float *out) {
+    if (!x || !out || n < 0 || fn < 0 || fn > 5) { set_error("bad argument"); return GNXR_ERR_INVALID; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n == 0) return GNXR_OK;
+    DevBuf<float> dx, dout;
+    if ((rc = dx.upload(x, (size_t)n)) || (rc = dout.alloc((size_t)n))) return rc;
+    hipLaunchKernelGGL(k_libm_probe, dim3(grid_for(n)), dim3(kBlock), 0, 0, (int)fn, (const float *)dx.p, (long long)n, dout.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return GNXR_OK;
+}
+
 int gnxr_framebuffer_update(float *running_mean_rgba, const float *frame_rgba, int32_t width, int32_t height, int32_t frame_count, uint8_t *rgba8_out) {
     if (!running_mean_rgba || !frame_rgba || !rgba8_out || width <= 0 || height <= 0 || frame_count <= 0) { set_error("bad argument"); return GNXR_ERR_INVALID; }
     int rc = ensure_device();

@@ -2,10 +2,10 @@
 //
 // Arithmetic follows the reference's inline math (core/Geometry.h, core/GNXRayTracer.h) operation for
 // operation: the library is compiled with -ffp-contract=off so hipcc does not fuse a*b+c (the x86-64
-// reference has no FMA), division and sqrt are IEEE (hipcc default), and libm calls go through
-// double-precision OCML and are rounded once to float (gx_sin etc.), which reproduces glibc's
-// correctly-rounded float results in all but ~1e-9 of the cases.  Together this keeps GPU paths on
-// the same discrete decisions (lobe choice, hit/miss, Russian roulette) as the CPU reference.
+// reference has no FMA), division and sqrt are IEEE (hipcc default), and the float libm calls the
+// reference makes (logf, expf, sinf, cosf) are glibc's own algorithms restated (gx_log etc. below).
+// Together this keeps GPU paths on the same discrete decisions (lobe choice, hit/miss, Russian
+// roulette, delta-tracking collisions) as the CPU reference.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -26,16 +26,170 @@ static constexpr float GX_SHADOW_EPS = 0.0001f;
 // gamma(n) = (n * MachineEpsilon) / (1 - n * MachineEpsilon), GNXRayTracer.h:354-357 (constant-folded in fp32)
 #define GX_GAMMA(n) (((n) * GX_MACH_EPS) / (1 - (n) * GX_MACH_EPS))
 
-// ---- libm through double (see header comment) ----
-GX_DEV float gx_sin(float x) { return (float)sin((double)x); }
-GX_DEV float gx_cos(float x) { return (float)cos((double)x); }
-// sin and cos of the same angle share OCML's argument reduction (same polynomials, same values as the two separate calls)
-GX_DEV void gx_sincos(float x, float *s, float *c) { double ds, dc; sincos((double)x, &ds, &dc); *s = (float)ds; *c = (float)dc; }
+// ---- float libm: glibc 2.35's own algorithms (sysdeps/ieee754/flt-32/{e_logf,e_expf,s_sinf,s_cosf}.c, the ARM
+// optimized-routines implementations: table + short polynomial evaluated in double, one rounding to float at the end).
+// The reference calls std::log / std::exp / std::sin / std::cos on floats, i.e. exactly these functions, and they are
+// NOT correctly rounded (0.5-0.9 ulp): rounding a double-precision result to float differs from them for 0.7 % (logf)
+// to 1.3 % (sinf, cosf) of the arguments.  Restating the algorithms operation for operation (same tables, same
+// evaluation order) reproduces glibc bit for bit -- checked against libm.so.6 on 4e5 random arguments per function --
+// and costs a dozen fp64 operations instead of OCML's full double-precision routines.
+// On x86-64 hosts with FMA (every host this runs next to) glibc dispatches to its -mfma builds of these functions, in
+// which GCC contracts a * b + c wherever every use of the product is an addition or subtraction; the explicit fma()
+// calls below are exactly those contractions (the plain products are the ones GCC leaves alone), e.g. in expf both
+// kd = z + Shift and r = z - kd take the unrounded product z = InvLn2N * x.
+// Rarely used functions (tan, acos, atan2, pow) still go through double OCML and are rounded once.
+__device__ static const double gx_logf_invc[16] = {
+    0x1.661ec79f8f3bep+0, 0x1.571ed4aaf883dp+0, 0x1.49539f0f010bp+0, 0x1.3c995b0b80385p+0, 0x1.30d190c8864a5p+0, 0x1.25e227b0b8eap+0,
+    0x1.1bb4a4a1a343fp+0, 0x1.12358f08ae5bap+0, 0x1.0953f419900a7p+0, 0x1p+0, 0x1.e608cfd9a47acp-1, 0x1.ca4b31f026aap-1,
+    0x1.b2036576afce6p-1, 0x1.9c2d163a1aa2dp-1, 0x1.886e6037841edp-1, 0x1.767dcf5534862p-1};
+__device__ static const double gx_logf_logc[16] = {
+    -0x1.57bf7808caadep-2, -0x1.2bef0a7c06ddbp-2, -0x1.01eae7f513a67p-2, -0x1.b31d8a68224e9p-3, -0x1.6574f0ac07758p-3, -0x1.1aa2bc79c81p-3,
+    -0x1.a4e76ce8c0e5ep-4, -0x1.1973c5a611cccp-4, -0x1.252f438e10c1ep-5, 0x0p+0, 0x1.aa5aa5df25984p-5, 0x1.c5e53aa362eb4p-4,
+    0x1.526e57720db08p-3, 0x1.bc2860d22477p-3, 0x1.1058bc8a07ee1p-2, 0x1.4043057b6ee09p-2};
+// exp2f_data.tab: asuint64(2^(i/32)) - (i << 47)
+__device__ static const unsigned long long gx_expf_tab[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+    0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+    0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+
+GX_DEV float gx_log(float x) {   // e_logf.c
+    uint32_t ix = __float_as_uint(x);
+    if (ix == 0x3f800000u) return 0.f;
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
+        if (ix * 2 == 0) return -__builtin_huge_valf();
+        if (ix == 0x7f800000u) return x;
+        if ((ix & 0x80000000u) || ix * 2 >= 0xff000000u) return __builtin_nanf("");
+        ix = __float_as_uint(x * 0x1p23f);   // subnormal: normalise
+        ix -= 23u << 23;
+    }
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> 19) & 15u);
+    const int k = (int)tmp >> 23;
+    const uint32_t iz = ix - (tmp & 0xff800000u);
+    const double invc = gx_logf_invc[i], logc = gx_logf_logc[i];
+    const double z = (double)__uint_as_float(iz);
+    const double r = fma(z, invc, -1.0);
+    const double y0 = fma((double)k, 0x1.62e42fefa39efp-1, logc);
+    const double r2 = r * r;
+    double y = fma(0x1.5575b0be00b6ap-2, r, -0x1.ffffef20a4123p-2);
+    y = fma(-0x1.00ea348b88334p-2, r2, y);
+    y = fma(y, r2, y0 + r);
+    return (float)y;
+}
+GX_DEV float gx_exp(float x) {   // e_expf.c (N = 32)
+    const uint32_t abstop = (__float_as_uint(x) >> 20) & 0x7ffu;
+    if (abstop >= 0x42bu) {   // |x| >= 88 or NaN
+        if (__float_as_uint(x) == 0xff800000u) return 0.f;
+        if (abstop >= 0x7f8u) return x + x;
+        if (x > 0x1.62e42ep6f) return __builtin_huge_valf();
+        if (x < -0x1.9fe368p6f) return 0.f;
+    }
+    const double xd = (double)x;
+    double kd = fma(0x1.71547652b82fep+0 * 32, xd, 0x1.8p+52);
+    const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+    kd -= 0x1.8p+52;
+    const double r = fma(0x1.71547652b82fep+0 * 32, xd, -kd);
+    const unsigned long long t = gx_expf_tab[ki & 31u] + (ki << 47);
+    const double s = __longlong_as_double((long long)t);
+    const double zz = fma(0x1.c6af84b912394p-5 / 32 / 32 / 32, r, 0x1.ebfce50fac4f3p-3 / 32 / 32);
+    const double r2 = r * r;
+    double y = fma(0x1.62e42ff0c52d6p-1 / 32, r, 1.0);
+    y = fma(zz, r2, y);
+    y = y * s;
+    return (float)y;
+}
+// s_sincosf.h: sinf_poly with the coefficient set of __sincosf_table[neg] (neg: cosine coefficients negated)
+GX_DEV double gx_sinf_poly(double x, double x2, bool neg, int n) {
+    if ((n & 1) == 0) {
+        double x3 = x * x2;
+        double s1 = fma(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7);
+        double x7 = x3 * x2;
+        double s = fma(x3, -0x1.555545995a603p-3, x);
+        return fma(x7, s1, s);
+    }
+    const double sg = neg ? -1.0 : 1.0;   // exact sign flips of the table constants
+    double x4 = x2 * x2;
+    double c2 = fma(x2, sg * 0x1.99343027bf8c3p-16, sg * -0x1.6c087e89a359dp-10);
+    double c1 = fma(x2, sg * -0x1.ffffffd0c621cp-2, sg * 0x1p0);
+    double x6 = x4 * x2;
+    double c = fma(x4, sg * 0x1.55553e1068f19p-5, c1);
+    return fma(x6, c2, c);
+}
+GX_DEV double gx_reduce_fast(double x, int *np) {   // |x| < 120
+    double r = x * 0x1.45F306DC9C883p+23;
+    int n = ((int)r + 0x800000) >> 24;
+    *np = n;
+    return fma(-(double)n, 0x1.921FB54442D18p0, x);
+}
+GX_DEV float gx_sin(float y) {   // s_sinf.c
+    const uint32_t top = (__float_as_uint(y) >> 20) & 0x7ffu;
+    double x = (double)y;
+    if (top < 0x3f4u) {            // |y| < pi/4 (abstop12 compare)
+        if (top < 0x398u) return y;   // |y| < 2^-12
+        return (float)gx_sinf_poly(x, x * x, false, 0);
+    }
+    if (top < 0x42fu) {            // |y| < 120
+        int n;
+        x = gx_reduce_fast(x, &n);
+        const double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;   // sign[n & 3] = {1, -1, -1, 1}
+        return (float)gx_sinf_poly(x * s, x * x, (n & 2) != 0, n);
+    }
+    return (float)sin((double)y);   // large arguments do not occur on this path
+}
+GX_DEV float gx_cos(float y) {   // s_cosf.c
+    const uint32_t top = (__float_as_uint(y) >> 20) & 0x7ffu;
+    double x = (double)y;
+    if (top < 0x3f4u) {
+        if (top < 0x398u) return 1.0f;
+        return (float)gx_sinf_poly(x, x * x, false, 1);
+    }
+    if (top < 0x42fu) {
+        int n;
+        x = gx_reduce_fast(x, &n);
+        const int m = n + 1;
+        const double s = ((m & 3) == 1 || (m & 3) == 2) ? -1.0 : 1.0;
+        return (float)gx_sinf_poly(x * s, x * x, (m & 2) != 0, n ^ 1);
+    }
+    return (float)cos((double)y);
+}
+// sinf(y) and cosf(y) of the same argument: the two calls share the argument reduction, and between them evaluate the
+// sine polynomial once and the cosine polynomial once (which of the two results gets which depends on the quadrant).
+GX_DEV void gx_sincos(float y, float *sOut, float *cOut) {
+    const uint32_t top = (__float_as_uint(y) >> 20) & 0x7ffu;
+    double x = (double)y;
+    if (top < 0x3f4u) {
+        if (top < 0x398u) { *sOut = y; *cOut = 1.0f; return; }
+        const double x2 = x * x;
+        *sOut = (float)gx_sinf_poly(x, x2, false, 0);
+        *cOut = (float)gx_sinf_poly(x, x2, false, 1);
+        return;
+    }
+    if (top < 0x42fu) {
+        int n;
+        x = gx_reduce_fast(x, &n);
+        const int m = n + 1;
+        const double ss = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;   // sign[n & 3]
+        const double cs = ((m & 3) == 1 || (m & 3) == 2) ? -1.0 : 1.0;   // sign[(n + 1) & 3]
+        const double x2 = x * x;
+        const bool odd = (n & 1) != 0;
+        // the even-index branch of sinf_poly takes the signed argument, the odd-index branch only x2 and the table
+        const double pe = gx_sinf_poly(x * (odd ? cs : ss), x2, false, 0);
+        const double po = gx_sinf_poly(0.0, x2, odd ? (n & 2) != 0 : (m & 2) != 0, 1);
+        *sOut = (float)(odd ? po : pe);
+        *cOut = (float)(odd ? pe : po);
+        return;
+    }
+    *sOut = (float)sin((double)y);
+    *cOut = (float)cos((double)y);
+}
 GX_DEV float gx_tan(float x) { return (float)tan((double)x); }
 GX_DEV float gx_acos(float x) { return (float)acos((double)x); }
 GX_DEV float gx_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }
-GX_DEV float gx_log(float x) { return (float)log((double)x); }
-GX_DEV float gx_exp(float x) { return (float)exp((double)x); }
 GX_DEV float gx_pow(float x, float y) { return (float)pow((double)x, (double)y); }
 // __fsqrt_rn maps to the *native* (not correctly rounded) sqrt in this ROCm; the builtin is IEEE under hipcc's default
 // -fhip-fp32-correctly-rounded-divide-sqrt.

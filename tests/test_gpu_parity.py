@@ -36,6 +36,30 @@ def test_native_library_is_the_one_loaded(gpu):
     assert "libgnxr.so" in maps
 
 
+@pytest.mark.parametrize("fn", ["log", "exp", "sin", "cos"])
+def test_float_libm_carries_glibc_bits(gpu, fn):
+    """std::log / exp / sin / cos on floats are glibc's logf / expf / sinf / cosf in the reference (not correctly rounded);
+    the device restates those algorithms (device_math.h).  Checked against this image's libm.so.6, bit for bit, over the
+    argument ranges the path produces (1 - u, -sigma_t * t, angles in [-pi, 2 pi])."""
+    import ctypes as C
+    libm = C.CDLL("libm.so.6")
+    f = getattr(libm, fn + "f")
+    f.restype, f.argtypes = C.c_float, [C.c_float]
+    rng = np.random.default_rng(11)
+    n = 200000
+    if fn == "log":
+        x = np.concatenate([1 - rng.random(n, dtype=np.float32), np.exp(rng.uniform(-30, 30, n)).astype(np.float32), [1.0, 0.5, 2.0 ** -24, 1e-40]])
+    elif fn == "exp":
+        x = np.concatenate([-rng.exponential(5.0, n), rng.uniform(-110, 90, n), [0.0, -0.0, -1e-8, -103.9, -104.5, 88.7, 89.0]])
+    else:
+        x = np.concatenate([rng.uniform(-np.pi, 2 * np.pi, n), rng.uniform(-1e-3, 1e-3, n // 4), rng.uniform(-119, 119, n), [0.0, np.pi / 4, 0.75, 0.78]])
+    x = x.astype(np.float32)
+    ref = np.array([f(float(v)) for v in x], np.float32)
+    assert biteq(gpu.eval_libm(fn, x), ref)
+    if fn in ("sin", "cos"):
+        assert biteq(gpu.eval_libm("sincos." + fn, x), ref)
+
+
 @pytest.mark.parametrize("res", [(256, 256), (1920, 1080), (64, 64)])
 def test_halton_bit_exact(gpu, res):
     g = golden(f"halton_{res[0]}x{res[1]}.npz")
