@@ -1,10 +1,10 @@
 """GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI (libgnxr.so),
 against the golden vectors from the compiled reference and against the CPU oracle on the same seeded inputs.
 
-Bars: bit-exact for integer / index work and for everything that involves no libm call (Halton values,
-camera rays, hit records); images within RMSE 1e-4 and max-abs 5e-3 of the reference (the north-star bar is
-RMSE < 1e-3) -- the residue is OCML-vs-glibc transcendental rounding on a handful of paths; ray counts within
-0.1 % (BASELINE.md parity gate)."""
+Bars: bit-exact for integer / index work, for Halton values, camera rays, hit records, the float libm, and -- since the
+device restates glibc's logf / expf / sinf / cosf -- for whole IMAGES and ray counts of every golden scene except the
+environment-lit one (acosf / atan2f still go through double-precision OCML there: RMSE 1e-4 / max-abs 5e-3, north-star
+bar RMSE < 1e-3, ray counts within 0.1 %)."""
 import os
 
 import numpy as np
@@ -132,13 +132,16 @@ def _render_case(gpu, name):
 def test_render_matches_reference_images(gpu, name):
     b, integ, (W, H, spp), ref_img, ref_rays = _render_case(gpu, name)
     img, st = integ.Render(gpu.Scene(b), W, H, spp)
-    r, mx = rmse(img, ref_img)
-    assert r < RMSE_TOL and mx < MAXABS_TOL, (r, mx)
-    assert abs(st["rays_closest"] - ref_rays[0]) <= RAYS_TOL * ref_rays[0]
-    assert abs(st["rays_any"] - ref_rays[1]) <= RAYS_TOL * ref_rays[1]
     assert (img[..., 3] == 1).all()
-    # the bulk of the pixels is bit-identical to the CPU reference
-    assert (img[..., :3].view(np.uint32) == ref_img[..., :3].view(np.uint32)).mean() > 0.9
+    if name == "cornell_env":   # InfiniteAreaLight::Pdf_Li / Le use acosf / atan2f (double OCML on the device)
+        r, mx = rmse(img, ref_img)
+        assert r < RMSE_TOL and mx < MAXABS_TOL, (r, mx)
+        assert abs(st["rays_closest"] - ref_rays[0]) <= RAYS_TOL * ref_rays[0]
+        assert abs(st["rays_any"] - ref_rays[1]) <= RAYS_TOL * ref_rays[1]
+        assert (img[..., :3].view(np.uint32) == ref_img[..., :3].view(np.uint32)).mean() > 0.9
+    else:                       # every pixel and both ray counts carry the reference's bits
+        assert (st["rays_closest"], st["rays_any"]) == ref_rays
+        assert biteq(img[..., :3], ref_img[..., :3])
 
 
 def test_cfg2_full_size_against_recorded_reference_run(gpu):
@@ -146,10 +149,9 @@ def test_cfg2_full_size_against_recorded_reference_run(gpu):
     were recorded from the complete reference."""
     g = golden("cfg2_recorded.npz")
     img, st = gpu.PathIntegrator(8, 1.0, "spatial").Render(gpu.Scene(scenes.cornell()), 256, 256, 64)
-    assert abs(st["rays_closest"] - 16058662) <= 16 and abs(st["rays_any"] - 12329468) <= RAYS_TOL * 12329468
-    assert abs(float(img[..., :3].astype(np.float64).sum()) - 78538.576918) < 0.05
-    r, mx = rmse(img[::4, ::4], g["thumb"])
-    assert r < RMSE_TOL
+    assert (st["rays_closest"], st["rays_any"]) == (16058662, 12329468)
+    assert abs(float(img[..., :3].astype(np.float64).sum()) - 78538.576918) < 1e-5
+    assert biteq(img[::4, ::4, :3], g["thumb"])
 
 
 def test_full_size_properties_1080p(gpu):
@@ -194,6 +196,9 @@ def test_dragon_scene_against_oracle(gpu):
     assert r < RMSE_TOL, (r, mx)
     assert abs(st["rays_closest"] - ost["rays_closest"]) <= RAYS_TOL * ost["rays_closest"]
     assert abs(st["rays_any"] - ost["rays_any"]) <= RAYS_TOL * ost["rays_any"]
+    same = (img[..., :3].view(np.uint32) == oimg[..., :3].view(np.uint32)).mean()
+    print(f"dragon 240x135x8: {same * 100:.4f} % of the values bit-identical, rays {st['rays_closest']}/{st['rays_any']} vs {ost['rays_closest']}/{ost['rays_any']}")
+    assert same > 0.999
 
 
 @pytest.mark.parametrize("name", ["vol_synth", "vol_cfg5"])
@@ -204,11 +209,8 @@ def test_volpath_matches_reference_images(gpu, name):
     W, H, spp, depth = (int(v) for v in g[name + "_cfg"])
     b = scenes.volume_cornell(sigma_a=(0.5,) * 3, sigma_s=(3.5,) * 3, g_grid=0.3) if name == "vol_synth" else scenes.volume_cornell_cfg5(0.05)
     img, st = gpu.VolPathIntegrator(depth, 1.0, "spatial").Render(gpu.Scene(b), W, H, spp)
-    r, mx = rmse(img, g[name])
-    assert r < RMSE_TOL and mx < MAXABS_TOL, (r, mx)
-    ref_rays = int(g[name + "_rays"][0])
-    assert abs(st["rays_closest"] - ref_rays) <= RAYS_TOL * ref_rays and st["rays_any"] == 0
-    assert (img[..., :3].view(np.uint32) == g[name][..., :3].view(np.uint32)).mean() > 0.9
+    assert (st["rays_closest"], st["rays_any"]) == (int(g[name + "_rays"][0]), 0)
+    assert biteq(img[..., :3], g[name][..., :3])
 
 
 def test_volpath_cfg5_density_against_oracle(gpu):
