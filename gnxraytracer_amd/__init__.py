@@ -289,12 +289,16 @@ def camera_rays(camera, width, height, px, py, s):
     return o, d
 
 
-def eval_libm(fn, x):
-    """Test hook: the device's logf / expf / sinf / cosf (fn = "log" | "exp" | "sin" | "cos") on the array x."""
+def eval_libm(fn, x, x2=None):
+    """Test hook: the device's float libm (fn = "log" | "exp" | "sin" | "cos" | "acos" | "atan2") on the array x (atan2: y = x, x = x2)."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     out = np.zeros_like(x)
-    _check(lib().gnxr_eval_libm({"log": 0, "exp": 1, "sin": 2, "cos": 3, "sincos.sin": 4, "sincos.cos": 5}[fn], x.ctypes.data_as(C.POINTER(C.c_float)), x.size,
-                                out.ctypes.data_as(C.POINTER(C.c_float))))
+    p2 = None
+    if x2 is not None:
+        x2 = np.ascontiguousarray(x2, dtype=np.float32)
+        p2 = x2.ctypes.data_as(C.POINTER(C.c_float))
+    code = {"log": 0, "exp": 1, "sin": 2, "cos": 3, "sincos.sin": 4, "sincos.cos": 5, "acos": 6, "atan2": 7}[fn]
+    _check(lib().gnxr_eval_libm(code, x.ctypes.data_as(C.POINTER(C.c_float)), p2, x.size, out.ctypes.data_as(C.POINTER(C.c_float))))
     return out
 
 

@@ -574,14 +574,15 @@ int gnxr_camera_rays(const gnxr_camera *cam, int32_t width, int32_t height, cons
     return GNXR_OK;
 }
 
-int gnxr_eval_libm(int32_t fn, const float *x, int64_t n, float *out) {
-    if (!x || !out || n < 0 || fn < 0 || fn > 5) { set_error("bad argument"); return GNXR_ERR_INVALID; }
+int gnxr_eval_libm(int32_t fn, const float *x, const float *x2, int64_t n, float *out) {
+    if (!x || !out || n < 0 || fn < 0 || fn > 7 || (fn == 7 && !x2)) { set_error("bad argument"); return GNXR_ERR_INVALID; }
     int rc = ensure_device();
     if (rc) return rc;
     if (n == 0) return GNXR_OK;
-    DevBuf<float> dx, dout;
+    DevBuf<float> dx, dx2, dout;
     if ((rc = dx.upload(x, (size_t)n)) || (rc = dout.alloc((size_t)n))) return rc;
-    hipLaunchKernelGGL(k_libm_probe, dim3(grid_for(n)), dim3(kBlock), 0, 0, (int)fn, (const float *)dx.p, (long long)n, dout.p);
+    if (x2 && (rc = dx2.upload(x2, (size_t)n))) return rc;
+    hipLaunchKernelGGL(k_libm_probe, dim3(grid_for(n)), dim3(kBlock), 0, 0, (int)fn, (const float *)dx.p, (const float *)(x2 ? dx2.p : nullptr), (long long)n, dout.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     return GNXR_OK;

@@ -37,7 +37,7 @@ static constexpr float GX_SHADOW_EPS = 0.0001f;
 // which GCC contracts a * b + c wherever every use of the product is an addition or subtraction; the explicit fma()
 // calls below are exactly those contractions (the plain products are the ones GCC leaves alone), e.g. in expf both
 // kd = z + Shift and r = z - kd take the unrounded product z = InvLn2N * x.
-// Rarely used functions (tan, acos, atan2, pow) still go through double OCML and are rounded once.
+// tan (host-side camera set-up only) and pow (Disney clearcoat sampling only) still go through double OCML.
 __device__ static const double gx_logf_invc[16] = {
     0x1.661ec79f8f3bep+0, 0x1.571ed4aaf883dp+0, 0x1.49539f0f010bp+0, 0x1.3c995b0b80385p+0, 0x1.30d190c8864a5p+0, 0x1.25e227b0b8eap+0,
     0x1.1bb4a4a1a343fp+0, 0x1.12358f08ae5bap+0, 0x1.0953f419900a7p+0, 0x1p+0, 0x1.e608cfd9a47acp-1, 0x1.ca4b31f026aap-1,
@@ -188,8 +188,102 @@ GX_DEV void gx_sincos(float y, float *sOut, float *cOut) {
     *cOut = (float)cos((double)y);
 }
 GX_DEV float gx_tan(float x) { return (float)tan((double)x); }
-GX_DEV float gx_acos(float x) { return (float)acos((double)x); }
-GX_DEV float gx_atan2(float y, float x) { return (float)atan2((double)y, (double)x); }
+// acosf / atanf / atan2f: glibc 2.35 still ships the fdlibm float versions (sysdeps/ieee754/flt-32/{e_acosf,s_atanf,e_atan2f}.c),
+// plain float arithmetic, no FMA build.  Constants are the decimal literals of those files (for aT[0] the literal,
+// 3.3333334327e-01 = 0x3eaaaaab, not the 0x3eaaaaaa of its comment).  Checked against libm.so.6 like the functions above.
+GX_DEV float gx_acos(float x) {
+    const float one = 1.0f, pi = 3.1415925026e+00f, pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f;
+    const float pS0 = 1.6666667163e-01f, pS1 = -3.2556581497e-01f, pS2 = 2.0121252537e-01f, pS3 = -4.0055535734e-02f, pS4 = 7.9153501429e-04f,
+                pS5 = 3.4793309169e-05f, qS1 = -2.4033949375e+00f, qS2 = 2.0209457874e+00f, qS3 = -6.8828397989e-01f, qS4 = 7.7038154006e-02f;
+    const int32_t hx = __float_as_int(x), ix = hx & 0x7fffffff;
+    if (ix == 0x3f800000) return hx > 0 ? 0.0f : pi + 2.0f * pio2_lo;
+    if (ix > 0x3f800000) return (x - x) / (x - x);
+    if (ix < 0x3f000000) {   // |x| < 0.5
+        if (ix <= 0x32800000) return pio2_hi + pio2_lo;
+        float z = x * x;
+        float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        float q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        float r = p / q;
+        return pio2_hi - (x - (pio2_lo - x * r));
+    } else if (hx < 0) {     // x < -0.5
+        float z = (one + x) * 0.5f;
+        float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        float q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        float s = __builtin_sqrtf(z);
+        float r = p / q;
+        float w = r * s - pio2_lo;
+        return pi - 2.0f * (s + w);
+    } else {                 // x > 0.5
+        float z = (one - x) * 0.5f;
+        float s = __builtin_sqrtf(z);
+        float df = __uint_as_float(__float_as_uint(s) & 0xfffff000u);
+        float c = (z - df * df) / (s + df);
+        float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        float q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        float r = p / q;
+        float w = r * s + c;
+        return 2.0f * (df + w);
+    }
+}
+GX_DEV float gx_atan(float x) {
+    const float atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+    const float atanlo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+    const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f, aT3 = -1.1111110449e-01f, aT4 = 9.0908870101e-02f,
+                aT5 = -7.6918758452e-02f, aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f, aT8 = 4.9768779427e-02f, aT9 = -3.6531571299e-02f,
+                aT10 = 1.6285819933e-02f;
+    const float one = 1.0f;
+    const int32_t hx = __float_as_int(x), ix = hx & 0x7fffffff;
+    int id;
+    if (ix >= 0x4c000000) {   // |x| >= 2^25
+        if (ix > 0x7f800000) return x + x;
+        return hx > 0 ? atanhi[3] + atanlo[3] : -atanhi[3] - atanlo[3];
+    }
+    if (ix < 0x3ee00000) {    // |x| < 0.4375
+        if (ix < 0x31000000) return x;
+        id = -1;
+    } else {
+        x = fabsf(x);
+        if (ix < 0x3f980000) {
+            if (ix < 0x3f300000) { id = 0; x = (2.0f * x - one) / (2.0f + x); }
+            else { id = 1; x = (x - one) / (x + one); }
+        } else {
+            if (ix < 0x401c0000) { id = 2; x = (x - 1.5f) / (one + 1.5f * x); }
+            else { id = 3; x = -1.0f / x; }
+        }
+    }
+    float z = x * x;
+    float w = z * z;
+    float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    if (id < 0) return x - x * (s1 + s2);
+    const float hi = id == 0 ? atanhi[0] : (id == 1 ? atanhi[1] : (id == 2 ? atanhi[2] : atanhi[3]));
+    const float lo = id == 0 ? atanlo[0] : (id == 1 ? atanlo[1] : (id == 2 ? atanlo[2] : atanlo[3]));
+    z = hi - ((x * (s1 + s2) - lo) - x);
+    return hx < 0 ? -z : z;
+}
+GX_DEV float gx_atan2(float y, float x) {
+    const float tiny = 1.0e-30f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f, pi_o_4 = 7.8539818525e-01f;
+    const int32_t hx = __float_as_int(x), ix = hx & 0x7fffffff, hy = __float_as_int(y), iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
+    if (hx == 0x3f800000) return gx_atan(y);
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+    if (iy == 0) return m < 2 ? y : (m == 2 ? pi + tiny : -pi - tiny);
+    if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000) return m == 0 ? pi_o_4 + tiny : (m == 1 ? -pi_o_4 - tiny : (m == 2 ? 3.0f * pi_o_4 + tiny : -3.0f * pi_o_4 - tiny));
+        return m == 0 ? 0.0f : (m == 1 ? -0.0f : (m == 2 ? pi + tiny : -pi - tiny));
+    }
+    if (iy == 0x7f800000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    const int k = (iy - ix) >> 23;
+    float z;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
+    else if (hx < 0 && k < -60) z = 0.0f;
+    else z = gx_atan(fabsf(y / x));
+    if (m == 0) return z;
+    if (m == 1) return -z;
+    if (m == 2) return pi - (z - pi_lo);
+    return (z - pi_lo) - pi;
+}
 GX_DEV float gx_pow(float x, float y) { return (float)pow((double)x, (double)y); }
 // __fsqrt_rn maps to the *native* (not correctly rounded) sqrt in this ROCm; the builtin is IEEE under hipcc's default
 // -fhip-fp32-correctly-rounded-divide-sqrt.

@@ -396,10 +396,12 @@ __global__ void k_camera_probe(DSamplerTables st, DCamera cam, const int *px, co
 }
 
 // test hook: the device's float libm (device_math.h) on caller-supplied arguments
-__global__ void k_libm_probe(int fn, const float *x, long long n, float *out) {
+__global__ void k_libm_probe(int fn, const float *x, const float *x2, long long n, float *out) {
     for (long long i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float v = x[i];
-        if (fn >= 4) { float sv, cv; gx_sincos(v, &sv, &cv); out[i] = fn == 4 ? sv : cv; }
+        if (fn == 6) out[i] = gx_acos(v);
+        else if (fn == 7) out[i] = gx_atan2(v, x2 ? x2[i] : 1.0f);
+        else if (fn >= 4) { float sv, cv; gx_sincos(v, &sv, &cv); out[i] = fn == 4 ? sv : cv; }
         else out[i] = fn == 0 ? gx_log(v) : (fn == 1 ? gx_exp(v) : (fn == 2 ? gx_sin(v) : gx_cos(v)));
     }
 }

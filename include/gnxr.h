@@ -261,11 +261,11 @@ int gnxr_camera_rays(const gnxr_camera *cam, int32_t width, int32_t height, cons
                      const int32_t *py, const int64_t *s, int64_t n, float *o_out, float *d_out);
 
 /* Unit-test hook: the device's float libm on caller-supplied arguments.  fn: 0 logf, 1 expf, 2 sinf, 3 cosf, 4 / 5 sinf / cosf
- * through the shared-reduction pair evaluation.  The
+ * through the shared-reduction pair evaluation, 6 acosf, 7 atan2f(x, x2) (x2 may be NULL otherwise).  The
  * reference reaches these through std::log / std::exp / std::sin / std::cos on floats (core/Sampling.cpp:87-105,
- * media/GridDensityMedium.cpp:41,67, media/HomogeneousMedium.cpp:13,24, core/Medium.cpp:187); the device restates
- * glibc 2.35's algorithms so the results carry glibc's bits. */
-int gnxr_eval_libm(int32_t fn, const float *x, int64_t n, float *out);
+ * media/GridDensityMedium.cpp:41,67, media/HomogeneousMedium.cpp:13,24, core/Medium.cpp:187, core/Geometry.h:1436-1443);
+ * the device restates glibc 2.35's algorithms so the results carry glibc's bits. */
+int gnxr_eval_libm(int32_t fn, const float *x, const float *x2, int64_t n, float *out);
 
 /* -- output stage (FrameBuffer::update_f_u_c, ui/FrameBuffer.h:127-149) ------------------ */
 /* Folds one Render() result into the running mean of `frame_count` previous frames and
