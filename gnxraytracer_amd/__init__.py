@@ -260,7 +260,18 @@ class PathIntegrator:
 
 
 class VolPathIntegrator(PathIntegrator):
+    """pbr::VolPathIntegrator (integrators/VolPathIntegrator.cpp): same constructor arguments as PathIntegrator."""
     integrator = _abi.INTEGRATOR_VOLPATH
+
+
+class WhittedIntegrator(PathIntegrator):
+    """pbr::WhittedIntegrator(maxDepth, ...) (integrators/WhittedIntegrator.h): BASELINE config 1, the reference's CPU-only
+    path.  libgnxr has no device implementation of it (gnxr_render returns GNXR_ERR_UNSUPPORTED); the class exists so that
+    the test oracle can be driven through the same interface."""
+    integrator = _abi.INTEGRATOR_WHITTED
+
+    def __init__(self, maxDepth=5):
+        super().__init__(maxDepth, 1.0, "uniform")
 
 
 def sample_halton(width, height, px, py, s, dim):

@@ -209,6 +209,22 @@ def main():
         assert maxdim < 1000, "fixture reaches the reference's undefined dimensions"
         assert (oimg.view(np.uint32) == vols[name].view(np.uint32)).all()
     save("render_vol.npz", **vols)
+    # ---- 12: WhittedIntegrator (cfg 1, the reference's CPU-only config): 64x64 fixtures + the full 256x256 @ 16 spp, maxDepth 5
+    wh = {}
+    for name, path in [("cornell", cornell_path), ("zoo", zoo_path)]:
+        W, H, spp, depth = 64, 64, 16, 5
+        raw = ol.run_ref(path, "render", None, [W, H, spp, depth, 1.0, 0, 0, 2])
+        wh[name] = np.frombuffer(raw[:W * H * 16], np.float32).reshape(H, W, 4).copy()
+        wh[name + "_rays"] = np.frombuffer(raw[W * H * 16:W * H * 16 + 16], np.uint64).copy()
+        wh[name + "_cfg"] = np.array([W, H, spp, depth], np.int32)
+    W, H, spp, depth = 256, 256, 16, 5
+    raw = ol.run_ref(cornell_path, "render", None, [W, H, spp, depth, 1.0, 0, 0, 2])
+    img = np.frombuffer(raw[:W * H * 16], np.float32).reshape(H, W, 4)
+    wh["cfg1_thumb"] = img[::4, ::4, :3].copy()
+    wh["cfg1_rays"] = np.frombuffer(raw[W * H * 16:W * H * 16 + 16], np.uint64).copy()
+    wh["cfg1_checksum"] = np.float64(img[..., :3].astype(np.float64).sum())
+    print("cfg1 (Whitted 256x256 @16spp): rays", wh["cfg1_rays"], "checksum %.6f" % float(wh["cfg1_checksum"]))
+    save("render_whitted.npz", **wh)
     # cfg 2 at full size: the counts the survey recorded from the COMPLETE reference
     img, cnt = render(cornell_path, 256, 256, 64)
     checksum = float(img[..., :3].astype(np.float64).sum())

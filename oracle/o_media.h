@@ -336,6 +336,54 @@ inline Spec VolPathLi(const RenderContext &rc, const PathParams &pp, const Ray &
     return L;
 }
 
-inline Spec WhittedLi(const RenderContext &, const PathParams &, const Ray &, SampleStream &, int) { return Spec(0.f); }
+// integrators/WhittedIntegrator.cpp:14-68 + SamplerIntegrator::SpecularReflect / SpecularTransmit, core/Integrator.cpp:321-442
+// (BASELINE config 1: the reference's CPU-only path).  Ray differentials are carried by the reference but feed only texture
+// filtering, and every texture on this path is a ConstantTexture, so they do not reach the radiance and are not restated.
+// The depth-first recursion consumes the sample stream in DFS order: all lights of a vertex, then the reflected subtree,
+// then the transmitted subtree.
+inline Spec WhittedLi(const RenderContext &rc, const PathParams &pp, const Ray &ray, SampleStream &sampler, int depth) {
+    const Scene &scene = *rc.scene;
+    Spec L(0.f);
+    SurfaceInteraction isect;
+    if (!scene.Intersect(ray, &isect)) {
+        for (int light = 0; light < (int)scene.lights.size(); ++light) L += rc.LightLe(light, ray);
+        return L;
+    }
+    V3 wo = isect.wo;
+    BSDF bsdf;
+    if (!ComputeScatteringFunctions(scene, &isect, false, &bsdf)) return WhittedLi(rc, pp, isect.SpawnRay(ray.d), sampler, depth);
+    const V3 n = isect.sn;   // `const Normal3f &n = isect.shading.n` is read after Bump ran
+    L += rc.Le(isect, wo);
+    Spec lightL(0.f);
+    for (int light = 0; light < (int)scene.lights.size(); ++light) {
+        LightSample ls = rc.Sample_Li(light, isect, sampler.Get2D());
+        if (ls.Li.IsBlack() || ls.pdf == 0) continue;
+        Spec f = bsdf.f(wo, ls.wi, BSDF_ALL);
+        if (!f.IsBlack() && !scene.IntersectP(isect.SpawnRayTo(ls.p1))) lightL += f * ls.Li * AbsDot(ls.wi, n) / ls.pdf;
+    }
+    L += lightL;
+    if (depth + 1 < pp.maxDepth) {
+        {   // SpecularReflect
+            V3 wi;
+            Float pdf;
+            int sampledType = 0;
+            Spec f = bsdf.Sample_f(wo, &wi, sampler.Get2D(), &pdf, BSDF_REFLECTION | BSDF_SPECULAR, &sampledType);
+            const V3 ns = isect.sn;
+            if (pdf > 0.f && !f.IsBlack() && AbsDot(wi, ns) != 0.f) L += f * WhittedLi(rc, pp, isect.SpawnRay(wi), sampler, depth + 1) * AbsDot(wi, ns) / pdf;
+            else L += Spec(0.f);
+        }
+        {   // SpecularTransmit
+            V3 wi;
+            Float pdf;
+            int sampledType = 0;
+            Spec f = bsdf.Sample_f(wo, &wi, sampler.Get2D(), &pdf, BSDF_TRANSMISSION | BSDF_SPECULAR, &sampledType);
+            const V3 ns = isect.sn;
+            Spec Lt(0.f);
+            if (pdf > 0.f && !f.IsBlack() && AbsDot(wi, ns) != 0.f) Lt = f * WhittedLi(rc, pp, isect.SpawnRay(wi), sampler, depth + 1) * AbsDot(wi, ns) / pdf;
+            L += Lt;
+        }
+    }
+    return L;
+}
 
 }  // namespace gnxo

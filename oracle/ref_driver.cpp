@@ -525,6 +525,60 @@ Spectrum refVolPathLi(const RayDifferential &r, const Scene &scene, Sampler &sam
     return L;
 }
 
+// WhittedIntegrator::Li + SamplerIntegrator::SpecularReflect / SpecularTransmit (integrators/WhittedIntegrator.cpp:14-68,
+// core/Integrator.cpp:321-442) restated on the reference's classes; the ray-differential bookkeeping is left out (it does
+// not reach the radiance with constant textures).
+Spectrum refWhittedLi(const RayDifferential &ray, const Scene &scene, Sampler &sampler, MemoryArena &arena, int maxDepth, int depth) {
+    Spectrum L(0.);
+    SurfaceInteraction isect;
+    if (!scene.Intersect(ray, &isect)) {
+        for (const auto &light : scene.lights) L += light->Le(ray);
+        return L;
+    }
+    const Normal3f &n = isect.shading.n;
+    Vector3f wo = isect.wo;
+    isect.ComputeScatteringFunctions(ray, arena);
+    if (!isect.bsdf) return refWhittedLi(isect.SpawnRay(ray.d), scene, sampler, arena, maxDepth, depth);
+    L += isect.Le(wo);
+    Spectrum lightL(0.0);
+    for (const auto &light : scene.lights) {
+        Vector3f wi;
+        Float pdf;
+        VisibilityTester visibility;
+        Spectrum Li = light->Sample_Li(isect, sampler.Get2D(), &wi, &pdf, &visibility);
+        if (Li.IsBlack() || pdf == 0) continue;
+        Spectrum f = isect.bsdf->f(wo, wi);
+        if (!f.IsBlack() && visibility.Unoccluded(scene)) lightL += f * Li * AbsDot(wi, n) / pdf;
+    }
+    L += lightL;
+    if (depth + 1 < maxDepth) {
+        {
+            Vector3f wi;
+            Float pdf;
+            BxDFType type = BxDFType(BSDF_REFLECTION | BSDF_SPECULAR);
+            Spectrum f = isect.bsdf->Sample_f(wo, &wi, sampler.Get2D(), &pdf, type);
+            const Normal3f &ns = isect.shading.n;
+            if (pdf > 0.f && !f.IsBlack() && AbsDot(wi, ns) != 0.f) {
+                RayDifferential rd = isect.SpawnRay(wi);
+                L += f * refWhittedLi(rd, scene, sampler, arena, maxDepth, depth + 1) * AbsDot(wi, ns) / pdf;
+            } else L += Spectrum(0.f);
+        }
+        {
+            Vector3f wi;
+            Float pdf;
+            Spectrum f = isect.bsdf->Sample_f(wo, &wi, sampler.Get2D(), &pdf, BxDFType(BSDF_TRANSMISSION | BSDF_SPECULAR));
+            Spectrum Lt = Spectrum(0.f);
+            Normal3f ns = isect.shading.n;
+            if (pdf > 0.f && !f.IsBlack() && AbsDot(wi, ns) != 0.f) {
+                RayDifferential rd = isect.SpawnRay(wi);
+                Lt = f * refWhittedLi(rd, scene, sampler, arena, maxDepth, depth + 1) * AbsDot(wi, ns) / pdf;
+            }
+            L += Lt;
+        }
+    }
+    return L;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -757,7 +811,8 @@ int main(int argc, char **argv) {
         Float rr = (Float)atof(argv[9]);
         int strat = atoi(argv[10]);
         if (argc > 11 && atoi(argv[11]) > 0) omp_set_num_threads(atoi(argv[11]));
-        const bool volpath = argc > 12 && atoi(argv[12]) == 1;
+        const int integ = argc > 12 ? atoi(argv[12]) : 0;   // 0 Path, 1 VolPath, 2 Whitted
+        const bool volpath = integ == 1;
         const gnxr_camera &c = rs.sf.cam;
         Transform lookat = LookAt(Point3f(c.eye[0], c.eye[1], c.eye[2]), Point3f(c.look[0], c.look[1], c.look[2]), Vector3f(c.up[0], c.up[1], c.up[2]));
         Transform c2w = Inverse(lookat), c2wEnd = c2w;
@@ -781,7 +836,8 @@ int main(int argc, char **argv) {
                     RayDifferential ray;
                     cam->GenerateRayDifferential(cs, &ray);
                     ray.ScaleDifferentials(1 / std::sqrt((Float)ps->samplesPerPixel));
-                    col += volpath ? refVolPathLi(ray, scene, *ps, arena, ld, maxDepth, rr) : refPathLi(ray, scene, *ps, arena, ld, maxDepth, rr);
+                    col += integ == 2 ? refWhittedLi(ray, scene, *ps, arena, maxDepth, 0)
+                                      : (volpath ? refVolPathLi(ray, scene, *ps, arena, ld, maxDepth, rr) : refPathLi(ray, scene, *ps, arena, ld, maxDepth, rr));
                 } while (ps->StartNextSample());
                 col = col / ps->samplesPerPixel;
                 size_t o = ((size_t)i + (size_t)j * W) * 4;

@@ -148,6 +148,25 @@ def test_volpath_images(name, gx):
     assert biteq(img, g[name])
 
 
+@pytest.mark.parametrize("name", ["cornell", "zoo", "cfg1"])
+def test_whitted_images(name, gx):
+    """WhittedIntegrator::Li + SpecularReflect / SpecularTransmit (cfg 1, SURVEY 8 row W): the restated recursion running on
+    the reference's own classes produced these images, ray counts and the full-size cfg 1 checksum."""
+    g = golden("render_whitted.npz")
+    if name == "cfg1":
+        img, st = ol.OracleScene(scenes.cornell()).render(gx.WhittedIntegrator(5), 256, 256, 16)
+        # BASELINE.md section 2: the complete reference traced 1 048 576 closest-hit / 2 028 213 any-hit rays for cfg 1
+        assert (st["rays_closest"], st["rays_any"]) == (1048576, 2028213) == tuple(int(v) for v in g["cfg1_rays"])
+        assert abs(float(img[..., :3].astype(np.float64).sum()) - float(g["cfg1_checksum"])) < 1e-6
+        assert biteq(img[::4, ::4, :3], g["cfg1_thumb"])
+        return
+    W, H, spp, depth = (int(v) for v in g[name + "_cfg"])
+    b = scenes.cornell() if name == "cornell" else scenes.material_zoo()
+    img, st = ol.OracleScene(b).render(gx.WhittedIntegrator(depth), W, H, spp)
+    assert (st["rays_closest"], st["rays_any"]) == tuple(int(v) for v in g[name + "_rays"])
+    assert biteq(img, g[name])
+
+
 def test_cfg2_reproduces_the_recorded_reference_run(gx):
     """the complete reference traced 16 058 662 closest-hit and 12 329 468 any-hit rays
     for cfg 2 and its image summed to 78538.576918.  This pins the restated Render / Li / EstimateDirect /
