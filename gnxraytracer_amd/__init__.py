@@ -156,6 +156,11 @@ class SceneBuilder:
             d = density.ctypes.data_as(C.POINTER(C.c_float))
         return _check(lib().gnxr_builder_add_medium(self._h, C.byref(medium), d))
 
+    def AddSphere(self, center, radius, material, medium_inside=-1, medium_outside=-1):
+        """pbrt-v3 quadratic sphere (the reference's shape/Sphere.h is an unfinished stub; see include/gnxr.h)."""
+        c = (C.c_float * 3)(*[float(v) for v in center])
+        return _check(lib().gnxr_builder_add_sphere(self._h, c, float(radius), int(material), int(medium_inside), int(medium_outside)))
+
     def set_camera(self, eye=(0, 0, 5), look=(0, 0, 0), up=(0, 1, 0), fov=90.0, lens_radius=0.0, focal_distance=3.0):
         cam = Camera(_f3(eye), _f3(look), _f3(up), fov, lens_radius, focal_distance)
         _check(lib().gnxr_builder_set_camera(self._h, C.byref(cam)))

@@ -5,7 +5,7 @@ include/gnxr.h field for field (tests/test_abi.py checks sizes and exported symb
 """
 import ctypes as C
 
-GNXR_ABI_VERSION = 1
+GNXR_ABI_VERSION = 2
 
 # gnxr_status
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_OOM, ERR_UNSUPPORTED, ERR_IO = 0, -1, -2, -3, -4, -5
@@ -50,6 +50,10 @@ class Medium(C.Structure):
                 ("g", f32), ("_pad", f32), ("medium_to_world", f32 * 16), ("density_offset", i64)]
 
 
+class Sphere(C.Structure):
+    _fields_ = [("center", f32 * 3), ("radius", f32), ("material", i32), ("medium_inside", i32), ("medium_outside", i32), ("_pad", i32)]
+
+
 class SceneDesc(C.Structure):
     _fields_ = [
         ("abi_version", i32), ("n_vertices", i32), ("n_triangles", i32), ("n_materials", i32), ("n_lights", i32),
@@ -58,7 +62,7 @@ class SceneDesc(C.Structure):
         ("tri_light", C.POINTER(i32)), ("tri_medium_inside", C.POINTER(i32)), ("tri_medium_outside", C.POINTER(i32)),
         ("materials", C.POINTER(Material)), ("lights", C.POINTER(Light)), ("media", C.POINTER(Medium)),
         ("grid_density", C.POINTER(f32)), ("env_rgb", C.POINTER(f32)),
-        ("camera", Camera), ("camera_medium", i32), ("_pad", i32),
+        ("camera", Camera), ("camera_medium", i32), ("n_spheres", i32), ("spheres", C.POINTER(Sphere)),
     ]
 
 
@@ -111,6 +115,7 @@ PROTOTYPES = {
     "gnxr_framebuffer_update": (C.c_int, [P(f32), P(f32), i32, i32, i32, P(u8)]),
     "gnxr_eval_libm": (C.c_int, [i32, P(f32), P(f32), i64, P(f32)]),
     "gnxr_builder_create": (C.c_int, [P(VP)]),
+    "gnxr_builder_add_sphere": (C.c_int, [VP, P(f32), f32, i32, i32, i32]),
     "gnxr_builder_destroy": (None, [VP]),
     "gnxr_builder_add_material": (C.c_int, [VP, P(Material)]),
     "gnxr_builder_matte": (C.c_int, [VP, P(f32), f32]),
@@ -133,7 +138,7 @@ PROTOTYPES = {
 }
 
 
-ABI_STRUCTS = [Material, Light, Camera, Medium, SceneDesc, RenderParams, Stats, Ray, Hit]
+ABI_STRUCTS = [Material, Light, Camera, Medium, SceneDesc, RenderParams, Stats, Ray, Hit, Sphere]
 
 
 def bind(lib):

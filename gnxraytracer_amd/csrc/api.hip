@@ -110,6 +110,7 @@ struct gnxr_scene {
     DevBuf<DNode> nodes;
     DevBuf<DNode4> nodes4;
     DevBuf<DTri> tris;
+    DevBuf<DSphere> spheres;
     DevBuf<DMaterial> materials;
     DevBuf<DLight> lights;
     DevBuf<int32_t> infinite;
@@ -146,6 +147,8 @@ struct gnxr_scene {
         d.nodes4 = reinterpret_cast<const float4 *>(nodes4.p);
         d.root4 = cs.root4;
         d.tris = tris.p;
+        d.spheres = spheres.p;
+        d.n_spheres = cs.n_spheres;
         d.materials = materials.p;
         d.lt.lights = lights.p;
         d.lt.n_lights = (int)cs.desc_lights.size();
@@ -216,7 +219,7 @@ int gnxr_scene_create(const gnxr_scene_desc *desc, gnxr_scene **out) {
     for (const DNode &n : cs.nodes) if ((n.meta & 0xffffu) > 127) s->wide_ok = false;
 #define UP(field) if ((rc = s->field.upload(cs.field)) != GNXR_OK) { delete s; return rc; }
     UP(nodes) UP(nodes4) UP(tris) UP(materials) UP(lights) UP(perms) UP(primes) UP(prime_sums) UP(prime_magic)
-    UP(dmedia) UP(grid_density) UP(tri_media)
+    UP(dmedia) UP(grid_density) UP(tri_media) UP(spheres)
     UP(env_texels) UP(env_cond_func) UP(env_cond_cdf) UP(env_cond_int) UP(env_marg_func) UP(env_marg_cdf)
 #undef UP
     if ((rc = s->infinite.upload(cs.infinite_lights)) != GNXR_OK) { delete s; return rc; }
@@ -313,7 +316,7 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     HIP_TRY(hipEventRecord(ev0, stream));
     unsigned long long rays_closest = 0, rays_any = 0, rays_mis = 0;
     unsigned int launches = 0, passes = 0;
-    const bool timing = (g_profiling & 1) != 0, counting = (g_profiling & 2) != 0;
+    const bool timing = (g_profiling & 1) != 0, counting = (g_profiling & 2) != 0, spheres = s->cs.n_spheres > 0;
     int class_mask = 0;
     for (const DMaterial &m : s->cs.materials) class_mask |= 1 << m.shade_class;
     bool area_only = true;
@@ -345,9 +348,13 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
             int blocks = (int)std::min<long long>((long long)g_num_cus * per_cu, (total + kBlock - 1) / kBlock);
             if (s->trace_spill.alloc((size_t)g_num_cus * per_cu * kBlock * (size_t)std::max(1, entries - lds_entries)) != GNXR_OK) return;
             if (timing) timer.begin(0, stream);
-            if (counting) hipLaunchKernelGGL((k_trace<true, false>), dim3(blocks), dim3(kBlock), lds, stream, sc, pa, w, &dctr->cursor, dctr, lds_entries, s->trace_spill.p);
-            else if (wide) hipLaunchKernelGGL((k_trace<false, true>), dim3(blocks), dim3(kBlock), lds, stream, sc, pa, w, &dctr->cursor, dctr, lds_entries, s->trace_spill.p);
-            else hipLaunchKernelGGL((k_trace<false, false>), dim3(blocks), dim3(kBlock), lds, stream, sc, pa, w, &dctr->cursor, dctr, lds_entries, s->trace_spill.p);
+#define GX_TRACE(C, W, S) hipLaunchKernelGGL((k_trace<C, W, S>), dim3(blocks), dim3(kBlock), lds, stream, sc, pa, w, &dctr->cursor, dctr, lds_entries, s->trace_spill.p)
+            if (spheres) {
+                if (counting) GX_TRACE(true, false, true); else if (wide) GX_TRACE(false, true, true); else GX_TRACE(false, false, true);
+            } else {
+                if (counting) GX_TRACE(true, false, false); else if (wide) GX_TRACE(false, true, false); else GX_TRACE(false, false, false);
+            }
+#undef GX_TRACE
             if (timing) timer.end(stream);
             rays_closest += (unsigned long long)w.n_closest + (unsigned long long)n_mis;
             rays_any += (unsigned long long)n_sh;
@@ -404,7 +411,11 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
             {
                 int *qc[3] = {s->queue_c0.p, s->queue_c1.p, s->queue_c2.p};
                 dim3 g(grid_for(n)), b(kBlock);
-#define GX_SHADE(LMV, LTV, C) hipLaunchKernelGGL((k_shade<LMV, LTV>), g, b, 0, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C])
+#define GX_SHADE(LMV, LTV, C)                                                                                                                        \
+    do {                                                                                                                                             \
+        if (spheres) hipLaunchKernelGGL((k_shade<LMV, LTV, true>), g, b, 0, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C]); \
+        else hipLaunchKernelGGL((k_shade<LMV, LTV, false>), g, b, 0, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C]);       \
+    } while (0)
                 if (area_only) {
                     GX_SHADE(LM_DIFFUSE, LT_AREA, 0);
                     if (class_mask & 2) GX_SHADE(LM_GLOSSY, LT_AREA, 1);

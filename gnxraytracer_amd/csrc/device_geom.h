@@ -217,6 +217,67 @@ GX_DEV SurfacePoint surface_point(V3 p0, V3 p1, V3 p2, const TriHit &h, bool has
     return s;
 }
 
+// ---- pbrt-v3 quadratic sphere (include/gnxr.h: the reference's Sphere is an unfinished stub; parity unpinned) ----
+// Same operations as oracle/o_scene.h SphereIntersect: quadratic in double, nearest root in (0, tMax].
+GX_DEV bool sphere_test(const DSphere &sp, V3 ro, V3 rd, float tMax, float *tHit) {
+    V3 o = ro - V3(sp.c[0], sp.c[1], sp.c[2]);
+    double ox = o.x, oy = o.y, oz = o.z, dx = rd.x, dy = rd.y, dz = rd.z;
+    double a = dx * dx + dy * dy + dz * dz;
+    double b = 2 * (dx * ox + dy * oy + dz * oz);
+    double cc = ox * ox + oy * oy + oz * oz - (double)sp.r * (double)sp.r;
+    double discrim = b * b - 4 * a * cc;
+    if (discrim < 0) return false;
+    double rootDiscrim = __builtin_sqrt(discrim);
+    double q = (b < 0) ? -.5 * (b - rootDiscrim) : -.5 * (b + rootDiscrim);
+    double t0 = q / a, t1 = cc / q;
+    if (t0 > t1) { double tmp = t0; t0 = t1; t1 = tmp; }
+    if (!(t0 <= (double)tMax) || !(t1 > 0)) return false;
+    double tShapeHit = t0;
+    if (tShapeHit <= 0) {
+        tShapeHit = t1;
+        if (tShapeHit > (double)tMax) return false;
+    }
+    *tHit = (float)tShapeHit;
+    return true;
+}
+// hit point, error bound, normal and BSDF frame of a sphere hit at tHit (+ Material::Bump with the constant-0 map)
+GX_DEV SurfacePoint sphere_surface_point(const DSphere &sp, V3 ro, V3 rd, float tHit, bool has_bump) {
+    SurfacePoint s;
+    s.valid = true;
+    const float radius = sp.r;
+    V3 c(sp.c[0], sp.c[1], sp.c[2]);
+    V3 o = ro - c;
+    V3 pHit = o + rd * tHit;
+    pHit = pHit * (radius / length(pHit));
+    if (pHit.x == 0 && pHit.y == 0) pHit.x = 1e-5f * radius;
+    const float phiMax = 2 * GX_PI, thetaMin = GX_PI, thetaMax = 0;
+    float theta = gx_acos(clampf(pHit.z / radius, -1, 1));
+    float zRadius = gx_sqrt(pHit.x * pHit.x + pHit.y * pHit.y);
+    float invZRadius = 1 / zRadius;
+    float cosPhi = pHit.x * invZRadius, sinPhi = pHit.y * invZRadius;
+    V3 dpdu(-phiMax * pHit.y, phiMax * pHit.x, 0);
+    V3 dpdv = (thetaMax - thetaMin) * V3(pHit.z * cosPhi, pHit.z * sinPhi, -radius * gx_sin(theta));
+    V3 pError = GX_GAMMA(5) * vabs(pHit);
+    s.p = pHit + c;
+    s.pError = V3((GX_GAMMA(3) + 1) * pError.x + GX_GAMMA(3) * (fabsf(pHit.x) + fabsf(c.x)),
+                  (GX_GAMMA(3) + 1) * pError.y + GX_GAMMA(3) * (fabsf(pHit.y) + fabsf(c.y)),
+                  (GX_GAMMA(3) + 1) * pError.z + GX_GAMMA(3) * (fabsf(pHit.z) + fabsf(c.z)));
+    s.n = normalize(normalize(cross(dpdu, dpdv)));
+    V3 sn = s.n, sdpdu = dpdu, sdpdv = dpdv;
+    if (has_bump) {   // Material::Bump, core/Material.cpp:16-52, displacement 0 (see surface_point)
+        const float du = .0005f;
+        V3 zero(0, 0, 0);
+        sdpdu = dpdu + (0.f - 0.f) / du * sn + 0.f * zero;
+        sdpdv = dpdv + (0.f - 0.f) / du * sn + 0.f * zero;
+        sn = normalize(cross(sdpdu, sdpdv));
+        sn = faceforward(sn, s.n);
+    }
+    s.ns = sn;
+    s.ss = normalize(sdpdu);
+    s.ts = cross(s.ns, s.ss);
+    return s;
+}
+
 // Interaction::SpawnRay / SpawnRayTo, Interaction.h:33-53
 GX_DEV void spawn_ray(V3 p, V3 pError, V3 n, V3 d, V3 *o) { *o = offset_ray_origin(p, pError, n, d); }
 GX_DEV void spawn_ray_to(V3 p, V3 pError, V3 n, V3 p2, V3 p2Error, V3 n2, V3 *o, V3 *d) {

@@ -41,6 +41,14 @@ struct DTri {
 };
 static_assert(sizeof(DTri) == 48, "DTri must be 48 bytes");
 
+// Sphere (pbrt-v3 quadratic sphere; include/gnxr.h explains why): kept outside the triangle BVH, tested first.
+// A sphere hit is reported as hit code -2 - sphereIndex (triangles: leaf index >= 0, miss: -1).
+struct DSphere {
+    float c[3]; float r;
+    int32_t material, med_in, med_out, prim;
+};
+static_assert(sizeof(DSphere) == 32, "DSphere must be 32 bytes");
+
 // ---- BSDF lobes, precomputed per material on the host (all textures are constants) ----
 enum LobeKind : int32_t {
     LOBE_LAMBERT = 0, LOBE_OREN, LOBE_SPEC_REFL, LOBE_SPEC_TRANS, LOBE_FRESNEL_SPEC, LOBE_MICRO_REFL, LOBE_MICRO_TRANS,

@@ -20,6 +20,7 @@ struct Builder {
     std::vector<gnxr_material> materials;
     std::vector<gnxr_light> lights;
     std::vector<gnxr_medium> media;
+    std::vector<gnxr_sphere> spheres;
     std::vector<float> grid_density;
     std::vector<float> env_rgb;
     int env_w = 0, env_h = 0;
@@ -63,6 +64,8 @@ struct CompiledScene {
     std::vector<gnxr_medium> media;
     std::vector<DMedium> dmedia;
     std::vector<float> grid_density;
+    std::vector<DSphere> spheres;
+    int n_spheres = 0;
     std::vector<int32_t> tri_media;      // leaf order, (inside, outside) per triangle; empty when no triangle is a medium boundary
     // camera description (matrices depend on the render resolution)
     gnxr_camera camera;

@@ -53,6 +53,8 @@ struct DScene {
     const float4 *nodes4;   // DNode4[] as 8 float4 each
     int root4;
     const DTri *tris;
+    const DSphere *spheres;   // tested before the BVH; hit code -2 - index
+    int n_spheres;
     const DMaterial *materials;
     DLightTables lt;
     DSamplerTables st;
@@ -151,7 +153,7 @@ __global__ void __launch_bounds__(kBlock) k_raygen(DScene sc, DRender r, PathArr
 #else
 #define GX_SHADE_ATTR
 #endif
-template <uint32_t LM, int LT>
+template <uint32_t LM, int LT, bool SPH>
 __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRender r, PathArrays pa, const int *__restrict__ queue, const unsigned int *n_dev) {
     const int n = (int)*n_dev;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -168,13 +170,19 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
             Spec beta(b4.x, b4.y, b4.z), L(L4.x, L4.y, L4.z);
             float etaScale = b4.w;
             int leaf = pa.hit[path];
-            bool found = leaf >= 0;
+            bool found = leaf != -1;
             V3 p0, p1, p2;
             int triMat = -1, triLight = -1;
             TriHit h;
             SurfacePoint sp;
             sp.valid = false;
-            if (found) {
+            if (SPH && leaf < -1) {   // sphere
+                const DSphere &sph = sc.spheres[-2 - leaf];
+                triMat = sph.material;
+                float tH;
+                found = sphere_test(sph, ro, rd, o4.w, &tH);
+                if (found) sp = sphere_surface_point(sph, ro, rd, tH, triMat >= 0 ? sc.materials[triMat].has_bump != 0 : false);
+            } else if (found) {
                 const float4 *q = reinterpret_cast<const float4 *>(sc.tris + leaf);
                 float4 a = q[0], b = q[1], c = q[2];
                 p0 = V3(a.x, a.y, a.z); p1 = V3(b.x, b.y, b.z); p2 = V3(c.x, c.y, c.z);
@@ -351,9 +359,17 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest_api(DScene sc, const g
         gnxr_ray r = rays[i];
         V3 ro(r.o[0], r.o[1], r.o[2]), rd(r.d[0], r.d[1], r.d[2]);
         TriHit h;
-        int leaf = bvh_traverse<false, kBlock, false>(sc.nodes, sc.tris, ro, rd, r.tmax, &stack[threadIdx.x], &h, &tc);
+        float tMax = r.tmax;
+        int sphereHit = -1;
+        for (int si = 0; si < sc.n_spheres; ++si) { float tH; if (sphere_test(sc.spheres[si], ro, rd, tMax, &tH)) { tMax = tH; sphereHit = si; } }
+        int leaf = bvh_traverse<false, kBlock, false>(sc.nodes, sc.tris, ro, rd, tMax, &stack[threadIdx.x], &h, &tc);
         gnxr_hit out;
         out.prim = -1; out.t = 0; out.b0 = out.b1 = out.b2 = 0; out.n[0] = out.n[1] = out.n[2] = 0;
+        if (leaf < 0 && sphereHit >= 0) {
+            SurfacePoint sp = sphere_surface_point(sc.spheres[sphereHit], ro, rd, tMax, false);
+            out.prim = sc.spheres[sphereHit].prim; out.t = tMax;
+            out.n[0] = sp.n.x; out.n[1] = sp.n.y; out.n[2] = sp.n.z;
+        }
         if (leaf >= 0) {
             V3 p0, p1, p2;
             load_tri(sc.tris, leaf, &p0, &p1, &p2);
@@ -371,7 +387,10 @@ __global__ void __launch_bounds__(kBlock) k_trace_any_api(DScene sc, const gnxr_
     for (long long i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         gnxr_ray r = rays[i];
         TriHit h;
-        int leaf = bvh_traverse<true, kBlock, false>(sc.nodes, sc.tris, V3(r.o[0], r.o[1], r.o[2]), V3(r.d[0], r.d[1], r.d[2]), r.tmax, &stack[threadIdx.x], &h, &tc);
+        V3 ro(r.o[0], r.o[1], r.o[2]), rd(r.d[0], r.d[1], r.d[2]);
+        bool hitSphere = false;
+        for (int si = 0; si < sc.n_spheres && !hitSphere; ++si) { float tH; hitSphere = sphere_test(sc.spheres[si], ro, rd, r.tmax, &tH); }
+        int leaf = hitSphere ? 0 : bvh_traverse<true, kBlock, false>(sc.nodes, sc.tris, ro, rd, r.tmax, &stack[threadIdx.x], &h, &tc);
         occluded[i] = leaf >= 0 ? 1 : 0;
     }
 }

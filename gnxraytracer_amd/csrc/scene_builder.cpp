@@ -170,6 +170,8 @@ void Builder::fill_desc(gnxr_scene_desc *d) const {
     d->env_rgb = env_rgb.empty() ? nullptr : env_rgb.data();
     d->camera = camera;
     d->camera_medium = camera_medium;
+    d->n_spheres = (int)spheres.size();
+    d->spheres = spheres.empty() ? nullptr : spheres.data();
 }
 
 // ---- `.3d` text meshes: shape/plyRead.h:19-48 ----
@@ -535,6 +537,16 @@ int gnxr_builder_add_medium(gnxr_builder *b, const gnxr_medium *m, const float *
     return (int)b->b.media.size() - 1;
 }
 
+int gnxr_builder_add_sphere(gnxr_builder *b, const float center[3], float radius, int32_t material, int32_t medium_inside, int32_t medium_outside) {
+    if (!b || !center || !(radius > 0)) return GNXR_ERR_INVALID;
+    gnxr_sphere s;
+    memset(&s, 0, sizeof(s));
+    memcpy(s.center, center, 12);
+    s.radius = radius; s.material = material; s.medium_inside = medium_inside; s.medium_outside = medium_outside;
+    b->b.spheres.push_back(s);
+    return (int)b->b.spheres.size() - 1;
+}
+
 int gnxr_builder_set_camera(gnxr_builder *b, const gnxr_camera *cam) {
     if (!b || !cam) return GNXR_ERR_INVALID;
     b->b.camera = *cam;
@@ -565,6 +577,7 @@ int gnxr_abi_sizeof(int which) {
     case 6: return (int)sizeof(gnxr_stats);
     case 7: return (int)sizeof(gnxr_ray);
     case 8: return (int)sizeof(gnxr_hit);
+    case 9: return (int)sizeof(gnxr_sphere);
     default: return -1;
     }
 }

@@ -633,6 +633,26 @@ bool compile_scene(const gnxr_scene_desc *d, CompiledScene *cs) {
     if (cs->nodes4.empty()) cs->nodes4.push_back(DNode4());
     cs->world_bound.lo = Vec3(cs->nodes[0].lo[0], cs->nodes[0].lo[1], cs->nodes[0].lo[2]);
     cs->world_bound.hi = Vec3(cs->nodes[0].hi0, cs->nodes[0].hi1, cs->nodes[0].hi2);
+    // ---- spheres (outside the BVH)
+    cs->spheres.assign(std::max(1, d->n_spheres), DSphere());
+    for (int i = 0; i < d->n_spheres; ++i) {
+        const gnxr_sphere &sp = d->spheres[i];
+        DSphere &ds = cs->spheres[i];
+        if (!(sp.radius > 0) || sp.material >= d->n_materials || sp.medium_inside >= d->n_media || sp.medium_outside >= d->n_media) {
+            set_error("sphere %d: bad radius / material / medium", i);
+            return false;
+        }
+        memcpy(ds.c, sp.center, 12);
+        ds.r = sp.radius;
+        ds.material = (sp.material >= 0 && d->materials[sp.material].type == GNXR_MAT_NONE) ? -1 : sp.material;
+        ds.med_in = sp.medium_inside; ds.med_out = sp.medium_outside;
+        ds.prim = d->n_triangles + i;
+        Box3 b;   // Scene::WorldBound covers every primitive (the light-selection grid is laid over it)
+        b.grow(Vec3(sp.center[0] - sp.radius, sp.center[1] - sp.radius, sp.center[2] - sp.radius));
+        b.grow(Vec3(sp.center[0] + sp.radius, sp.center[1] + sp.radius, sp.center[2] + sp.radius));
+        cs->world_bound.grow(b);
+    }
+    cs->n_spheres = d->n_spheres;
     // ---- triangles in leaf order
     cs->tris.resize(d->n_triangles);
     cs->leaf_of_prim.assign(d->n_triangles, -1);

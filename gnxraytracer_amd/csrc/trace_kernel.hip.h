@@ -134,7 +134,8 @@ __device__ unsigned long long g_trace_stats[16];
 
 // COUNT: count nodes / triangles (profiling).  WIDE: traverse the collapsed 4-wide tree (sc.nodes4) instead of the
 // reference's binary nodes; the counting runs use WIDE = false so that the counts are those of the reference traversal.
-template <bool COUNT, bool WIDE>
+// SPH: the scene has spheres (a separate instantiation keeps their registers out of the triangle-only kernel).
+template <bool COUNT, bool WIDE, bool SPH>
 __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, TraceWork w, unsigned int *cursor, Counters *ctr, int lds_entries, int *spill) {
     extern __shared__ int stack_mem[];   // lds_entries * kBlock ints
     LaneStack stack;
@@ -212,6 +213,15 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
                         neg0 = invDir.x < 0; neg1 = invDir.y < 0; neg2 = invDir.z < 0;
                         if (WIDE) oct = ray_octant(neg0, neg1, neg2);
                         cur = WIDE ? sc.root4 : 0; toVisit = 0; leafN = 0; hitLeaf = -1;
+                        // spheres live outside the BVH and are tested first (Scene::Intersect of this build, oracle/o_scene.h)
+                        for (int si = 0; SPH && si < sc.n_spheres; ++si) {
+                            float tH;
+                            if (sphere_test(sc.spheres[si], ro, rd, tMax, &tH)) {
+                                hitLeaf = -2 - si;
+                                if (kind == 1) { cur = -1; break; }
+                                tMax = tH;
+                            }
+                        }
                     }
                 }
                 poolBase += take; poolCount -= take;
@@ -288,7 +298,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
 #endif
         if (item >= 0 && leafN > 0) {
             bool visit = true;
-            if (WIDE && hitLeaf >= 0) {   // tMax only ever shrinks after a hit: before the first hit the earlier test stands
+            if (WIDE && (SPH ? hitLeaf != -1 : hitLeaf >= 0)) {   // tMax only ever shrinks after a hit: before the first hit the earlier test stands
                 // BVHAccel::Intersect tests a leaf's box when it pops it, i.e. against the CURRENT ray.tMax; the 4-wide
                 // step tested it earlier with an older tMax.  Re-test here so that exact ties (t == tMax on flat,
                 // axis-aligned boxes such as the Cornell walls) resolve as in the reference.  The leaf box is the
@@ -321,12 +331,15 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
             if (kind == 0) {
                 pa.hit[path] = hitLeaf;
                 int cls = 0;   // misses and null materials only need the emission / pass-through code of class 0
-                if (hitLeaf >= 0) { int mat = tris[hitLeaf].material; if (mat >= 0) cls = sc.materials[mat].shade_class; }
+                if (SPH ? hitLeaf != -1 : hitLeaf >= 0) {
+                    int mat = (!SPH || hitLeaf >= 0) ? tris[hitLeaf].material : sc.spheres[-2 - hitLeaf].material;
+                    if (mat >= 0) cls = sc.materials[mat].shade_class;
+                }
                 pa.pclass[path] = (unsigned char)cls;
             }
-            else if (kind == 1) reinterpret_cast<float *>(&pa.sh_o[path])[3] = hitLeaf < 0 ? 1.f : 0.f;
+            else if (kind == 1) reinterpret_cast<float *>(&pa.sh_o[path])[3] = hitLeaf == -1 ? 1.f : 0.f;
             else {
-                bool ok = (expect >= 0) ? (hitLeaf == expect) : (hitLeaf < 0);
+                bool ok = (expect >= 0) ? (hitLeaf == expect) : (hitLeaf == -1);
                 reinterpret_cast<float *>(&pa.mis_o[path])[3] = ok ? 1.f : 0.f;
             }
             item = -1;

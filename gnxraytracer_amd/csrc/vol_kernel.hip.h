@@ -57,12 +57,19 @@ __global__ void __launch_bounds__(kBlock) k_vol_init(PathArrays pa, VolArrays va
 
 // Interaction::GetMedium(w) for a surface hit: GeometricPrimitive::Intersect (core/Primitive.cpp:32-46) keeps the
 // primitive's MediumInterface when it is a transition and the ray's medium otherwise.
-GX_DEV int hit_medium(const DMediaTables &mt, int leaf, int rayMedium, V3 n, V3 w) {
-    int mi = rayMedium, mo = rayMedium;
-    if (mt.tri_media) {
+GX_DEV void hit_interface(const DScene &sc, const DMediaTables &mt, int leaf, int rayMedium, int *mi, int *mo) {
+    *mi = rayMedium; *mo = rayMedium;
+    if (leaf < -1) {   // sphere
+        const DSphere &sph = sc.spheres[-2 - leaf];
+        if (sph.med_in != sph.med_out) { *mi = sph.med_in; *mo = sph.med_out; }
+    } else if (mt.tri_media) {
         int2 tm = mt.tri_media[leaf];
-        if (tm.x != tm.y) { mi = tm.x; mo = tm.y; }
+        if (tm.x != tm.y) { *mi = tm.x; *mo = tm.y; }
     }
+}
+GX_DEV int hit_medium(const DScene &sc, const DMediaTables &mt, int leaf, int rayMedium, V3 n, V3 w) {
+    int mi, mo;
+    hit_interface(sc, mt, leaf, rayMedium, &mi, &mo);
     return dot(w, n) > 0 ? mo : mi;
 }
 
@@ -106,10 +113,14 @@ __global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt
                     V3 ro(o4.x, o4.y, o4.z), rd(d4.x, d4.y, d4.z);
                     const int med = __float_as_int(d4.w);
                     const int leaf = pa.hit[p];
-                    bool found = leaf >= 0;
+                    bool found = leaf != -1;
                     int triMat = -1;
                     TriHit h;
-                    if (found) {
+                    if (leaf < -1) {
+                        const DSphere &sph = sc.spheres[-2 - leaf];
+                        triMat = sph.material;
+                        found = sphere_test(sph, ro, rd, o4.w, &h.t);
+                    } else if (found) {
                         const float4 *q = reinterpret_cast<const float4 *>(sc.tris + leaf);
                         float4 a = q[0], b = q[1], c = q[2];
                         triMat = __float_as_int(b.w);
@@ -230,17 +241,23 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
         float etaScale = 1;
 
         // the traced ray's hit, shared by all three states
-        bool found = leaf >= 0;
+        bool found = leaf != -1;
         V3 p0, p1, p2;
         int triMat = -1, triLight = -1;
         TriHit h;
-        if (found) {
+        if (leaf < -1) {   // sphere
+            const DSphere &sph = sc.spheres[-2 - leaf];
+            triMat = sph.material;
+            found = sphere_test(sph, ro, rd, o4.w, &h.t);
+        } else if (found) {
             const float4 *q = reinterpret_cast<const float4 *>(sc.tris + leaf);
             float4 a = q[0], b = q[1], c = q[2];
             p0 = V3(a.x, a.y, a.z); p1 = V3(b.x, b.y, b.z); p2 = V3(c.x, c.y, c.z);
             triMat = __float_as_int(b.w); triLight = __float_as_int(c.w);
             found = tri_test(p0, p1, p2, ro, rd, o4.w, &h);   // same arithmetic as the traversal
         }
+        // hit point / error bound / normal of the traced ray's hit (no Bump: only p, pError, n are used)
+        auto hit_geometry = [&]() { return leaf < -1 ? sphere_surface_point(sc.spheres[-2 - leaf], ro, rd, h.t, false) : surface_point(p0, p1, p2, h, false); };
 
         if (vs.x != VS_MAIN) {
             // ---------------- phase 1: one segment of the light-sample ray or of the scattering ray ----------------
@@ -249,7 +266,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
             const int nflags = __float_as_int(f4.w);
             SurfacePoint sp;
             sp.valid = false;
-            if (found) { sp = surface_point(p0, p1, p2, h, false); found = sp.valid; }
+            if (found) { sp = hit_geometry(); found = sp.valid; }
             bool segDone = false;
             int segMedium = -1;        // medium of the next segment's ray
             if (vs.x == VS_SHADOW) {   // VisibilityTester::Tr, Light.cpp:33-53
@@ -266,7 +283,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
                         float4 q1 = va.p1[path], q1e = va.p1e[path], qn1 = va.n1[path];
                         V3 so, sd;
                         spawn_ray_to(sp.p, sp.pError, sp.n, V3(q1.x, q1.y, q1.z), V3(q1e.x, q1e.y, q1e.z), V3(qn1.x, qn1.y, qn1.z), &so, &sd);
-                        segMedium = hit_medium(mt, leaf, rayMedium, sp.n, sd);
+                        segMedium = hit_medium(sc, mt, leaf, rayMedium, sp.n, sd);
                         pa.ray_o[path] = make_float4(so.x, so.y, so.z, 1 - GX_SHADOW_EPS);
                         pa.ray_d[path] = make_float4(sd.x, sd.y, sd.z, __int_as_float(segMedium));
                     }
@@ -284,7 +301,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
                 if (rayMedium >= 0) { float4 w = va.mres[path]; Tr = Tr * Spec(w.x, w.y, w.z); }
                 if (found && triMat < 0) {   // ray = isect->SpawnRay(ray.d)
                     V3 o2 = offset_ray_origin(sp.p, sp.pError, sp.n, rd);
-                    segMedium = hit_medium(mt, leaf, rayMedium, sp.n, rd);
+                    segMedium = hit_medium(sc, mt, leaf, rayMedium, sp.n, rd);
                     pa.ray_o[path] = make_float4(o2.x, o2.y, o2.z, GX_INF);
                     pa.ray_d[path] = make_float4(rd.x, rd.y, rd.z, __int_as_float(segMedium));
                 } else {
@@ -322,7 +339,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
             L = Spec(L4.x, L4.y, L4.z);
             SurfacePoint sp0;
             sp0.valid = false;
-            if (found) { sp0 = surface_point(p0, p1, p2, h, false); found = sp0.valid; }
+            if (found) { sp0 = hit_geometry(); found = sp0.valid; }
             bool miValid = false;
             if (rayMedium >= 0) {   // beta *= ray.medium->Sample(ray, sampler, arena, &mi), evaluated by k_vol_media
                 float4 w = va.mres[path];
@@ -347,7 +364,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
                 else if (triMat < 0) {
                     // no BSDF: ray = isect.SpawnRay(ray.d); bounces--; continue  (VolPathIntegrator.cpp:88-92)
                     V3 o2 = offset_ray_origin(sp0.p, sp0.pError, sp0.n, rd);
-                    const int nm = hit_medium(mt, leaf, rayMedium, sp0.n, rd);
+                    const int nm = hit_medium(sc, mt, leaf, rayMedium, sp0.n, rd);
                     pa.ray_o[path] = make_float4(o2.x, o2.y, o2.z, GX_INF);
                     pa.ray_d[path] = make_float4(rd.x, rd.y, rd.z, __int_as_float(nm));
                     pa.beta[path] = make_float4(beta.r, beta.g, beta.b, etaScale);
@@ -379,19 +396,24 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
             itP = ro + rd * miT;    // mi.p = ray(t)
             g = mt.media[rayMedium].g;
         } else {
-            const float4 *q = reinterpret_cast<const float4 *>(sc.tris + vleaf);
-            float4 a = q[0], b = q[1], c = q[2];
-            p0 = V3(a.x, a.y, a.z); p1 = V3(b.x, b.y, b.z); p2 = V3(c.x, c.y, c.z);
-            triMat = __float_as_int(b.w);
-            (void)tri_test(p0, p1, p2, ro, rd, o4.w, &h);
-            mat = sc.materials + triMat;
-            sp = surface_point(p0, p1, p2, h, mat->has_bump != 0);
+            if (vleaf < -1) {
+                const DSphere &sph = sc.spheres[-2 - vleaf];
+                triMat = sph.material;
+                (void)sphere_test(sph, ro, rd, o4.w, &h.t);
+                mat = sc.materials + triMat;
+                sp = sphere_surface_point(sph, ro, rd, h.t, mat->has_bump != 0);
+            } else {
+                const float4 *q = reinterpret_cast<const float4 *>(sc.tris + vleaf);
+                float4 a = q[0], b = q[1], c = q[2];
+                p0 = V3(a.x, a.y, a.z); p1 = V3(b.x, b.y, b.z); p2 = V3(c.x, c.y, c.z);
+                triMat = __float_as_int(b.w);
+                (void)tri_test(p0, p1, p2, ro, rd, o4.w, &h);
+                mat = sc.materials + triMat;
+                sp = surface_point(p0, p1, p2, h, mat->has_bump != 0);
+            }
             bsdf.mat = mat; bsdf.ns = sp.ns; bsdf.ng = sp.n; bsdf.ss = sp.ss; bsdf.ts = sp.ts;
             itP = sp.p; itPError = sp.pError; itN = sp.n;
-            if (mt.tri_media) {
-                int2 tm = mt.tri_media[vleaf];
-                if (tm.x != tm.y) { medIn = tm.x; medOut = tm.y; }
-            }
+            hit_interface(sc, mt, vleaf, rayMedium, &medIn, &medOut);
         }
         const V3 woN = normalize(-rd);   // SurfaceInteraction::wo
         const V3 woM = -rd;              // MediumInteraction::wo

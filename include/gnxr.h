@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GNXR_ABI_VERSION 1
+#define GNXR_ABI_VERSION 2
 
 typedef enum gnxr_status {
     GNXR_OK = 0,
@@ -135,6 +135,19 @@ typedef struct gnxr_medium {
     int64_t density_offset;    /* GRID: first float of this grid in desc.grid_density      */
 } gnxr_medium;
 
+/* ---- sphere: shape/Sphere.{h,cpp} is an unfinished stub in the reference (Intersect returns `discriminant > 0` and
+ * fills neither tHit nor the interaction), so the quadratic sphere of pbrt-v3 -- whose file it was started from -- is
+ * built instead: full sphere, ObjectToWorld = Translate(center).  Parity with the reference is UNPINNED (nothing to
+ * pin against); the device is pinned against the CPU restatement and against analytic hits. ------------------------- */
+typedef struct gnxr_sphere {
+    float center[3];
+    float radius;
+    int32_t material;       /* index into materials, -1 == null material          */
+    int32_t medium_inside;  /* MediumInterface, -1 == none                        */
+    int32_t medium_outside;
+    int32_t _pad;
+} gnxr_sphere;
+
 /* ---- scene description: what ModelList.cpp / RenderThread.cpp author --------------- */
 typedef struct gnxr_scene_desc {
     int32_t abi_version;        /* GNXR_ABI_VERSION */
@@ -158,7 +171,8 @@ typedef struct gnxr_scene_desc {
     const float *env_rgb;       /* env_width*env_height*3, row-major, as decoded from .hdr   */
     gnxr_camera camera;
     int32_t camera_medium;      /* medium the camera sits in, -1 == none                     */
-    int32_t _pad;
+    int32_t n_spheres;
+    const gnxr_sphere *spheres; /* tested before the triangle BVH; gnxr_hit.prim = n_triangles + sphere index */
 } gnxr_scene_desc;
 
 typedef enum gnxr_integrator {
@@ -298,6 +312,8 @@ int gnxr_builder_add_inf_light(gnxr_builder *b, const char *hdr_path);          
 int gnxr_builder_add_inf_light_data(gnxr_builder *b, const float *rgb, int32_t w, int32_t h,
                                     const float *light_to_world16, const float power[3]);
 int gnxr_builder_add_medium(gnxr_builder *b, const gnxr_medium *m, const float *density);
+int gnxr_builder_add_sphere(gnxr_builder *b, const float center[3], float radius, int32_t material, int32_t medium_inside,
+                            int32_t medium_outside);                                      /* returns the sphere index */
 int gnxr_builder_set_camera(gnxr_builder *b, const gnxr_camera *cam);                 /* RenderThread.cpp:60-68 */
 /* The returned description points into builder-owned memory, valid until the next builder
  * call or gnxr_builder_destroy.                                                            */

@@ -83,6 +83,7 @@ struct Scene {
     int envW = 0, envH = 0;
     gnxr_camera camera;
     int cameraMedium = -1;
+    std::vector<gnxr_sphere> spheres;   // prim index = nTriangles() + sphere index; tested before the triangle BVH
     // BVH
     std::vector<LinearBVHNode> nodes;
     std::vector<int> orderedPrims;  // BVH leaf order -> authoring index (primitives.swap(orderedPrims), BVHAccel.cpp:171)
@@ -98,7 +99,7 @@ struct Scene {
         V3 p0, p1, p2; Tri(i, &p0, &p1, &p2);
         return Union(Bounds3(p0, p1), p2);
     }
-    Bounds3 WorldBound() const { return nodes.empty() ? Bounds3() : nodes[0].bounds; }
+    Bounds3 WorldBound() const { return nodes.empty() ? sphereOnlyBound : nodes[0].bounds; }
 
     void Load(const gnxr_scene_desc *d) {
         verts.resize(d->n_vertices);
@@ -122,8 +123,22 @@ struct Scene {
         if (envW && envH) envRgb.assign(d->env_rgb, d->env_rgb + (size_t)envW * envH * 3);
         camera = d->camera;
         cameraMedium = d->camera_medium;
+        if (d->n_spheres > 0) {
+            spheres.assign(d->spheres, d->spheres + d->n_spheres);
+            for (const gnxr_sphere &sp : spheres) {   // per-primitive tables continue past the triangles
+                triMaterial.push_back(sp.material); triLight.push_back(-1);
+                triMedIn.push_back(sp.medium_inside); triMedOut.push_back(sp.medium_outside);
+            }
+        }
         BuildBVH();
+        for (const gnxr_sphere &sp : spheres) {       // Scene::WorldBound covers every primitive
+            V3 c(sp.center[0], sp.center[1], sp.center[2]), r(sp.radius, sp.radius, sp.radius);
+            Bounds3 b(c - r, c + r);
+            if (nodes.empty()) { LinearBVHNode n; n.bounds = b; n.offset = 0; n.nPrimitives = 0; n.axis = 0; sphereOnlyBound = Union(sphereOnlyBound, b); }
+            else nodes[0].bounds = Union(nodes[0].bounds, b);
+        }
     }
+    Bounds3 sphereOnlyBound;
 
     // ---------------- BVH build: BVHAccel.cpp:147-189, 201-367 (SAH, maxPrimsInNode = 1) -----------
     struct PrimInfo { size_t primitiveNumber; Bounds3 bounds; V3 centroid; };
@@ -329,11 +344,74 @@ struct Scene {
         return true;
     }
 
-    // BVHAccel::Intersect, BVHAccel.cpp:653-691
+    // ---------------- Sphere::Intersect: pbrt-v3's quadratic sphere (the reference's shape/Sphere.h is an unfinished stub;
+    // PARITY UNPINNED).  Full sphere, ObjectToWorld = Translate(center).  The quadratic is solved in double precision (in
+    // place of pbrt's EFloat error intervals), everything else follows pbrt-v3 src/shapes/sphere.cpp: nearest root in
+    // (0, tMax], hit point re-projected onto the sphere, (phi, theta) parameterisation, dpdu / dpdv, pError = gamma(5)|p|,
+    // and the SurfaceInteraction is carried to world space with Transform's error bound for the translation.
+    bool SphereIntersect(int si, const Ray &ray, SurfaceInteraction *isect) const {
+        const gnxr_sphere &sp = spheres[si];
+        const Float radius = sp.radius;
+        V3 c(sp.center[0], sp.center[1], sp.center[2]);
+        V3 o = ray.o - c, d = ray.d;   // WorldToObject = Translate(-center)
+        double ox = o.x, oy = o.y, oz = o.z, dx = d.x, dy = d.y, dz = d.z;
+        double a = dx * dx + dy * dy + dz * dz;
+        double b = 2 * (dx * ox + dy * oy + dz * oz);
+        double cc = ox * ox + oy * oy + oz * oz - (double)radius * (double)radius;
+        double discrim = b * b - 4 * a * cc;
+        if (discrim < 0) return false;
+        double rootDiscrim = std::sqrt(discrim);
+        double q = (b < 0) ? -.5 * (b - rootDiscrim) : -.5 * (b + rootDiscrim);
+        double t0 = q / a, t1 = cc / q;
+        if (t0 > t1) std::swap(t0, t1);
+        if (!(t0 <= (double)ray.tMax) || !(t1 > 0)) return false;
+        double tShapeHit = t0;
+        if (tShapeHit <= 0) {
+            tShapeHit = t1;
+            if (tShapeHit > (double)ray.tMax) return false;
+        }
+        Float tHit = (Float)tShapeHit;
+        if (!isect) { ray.tMax = tHit; return true; }
+        V3 pHit = o + d * tHit;
+        pHit = pHit * (radius / pHit.Length());
+        if (pHit.x == 0 && pHit.y == 0) pHit.x = 1e-5f * radius;
+        Float phi = std::atan2(pHit.y, pHit.x);
+        if (phi < 0) phi += 2 * Pi;
+        const Float phiMax = 2 * Pi, thetaMin = Pi, thetaMax = 0;   // zMin = -r, zMax = r
+        Float u = phi / phiMax;
+        Float theta = std::acos(Clamp(pHit.z / radius, -1, 1));
+        Float v = (theta - thetaMin) / (thetaMax - thetaMin);
+        Float zRadius = std::sqrt(pHit.x * pHit.x + pHit.y * pHit.y);
+        Float invZRadius = 1 / zRadius;
+        Float cosPhi = pHit.x * invZRadius, sinPhi = pHit.y * invZRadius;
+        V3 dpdu(-phiMax * pHit.y, phiMax * pHit.x, 0);
+        V3 dpdv = (thetaMax - thetaMin) * V3(pHit.z * cosPhi, pHit.z * sinPhi, -radius * std::sin(theta));
+        V3 pError = gamma(5) * Abs(pHit);
+        // (*ObjectToWorld)(SurfaceInteraction): Transform.cpp, point with error (Transform.h:285-308), normals re-normalised
+        SurfaceInteraction s;
+        s.p = pHit + c;
+        s.pError = V3((gamma(3) + 1) * pError.x + gamma(3) * (std::abs(pHit.x) + std::abs(c.x)),
+                      (gamma(3) + 1) * pError.y + gamma(3) * (std::abs(pHit.y) + std::abs(c.y)),
+                      (gamma(3) + 1) * pError.z + gamma(3) * (std::abs(pHit.z) + std::abs(c.z)));
+        s.uv = P2(u, v);
+        s.wo = Normalize(-ray.d);
+        s.dpdu = dpdu; s.dpdv = dpdv; s.sdpdu = dpdu; s.sdpdv = dpdv;
+        s.n = s.sn = Normalize(Normalize(Cross(dpdu, dpdv)));
+        s.prim = nTriangles() + si; s.b0 = s.b1 = s.b2 = 0; s.t = tHit;
+        ray.tMax = tHit;   // GeometricPrimitive::Intersect, Primitive.cpp:32-46
+        int mi = sp.medium_inside, mo = sp.medium_outside;
+        if (mi != mo) { s.mediumInside = mi; s.mediumOutside = mo; }
+        else { s.mediumInside = s.mediumOutside = ray.medium; }
+        *isect = s;
+        return true;
+    }
+
+    // BVHAccel::Intersect, BVHAccel.cpp:653-691 (spheres, which live outside the triangle BVH, are tested first)
     bool Intersect(const Ray &ray, SurfaceInteraction *isect) const {
         counters.nIntersect.fetch_add(1, std::memory_order_relaxed);
-        if (nodes.empty()) return false;
         bool hit = false;
+        for (int si = 0; si < (int)spheres.size(); ++si) if (SphereIntersect(si, ray, isect)) hit = true;
+        if (nodes.empty()) return hit;
         V3 invDir(1 / ray.d.x, 1 / ray.d.y, 1 / ray.d.z);
         int dirIsNeg[3] = {invDir.x < 0, invDir.y < 0, invDir.z < 0};
         int toVisitOffset = 0, currentNodeIndex = 0;
@@ -370,6 +448,10 @@ struct Scene {
     // BVHAccel::IntersectP, BVHAccel.cpp:693-729
     bool IntersectP(const Ray &ray) const {
         counters.nIntersectP.fetch_add(1, std::memory_order_relaxed);
+        for (int si = 0; si < (int)spheres.size(); ++si) {
+            Ray r2 = ray;
+            if (SphereIntersect(si, r2, nullptr)) return true;
+        }
         if (nodes.empty()) return false;
         V3 invDir(1.f / ray.d.x, 1.f / ray.d.y, 1.f / ray.d.z);
         int dirIsNeg[3] = {invDir.x < 0, invDir.y < 0, invDir.z < 0};

@@ -196,3 +196,27 @@ def volume_cornell_cfg5(sigma_scale=1.0, golden_dir=None):
     PrimeSums out of bounds (undefined there; this build wraps, device_sampler.h)."""
     return volume_cornell(reference_density(golden_dir), sigma_a=(10 * sigma_scale,) * 3, sigma_s=(90 * sigma_scale,) * 3,
                           grid_lo=(-1.9, -2.4, -0.4), grid_hi=(0.1, -0.4, 0.4))
+
+
+def cornell_sphere(kind="matte", center=(0.6, -1.5, 0.2), radius=1.0):
+    """cfg 1 as BASELINE.json words it ("6 quads + 1 Sphere"): the Cornell box plus one pbrt-v3 sphere (the reference's own
+    Sphere is an unfinished stub -- parity unpinned, see include/gnxr.h).  kind: matte | mirror | glass | medium."""
+    b = cornell()
+    if kind == "matte":
+        m = b.MatteMaterial(DRAGON_GREEN, 60.0)
+    elif kind == "mirror":
+        m = b.MirrorMaterial((0.9, 0.9, 0.9))
+    elif kind == "glass":
+        m = b.add_material(type=gx._abi.MAT_GLASS, kr=(0.98,) * 3, kt=(0.98,) * 3, eta=(1.5, 0, 0), urough=0.0, vrough=0.0)
+    else:
+        m = -1
+    mi = -1
+    if kind == "medium":
+        hom = gx.Medium()
+        hom.type = gx._abi.MEDIUM_HOMOGENEOUS
+        hom.sigma_a[:] = (0.4, 0.8, 1.2)
+        hom.sigma_s[:] = (2.0, 1.6, 1.2)
+        hom.g = 0.3
+        mi = b.add_medium(hom)
+    b.AddSphere(center, radius, m, medium_inside=mi, medium_outside=-1)
+    return b

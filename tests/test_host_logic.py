@@ -103,3 +103,42 @@ def test_oracle_edge_cases(gx):
     assert (osc.Intersect(rays)["prim"] == -1).all() and (osc.IntersectP(rays) == 0).all()
     # zero-length batch
     assert len(osc.Intersect(np.zeros((0, 8), np.float32))) == 0
+
+
+def test_sphere_against_analytic_hits(gx):
+    """the oracle's pbrt-v3 sphere against the closed-form ray/sphere solution evaluated in float64."""
+    import oracle_lib as ol
+    import scenes
+    c, r = np.array([0.6, -1.5, 0.2], np.float32).astype(np.float64), 1.0   # the float32 centre the scene stores
+    b = scenes.cornell_sphere("matte", center=tuple(c), radius=r)
+    osc = ol.OracleScene(b)
+    rng = np.random.default_rng(4)
+    n = 20000
+    o = rng.uniform(-2.3, 2.3, (n, 3)).astype(np.float32)
+    tgt = (c + rng.normal(size=(n, 3)) * 0.8).astype(np.float32)
+    d = tgt - o
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays = gx.make_rays(o, d)
+    hits = osc.Intersect(rays)
+    nt = b.desc().n_triangles
+    on_sphere = hits["prim"] == nt
+    assert on_sphere.sum() > n // 4
+    od, dd = o.astype(np.float64) - c, d.astype(np.float64)
+    A = (dd * dd).sum(1); B = 2 * (dd * od).sum(1); Cq = (od * od).sum(1) - r * r
+    disc = B * B - 4 * A * Cq
+    t0 = (-B - np.sqrt(np.maximum(disc, 0))) / (2 * A); t1 = (-B + np.sqrt(np.maximum(disc, 0))) / (2 * A)
+    t_exact = np.where(t0 > 0, t0, t1)
+    sel = on_sphere & (disc > 1e-3)            # away from grazing incidence, where t is ill-conditioned
+    assert np.allclose(hits["t"][sel], t_exact[sel], rtol=1e-6, atol=1e-6)
+    p = o[sel].astype(np.float64) + dd[sel] * hits["t"][sel][:, None].astype(np.float64)
+    n_exact = (p - c) / np.linalg.norm(p - c, axis=1, keepdims=True)
+    assert np.abs(np.abs((hits["n"][sel] * n_exact).sum(1)) - 1).max() < 1e-5      # the normal is radial
+    assert np.abs(np.linalg.norm(p - c, axis=1) - r).max() < 1e-5                  # the hit lies on the sphere
+    # rays whose exact solution misses the sphere (or lies behind a wall) never report it
+    miss = (disc < -1e-6) | (t1 < -1e-6)
+    assert not (hits["prim"][miss] == nt).any()
+    # IntersectP agrees with Intersect for segments that end inside / beyond the sphere
+    seg = gx.make_rays(o, (tgt - o), 1.0)
+    occ = osc.IntersectP(seg)
+    full = osc.Intersect(seg)
+    assert ((full["prim"] >= 0) == (occ != 0)).all()
