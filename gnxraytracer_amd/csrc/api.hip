@@ -282,8 +282,8 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     if (r.npix == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return GNXR_OK; }
     int nsamples = p.spp_end - p.spp_begin;
     int k = p.samples_per_pass;
-    if (k <= 0) {  // auto: about 4M paths in flight
-        long long target = 4ll << 20;
+    if (k <= 0) {  // auto: about 32M paths in flight (big passes keep the thin late bounces from under-filling the GPU)
+        long long target = 32ll << 20;
         k = (int)std::max<long long>(1, std::min<long long>(nsamples, target / r.npix));
     }
     k = std::min(k, nsamples);
