@@ -64,9 +64,6 @@ GX_DEV float radical_inverse_2(uint32_t a) { return (float)((double)__brev(a) * 
 
 // HaltonSampler::SampleDimension, HaltonSampler.cpp:85-94 (sampleAtPixelCenter == false)
 GX_DEV float halton_sample(const DSamplerTables &t, uint32_t index, int dim) {
-#ifdef GX_ABL_HALTON   // ablation build (timing experiments only): a cheap hash instead of the radical inverse
-    if (dim >= 2) { uint32_t hsh = (index * 2654435761u) ^ ((uint32_t)dim * 0x9E3779B9u); hsh ^= hsh >> 15; return (float)(hsh >> 8) * 0x1p-24f; }
-#endif
     if (dim >= 1000) dim = 2 + (dim - 2) % 998;  // reference reads PrimeSums out of bounds here; defined to wrap
     if (dim == 0) return radical_inverse_2(index >> t.h.base_exp[0]);
     uint32_t base = (uint32_t)t.primes[dim], M = t.prime_magic[2 * dim], s = t.prime_magic[2 * dim + 1];
