@@ -270,9 +270,8 @@ class VolPathIntegrator(PathIntegrator):
 
 
 class WhittedIntegrator(PathIntegrator):
-    """pbr::WhittedIntegrator(maxDepth, ...) (integrators/WhittedIntegrator.h): BASELINE config 1, the reference's CPU-only
-    path.  libgnxr has no device implementation of it (gnxr_render returns GNXR_ERR_UNSUPPORTED); the class exists so that
-    the test oracle can be driven through the same interface."""
+    """pbr::WhittedIntegrator(maxDepth, ...) (integrators/WhittedIntegrator.h): BASELINE config 1, which the reference runs on
+    the CPU only.  On the device it is a per-path depth-first state machine (csrc/whitted_kernel.hip.h)."""
     integrator = _abi.INTEGRATOR_WHITTED
 
     def __init__(self, maxDepth=5):

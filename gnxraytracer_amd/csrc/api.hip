@@ -12,6 +12,7 @@
 #include "host_scene.h"
 #include "kernels.hip.h"
 #include "vol_kernel.hip.h"
+#include "whitted_kernel.hip.h"
 
 using namespace gnxr;
 
@@ -111,7 +112,7 @@ struct gnxr_scene {
     DevBuf<DNode4> nodes4;
     DevBuf<DTri> tris;
     DevBuf<DSphere> spheres;
-    DevBuf<DMaterial> materials;
+    DevBuf<DMaterial> materials, materials_single;
     DevBuf<DLight> lights;
     DevBuf<int32_t> infinite;
     DevBuf<uint16_t> perms;
@@ -133,6 +134,9 @@ struct gnxr_scene {
     DevBuf<int> trace_spill;   // global part of k_trace's per-lane traversal stacks
     DevBuf<float4> vol_n1, vol_f, vol_Li, vol_Tr, vol_Ld, vol_mres;   // VolPath light-estimate records (vol_kernel.hip.h)
     DevBuf<int4> vol_vs;
+    DevBuf<float4> wh_o, wh_d, wh_L, wh_w;   // Whitted recursion frames (whitted_kernel.hip.h)
+    DevBuf<float> wh_pdf;
+    DevBuf<int> wh_rec;
     DevBuf<Counters> counters;
     Counters *h_counters = nullptr;  // pinned
     int stack_size = 32;
@@ -219,7 +223,7 @@ int gnxr_scene_create(const gnxr_scene_desc *desc, gnxr_scene **out) {
     for (const DNode &n : cs.nodes) if ((n.meta & 0xffffu) > 127) s->wide_ok = false;
 #define UP(field) if ((rc = s->field.upload(cs.field)) != GNXR_OK) { delete s; return rc; }
     UP(nodes) UP(nodes4) UP(tris) UP(materials) UP(lights) UP(perms) UP(primes) UP(prime_sums) UP(prime_magic)
-    UP(dmedia) UP(grid_density) UP(tri_media) UP(spheres)
+    UP(dmedia) UP(grid_density) UP(tri_media) UP(spheres) UP(materials_single)
     UP(env_texels) UP(env_cond_func) UP(env_cond_cdf) UP(env_cond_int) UP(env_marg_func) UP(env_marg_cdf)
 #undef UP
     if ((rc = s->infinite.upload(cs.infinite_lights)) != GNXR_OK) { delete s; return rc; }
@@ -259,11 +263,16 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
         set_error("invalid render parameters");
         return GNXR_ERR_INVALID;
     }
-    if (p.integrator != GNXR_INTEGRATOR_PATH && p.integrator != GNXR_INTEGRATOR_VOLPATH) {
-        set_error("integrator %d has no device implementation (Whitted is the reference's CPU-only config 1)", p.integrator);
+    if (p.integrator != GNXR_INTEGRATOR_PATH && p.integrator != GNXR_INTEGRATOR_VOLPATH && p.integrator != GNXR_INTEGRATOR_WHITTED) {
+        set_error("unknown integrator %d", p.integrator);
         return GNXR_ERR_UNSUPPORTED;
     }
-    const bool volpath = p.integrator == GNXR_INTEGRATOR_VOLPATH;
+    const bool volpath = p.integrator == GNXR_INTEGRATOR_VOLPATH, whitted = p.integrator == GNXR_INTEGRATOR_WHITTED;
+    const int nL = (int)s->cs.desc_lights.size();
+    if (whitted && (nL > 16 || p.max_depth > 32 || !s->cs.media.empty())) {
+        set_error("Whitted on the device: at most 16 lights (every light is sampled at every vertex), depth 32, no media");
+        return GNXR_ERR_UNSUPPORTED;
+    }
     std::lock_guard<std::mutex> lock(s->render_mutex);
     auto t_start = std::chrono::steady_clock::now();
     hipStream_t stream = (hipStream_t)hip_stream;
@@ -283,7 +292,7 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     int nsamples = p.spp_end - p.spp_begin;
     int k = p.samples_per_pass;
     if (k <= 0) {  // auto: about 32M paths in flight (big passes keep the thin late bounces from under-filling the GPU)
-        long long target = 32ll << 20;
+        long long target = whitted ? (4ll << 20) : (32ll << 20);   // Whitted keeps max_depth frames per path
         k = (int)std::max<long long>(1, std::min<long long>(nsamples, target / r.npix));
     }
     k = std::min(k, nsamples);
@@ -292,6 +301,13 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
 #define AL(f) if ((rc = s->f.alloc(cap)) != GNXR_OK) return rc;
     AL(ray_o) AL(ray_d) AL(beta) AL(L) AL(sh_o) AL(sh_d) AL(sh_X) AL(mis_o) AL(mis_d) AL(mis_Y) AL(nbeta) AL(meta) AL(hit) AL(queue_a) AL(queue_b) AL(queue_nee) AL(queue_c0) AL(queue_c1) AL(queue_c2) AL(pflags) AL(pclass)
 #undef AL
+    if (whitted) {
+        const size_t nl = (size_t)std::max(1, nL), md = (size_t)std::max(1, p.max_depth);
+        if ((rc = s->sh_o.alloc(cap * nl)) || (rc = s->sh_d.alloc(cap * nl)) || (rc = s->sh_X.alloc(cap * nl)) || (rc = s->wh_rec.alloc(cap * nl)) ||
+            (rc = s->wh_o.alloc(cap * md)) || (rc = s->wh_d.alloc(cap * md)) || (rc = s->wh_L.alloc(cap * md)) || (rc = s->wh_w.alloc(cap * md)) ||
+            (rc = s->wh_pdf.alloc(cap * md)) || (rc = s->vol_vs.alloc(cap)))
+            return rc;
+    }
     if (volpath) {
 #define AL(f) if ((rc = s->f.alloc(cap)) != GNXR_OK) return rc;
         AL(vol_n1) AL(vol_f) AL(vol_Li) AL(vol_Tr) AL(vol_Ld) AL(vol_mres) AL(vol_vs)
@@ -307,6 +323,10 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     va.vs = s->vol_vs.p; va.sv_o = s->sh_o.p; va.sv_d = s->sh_d.p; va.p1 = s->sh_X.p; va.p1e = s->nbeta.p; va.n1 = s->vol_n1.p; va.f = s->vol_f.p;
     va.Li = s->vol_Li.p; va.Tr = s->vol_Tr.p; va.Ld = s->vol_Ld.p; va.mis_o = s->mis_o.p; va.mis_d = s->mis_d.p; va.mis_Y = s->mis_Y.p; va.mres = s->vol_mres.p;
     DMediaTables mt = s->media_tables();
+    WhittedArrays wa;
+    wa.ws = s->vol_vs.p; wa.fr_o = s->wh_o.p; wa.fr_d = s->wh_d.p; wa.fr_L = s->wh_L.p; wa.fr_w = s->wh_w.p; wa.fr_pdf = s->wh_pdf.p;
+    wa.cap = (int)cap; wa.n_lights = nL;
+    if (whitted) { sc.materials = s->materials_single.p; pa.sh_o = s->sh_o.p; pa.sh_d = s->sh_d.p; pa.sh_X = s->sh_X.p; }
 
     HIP_TRY(hipMemsetAsync(s->accum.p, 0, sizeof(float4) * r.npix, stream));
     HIP_TRY(hipMemsetAsync(s->counters.p, 0, sizeof(Counters), stream));
@@ -368,11 +388,43 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
             if (mode == COMPACT_FLAGS) hipLaunchKernelGGL((k_compact_count<COMPACT_FLAGS, 4>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles);
             else hipLaunchKernelGGL((k_compact_count<COMPACT_CLASS, 3>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles);
             hipLaunchKernelGGL(k_compact_scan, dim3(nout), dim3(1024), 0, stream, s->tile_counts.p, tiles, totals);
-            if (mode == COMPACT_FLAGS) hipLaunchKernelGGL((k_compact_scatter<COMPACT_FLAGS, 2>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, (const unsigned int *)s->tile_counts.p, tiles, o0, o1, o2);
+            if (mode == COMPACT_FLAGS && nscatter == 3) hipLaunchKernelGGL((k_compact_scatter<COMPACT_FLAGS, 3>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, (const unsigned int *)s->tile_counts.p, tiles, o0, o1, o2);
+            else if (mode == COMPACT_FLAGS) hipLaunchKernelGGL((k_compact_scatter<COMPACT_FLAGS, 2>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, (const unsigned int *)s->tile_counts.p, tiles, o0, o1, o2);
             else hipLaunchKernelGGL((k_compact_scatter<COMPACT_CLASS, 3>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, (const unsigned int *)s->tile_counts.p, tiles, o0, o1, o2);
             launches += 3;
         };
-        if (volpath) {
+        if (whitted) {
+            // depth-first recursion per path (whitted_kernel.hip.h): the path's ray + the previous vertex's shadow rays per round
+            hipLaunchKernelGGL(k_whitted_init, dim3(grid_for(n_paths)), dim3(kBlock), 0, stream, pa, wa, n_paths);
+            ++launches;
+            int n_cl = n, n_shp = 0;
+            const int *q_cl = nullptr;
+            unsigned long long *d_shadow = &dctr->whitted_shadow;
+            while (n > 0) {
+                if (n_shp > 0) {
+                    hipLaunchKernelGGL(k_whitted_expand, dim3(grid_for((long long)n_shp * nL)), dim3(kBlock), 0, stream, (const int *)s->queue_nee.p, n_shp, nL, (int)cap, s->wh_rec.p);
+                    ++launches;
+                }
+                launch_trace(TraceWork{q_cl, n_cl, s->wh_rec.p, n_shp * nL}, 0, 0);
+                if (timing) timer.begin(2, stream);
+#define GX_WH(LTV, SPHV) hipLaunchKernelGGL((k_whitted_step<LTV, SPHV>), dim3(grid_for(n)), dim3(kBlock), 0, stream, sc, r, pa, wa, q_in, n, d_shadow)
+                if (area_only) { if (spheres) GX_WH(LT_AREA, true); else GX_WH(LT_AREA, false); }
+                else { if (spheres) GX_WH(LT_ALL, true); else GX_WH(LT_ALL, false); }
+#undef GX_WH
+                ++launches;
+                compact(COMPACT_FLAGS, q_in, n, s->pflags.p, 4, 3, &dctr->q_next, q_cur, s->queue_nee.p, s->queue_c0.p);
+                if (timing) timer.end(stream);
+                HIP_TRY(hipMemcpyAsync(s->h_counters, dctr, sizeof(Counters), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                n = (int)s->h_counters->q_next;
+                n_shp = (int)s->h_counters->q_nee;
+                n_cl = (int)s->h_counters->q_shadow;   // count of pflags bit2: paths with a closest-hit ray to trace
+                q_cl = s->queue_c0.p;
+                q_in = q_cur;
+                std::swap(q_cur, q_other);
+                if (++guard > (1 << 20)) { set_error("path loop did not terminate"); return GNXR_ERR_INVALID; }
+            }
+        } else if (volpath) {
             // one closest-hit ray per live path and round: k_trace -> k_vol_step -> compaction (vol_kernel.hip.h)
             hipLaunchKernelGGL(k_vol_init, dim3(grid_for(n_paths)), dim3(kBlock), 0, stream, pa, va, n_paths);
             ++launches;
@@ -465,7 +517,7 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     if (stats) {
         memset(stats, 0, sizeof(*stats));
         stats->rays_closest = rays_closest;
-        stats->rays_any = rays_any;
+        stats->rays_any = whitted ? s->h_counters->whitted_shadow : rays_any;
         stats->camera_samples = (uint64_t)r.npix * nsamples;
         stats->nodes_visited = s->h_counters->nodes;
         stats->tris_tested = s->h_counters->tris;

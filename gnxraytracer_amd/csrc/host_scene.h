@@ -48,6 +48,7 @@ struct CompiledScene {
     Box3 world_bound;
     // shading
     std::vector<DMaterial> materials;
+    std::vector<DMaterial> materials_single;   // allowMultipleLobes == false (Whitted)
     std::vector<DLight> lights;
     std::vector<int32_t> infinite_lights;
     // sampler

@@ -46,6 +46,7 @@ struct Counters {
     unsigned int q_next, q_nee, q_shadow, q_mis;   // k_compact_scan totals: paths that continue / have NEE / shadow rays / MIS rays
     unsigned int q_class[3];                        // fill counts of the per-material-class shade queues
     unsigned int cursor;                            // k_trace work cursor
+    unsigned long long whitted_shadow;              // shadow rays queued by k_whitted_step
 };
 
 struct DScene {

@@ -190,7 +190,7 @@ static void set_alpha(DLobe &l, float ax, float ay) { l.alphax = std::max(0.001f
 static void set_R(DLobe &l, const RGB &r) { memcpy(l.R, r.c, 12); }
 static void set_T(DLobe &l, const RGB &r) { memcpy(l.T, r.c, 12); }
 
-static bool compile_material(const gnxr_material &m, DMaterial *out) {
+static bool compile_material(const gnxr_material &m, DMaterial *out, bool allowMultipleLobes = true) {
     memset(out, 0, sizeof(*out));
     out->has_bump = m.has_bump;
     out->eta = 1;
@@ -225,10 +225,21 @@ static bool compile_material(const gnxr_material &m, DMaterial *out) {
         out->eta = eta;
         if (black(R) && black(T)) break;
         bool isSpecular = urough == 0 && vrough == 0;
-        if (isSpecular) {
+        if (isSpecular && allowMultipleLobes) {
             DLobe l = blank_lobe(LOBE_FRESNEL_SPEC, BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_SPECULAR);
             set_R(l, R); set_T(l, T); l.etaA = 1.f; l.etaB = eta;
             add(l);
+        } else if (isSpecular) {   // allowMultipleLobes == false (WhittedIntegrator.cpp:34): SpecularReflection + SpecularTransmission
+            if (!black(R)) {
+                DLobe l = blank_lobe(LOBE_SPEC_REFL, BSDF_REFLECTION | BSDF_SPECULAR);
+                set_R(l, R); l.fresnel = FRESNEL_DIELECTRIC; l.f_etaI = 1.f; l.f_etaT = eta;
+                add(l);
+            }
+            if (!black(T)) {
+                DLobe l = blank_lobe(LOBE_SPEC_TRANS, BSDF_TRANSMISSION | BSDF_SPECULAR);
+                set_T(l, T); l.etaA = 1.f; l.etaB = eta; l.fresnel = FRESNEL_DIELECTRIC; l.f_etaI = 1.f; l.f_etaT = eta;
+                add(l);
+            }
         } else {
             if (m.remap_roughness) { urough = roughness_to_alpha(urough); vrough = roughness_to_alpha(vrough); }
             if (!black(R)) {
@@ -670,6 +681,8 @@ bool compile_scene(const gnxr_scene_desc *d, CompiledScene *cs) {
     cs->materials.resize(std::max(1, d->n_materials));
     memset(cs->materials.data(), 0, sizeof(DMaterial) * cs->materials.size());
     for (int i = 0; i < d->n_materials; ++i) if (!compile_material(d->materials[i], &cs->materials[i])) return false;
+    cs->materials_single = cs->materials;   // ComputeScatteringFunctions(..., allowMultipleLobes = false): differs for smooth glass only
+    for (int i = 0; i < d->n_materials; ++i) if (!compile_material(d->materials[i], &cs->materials_single[i], false)) return false;
     // ---- lights
     cs->lights.resize(std::max(1, d->n_lights));
     memset(cs->lights.data(), 0, sizeof(DLight) * cs->lights.size());

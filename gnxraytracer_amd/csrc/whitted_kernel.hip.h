@@ -1,0 +1,222 @@
+// whitted_kernel.hip.h -- WhittedIntegrator::Li (integrators/WhittedIntegrator.cpp:14-68) with SamplerIntegrator::
+// SpecularReflect / SpecularTransmit (core/Integrator.cpp:321-442) as a per-path depth-first state machine (BASELINE
+// config 1; the reference runs it on the CPU only).
+//
+// The recursion consumes the sample stream in DFS order -- all lights of a vertex, the reflected subtree, then the
+// transmitted subtree -- and combines radiance on the way back up as `f * Li(child) * |cos| / pdf`, so each path keeps an
+// explicit stack of frames (one per recursion level: the vertex's ray + hit to re-establish its BSDF, the radiance
+// accumulated so far, which child is pending and that child's weight) and has one closest-hit ray in flight.  A round is
+//     k_trace (the path's ray + the shadow rays of the vertex established in the previous round) -> k_whitted_step.
+// Every light is sampled at every vertex (WhittedIntegrator.cpp:44-55); the shadow rays use the NEE records of
+// PathArrays at slot `light * cap + path` (shadow part only).  Ray differentials are not carried: they only feed texture
+// filtering and every texture on this path is constant.
+#pragma once
+#include "kernels.hip.h"
+
+namespace gnxr {
+
+struct WhittedArrays {
+    int4 *ws;        // x: frames on the stack (= recursion depth of the ray in flight), y: Halton dimension,
+                     // z: frame whose shadow rays are in flight (-1: none), w: 1 = no ray in flight, waiting for those shadow rays
+    float4 *fr_o;    // [depth * cap + path] ray that reached the vertex: o.xyz, tMax
+    float4 *fr_d;    // d.xyz, w: hit code (int bits)
+    float4 *fr_L;    // radiance accumulated at the vertex, w: stage (int bits: 0 reflect next, 1 transmit next, 2 done)
+    float4 *fr_w;    // weight of the pending child: f.rgb, w: |cos|
+    float *fr_pdf;   // pdf of the pending child
+    int cap;
+    int n_lights;
+};
+
+__global__ void __launch_bounds__(kBlock) k_whitted_init(PathArrays pa, WhittedArrays wa, int n_paths) {
+    for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_paths; slot += gridDim.x * blockDim.x) {
+        uint2 m = pa.meta[slot];
+        wa.ws[slot] = make_int4(0, (int)m.y, -1, 0);
+    }
+}
+
+// record ids of the shadow rays of the paths in `q` (n paths): light * cap + path, light-major inside a path
+__global__ void __launch_bounds__(kBlock) k_whitted_expand(const int *__restrict__ q, int n, int n_lights, int cap, int *__restrict__ out) {
+    for (long long i = blockIdx.x * blockDim.x + threadIdx.x; i < (long long)n * n_lights; i += (long long)gridDim.x * blockDim.x) {
+        int p = (int)(i / n_lights), l = (int)(i - (long long)p * n_lights);
+        out[i] = l * cap + (q ? q[p] : p);
+    }
+}
+
+// pflags: bit0 the path is still alive, bit1 it has shadow rays to trace this round, bit2 it has a closest-hit ray to trace.
+template <int LT, bool SPH>
+__global__ void __launch_bounds__(kBlock) k_whitted_step(DScene sc, DRender r, PathArrays pa, WhittedArrays wa, const int *__restrict__ queue, int n,
+                                                         unsigned long long *ray_counts) {
+    unsigned long long nShadow = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int path = queue ? queue[i] : i;
+        const size_t cap = (size_t)wa.cap;
+        int4 ws = wa.ws[path];
+        int top = ws.x, pend = ws.z;
+        const uint32_t index = pa.meta[path].x;
+        SampleStream ss(sc.st, index, ws.y);
+        // ---- (a) the shadow rays of the most recent vertex have been traced: lightL, then L += lightL
+        if (pend >= 0) {
+            Spec lightL(0.f);
+            for (int l = 0; l < wa.n_lights; ++l) {
+                const size_t rec = (size_t)l * cap + path;
+                if ((__float_as_int(pa.sh_d[rec].w) & 1) && pa.sh_o[rec].w == 1.f) {
+                    float4 X = pa.sh_X[rec];
+                    lightL = lightL + Spec(X.x, X.y, X.z);
+                }
+            }
+            float4 *Lp = &wa.fr_L[(size_t)pend * cap + path];
+            float4 L4 = *Lp;
+            *Lp = make_float4(L4.x + lightL.r, L4.y + lightL.g, L4.z + lightL.b, L4.w);
+            pend = -1;
+        }
+        bool haveResult = false, traceClosest = false, traceShadow = false, done = false;
+        Spec result(0.f);
+        if (ws.w == 0) {
+            // ---- (b) the ray in flight (recursion depth `top`) has been traced
+            float4 o4 = pa.ray_o[path], d4 = pa.ray_d[path];
+            V3 ro(o4.x, o4.y, o4.z), rd(d4.x, d4.y, d4.z);
+            const int leaf = pa.hit[path];
+            bool found = leaf != -1;
+            V3 p0, p1, p2;
+            int triMat = -1, triLight = -1;
+            TriHit h;
+            SurfacePoint sp;
+            sp.valid = false;
+            if (SPH && leaf < -1) {
+                const DSphere &sph = sc.spheres[-2 - leaf];
+                triMat = sph.material;
+                found = sphere_test(sph, ro, rd, o4.w, &h.t);
+                if (found) sp = sphere_surface_point(sph, ro, rd, h.t, triMat >= 0 ? sc.materials[triMat].has_bump != 0 : false);
+            } else if (found) {
+                const float4 *q = reinterpret_cast<const float4 *>(sc.tris + leaf);
+                float4 a = q[0], b = q[1], c = q[2];
+                p0 = V3(a.x, a.y, a.z); p1 = V3(b.x, b.y, b.z); p2 = V3(c.x, c.y, c.z);
+                triMat = __float_as_int(b.w); triLight = __float_as_int(c.w);
+                found = tri_test(p0, p1, p2, ro, rd, o4.w, &h);
+                if (found) { sp = surface_point(p0, p1, p2, h, triMat >= 0 ? sc.materials[triMat].has_bump != 0 : false); found = sp.valid; }
+            }
+            if (!found) {           // `for (light : scene.lights) L += light->Le(ray)`
+                for (int l = 0; l < sc.lt.n_lights; ++l) result = result + light_Le<LT>(sc.lt, l, ro, rd);
+                haveResult = true;
+            } else if (triMat < 0) { // no BSDF: Li(isect.SpawnRay(ray.d), ..., depth)
+                V3 o2 = offset_ray_origin(sp.p, sp.pError, sp.n, rd);
+                pa.ray_o[path] = make_float4(o2.x, o2.y, o2.z, GX_INF);
+                traceClosest = true;
+            } else {
+                // establish the frame of this vertex: L = Le + (lightL, next round)
+                const DMaterial *mat = sc.materials + triMat;
+                Bsdf<LM_ALL> bsdf;
+                bsdf.mat = mat; bsdf.ns = sp.ns; bsdf.ng = sp.n; bsdf.ss = sp.ss; bsdf.ts = sp.ts;
+                const V3 woN = normalize(-rd);
+                Spec L(0.f);
+                if (triLight >= 0) L = L + area_L(sc.lt.lights[triLight], sp.n, woN);
+                for (int l = 0; l < wa.n_lights; ++l) {
+                    float u0, u1;
+                    ss.get2d(&u0, &u1);
+                    const size_t rec = (size_t)l * cap + path;
+                    int flag = 0;
+                    LightSample ls = light_sample<LT>(sc.lt, l, sp.p, u0, u1);
+                    if (!(ls.Li.is_black() || ls.pdf == 0)) {
+                        Spec f = bsdf.f(woN, ls.wi, BSDF_ALL);
+                        if (!f.is_black()) {
+                            V3 so, sd;
+                            spawn_ray_to(sp.p, sp.pError, sp.n, ls.p1, ls.p1Error, ls.n1, &so, &sd);
+                            Spec X = f * ls.Li * absdot(ls.wi, sp.ns) / ls.pdf;
+                            pa.sh_o[rec] = make_float4(so.x, so.y, so.z, 1 - GX_SHADOW_EPS);
+                            pa.sh_X[rec] = make_float4(X.r, X.g, X.b, 0.f);
+                            pa.sh_d[rec] = make_float4(sd.x, sd.y, sd.z, __int_as_float(1));
+                            flag = 1;
+                            ++nShadow;
+                        }
+                    }
+                    if (!flag) pa.sh_d[rec] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
+                }
+                const size_t fi = (size_t)top * cap + path;
+                wa.fr_o[fi] = o4;
+                wa.fr_d[fi] = make_float4(rd.x, rd.y, rd.z, __int_as_float(leaf));
+                wa.fr_L[fi] = make_float4(L.r, L.g, L.b, __int_as_float(0));
+                pend = top;
+                traceShadow = true;
+                ++top;
+            }
+        } else {
+            // the frame on top was complete and only waited for its shadow rays
+            float4 L4 = wa.fr_L[(size_t)(top - 1) * cap + path];
+            result = Spec(L4.x, L4.y, L4.z);
+            --top;
+            haveResult = true;
+        }
+        // ---- (c) deliver finished subtrees to their parents and advance the frame on top until a ray is needed
+        while (!traceClosest && !done) {
+            if (haveResult) {
+                if (top == 0) { pa.L[path] = make_float4(result.r, result.g, result.b, 0.f); done = true; break; }
+                const size_t fp = (size_t)(top - 1) * cap + path;
+                float4 w4 = wa.fr_w[fp], L4 = wa.fr_L[fp];
+                Spec add = Spec(w4.x, w4.y, w4.z) * result * w4.w / wa.fr_pdf[fp];   // f * Li(...) * AbsDot(wi, ns) / pdf
+                wa.fr_L[fp] = make_float4(L4.x + add.r, L4.y + add.g, L4.z + add.b, L4.w);
+                haveResult = false;
+            }
+            const int f = top - 1;
+            if (f < 0) break;   // only reachable right after a null-material pass-through handled above
+            const size_t fi = (size_t)f * cap + path;
+            float4 L4 = wa.fr_L[fi];
+            int stage = __float_as_int(L4.w);
+            bool emitted = false;
+            if (f + 1 < r.max_depth && stage < 2) {
+                // re-establish the vertex's BSDF from its ray and hit (same arithmetic as when it was first reached)
+                float4 fo = wa.fr_o[fi], fd = wa.fr_d[fi];
+                V3 ro(fo.x, fo.y, fo.z), rd(fd.x, fd.y, fd.z);
+                const int leaf = __float_as_int(fd.w);
+                SurfacePoint sp;
+                int triMat;
+                TriHit h;
+                if (SPH && leaf < -1) {
+                    const DSphere &sph = sc.spheres[-2 - leaf];
+                    triMat = sph.material;
+                    (void)sphere_test(sph, ro, rd, fo.w, &h.t);
+                    sp = sphere_surface_point(sph, ro, rd, h.t, sc.materials[triMat].has_bump != 0);
+                } else {
+                    const float4 *q = reinterpret_cast<const float4 *>(sc.tris + leaf);
+                    float4 a = q[0], b = q[1], c = q[2];
+                    V3 p0(a.x, a.y, a.z), p1(b.x, b.y, b.z), p2(c.x, c.y, c.z);
+                    triMat = __float_as_int(b.w);
+                    (void)tri_test(p0, p1, p2, ro, rd, fo.w, &h);
+                    sp = surface_point(p0, p1, p2, h, sc.materials[triMat].has_bump != 0);
+                }
+                Bsdf<LM_ALL> bsdf;
+                bsdf.mat = sc.materials + triMat; bsdf.ns = sp.ns; bsdf.ng = sp.n; bsdf.ss = sp.ss; bsdf.ts = sp.ts;
+                const V3 woN = normalize(-rd);
+                while (stage < 2 && !emitted) {
+                    const int type = stage == 0 ? (BSDF_REFLECTION | BSDF_SPECULAR) : (BSDF_TRANSMISSION | BSDF_SPECULAR);
+                    ++stage;
+                    float u0, u1, pdf = 0;
+                    ss.get2d(&u0, &u1);
+                    V3 wi;
+                    int sampledType;
+                    Spec fs = bsdf.sample_f(woN, &wi, u0, u1, &pdf, type, &sampledType);
+                    if (pdf > 0.f && !fs.is_black() && absdot(wi, sp.ns) != 0.f) {
+                        V3 o2 = offset_ray_origin(sp.p, sp.pError, sp.n, wi);
+                        pa.ray_o[path] = make_float4(o2.x, o2.y, o2.z, GX_INF);
+                        pa.ray_d[path] = make_float4(wi.x, wi.y, wi.z, __int_as_float(-1));
+                        wa.fr_w[fi] = make_float4(fs.r, fs.g, fs.b, absdot(wi, sp.ns));
+                        wa.fr_pdf[fi] = pdf;
+                        emitted = true;
+                    }
+                }
+                wa.fr_L[fi] = make_float4(L4.x, L4.y, L4.z, __int_as_float(stage));
+            }
+            if (emitted) { traceClosest = true; break; }
+            // the frame is complete
+            if (pend == f) break;   // ... but its shadow rays are still in flight: wait one round
+            result = Spec(L4.x, L4.y, L4.z);
+            --top;
+            haveResult = true;
+        }
+        const bool waiting = !traceClosest && !done;
+        wa.ws[path] = make_int4(top, ss.dim, pend, waiting ? 1 : 0);
+        pa.pflags[path] = (unsigned char)(done ? 0 : (1 | (traceShadow ? 2 : 0) | (traceClosest ? 4 : 0)));
+    }
+    if (nShadow) atomicAdd(ray_counts, nShadow);
+}
+
+}  // namespace gnxr

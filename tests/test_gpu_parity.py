@@ -252,6 +252,33 @@ def test_path_integrator_passes_through_medium_boundaries(gpu):
     assert abs(st["rays_closest"] - ost["rays_closest"]) <= RAYS_TOL * ost["rays_closest"]
 
 
+@pytest.mark.parametrize("name", ["cornell", "zoo", "cfg1", "sphere_mirror", "sphere_glass", "sky"])
+def test_whitted_matches_reference(gpu, name):
+    """cfg 1 (WhittedIntegrator) on the device: the depth-first recursion as a per-path state machine.  cornell /
+    zoo / cfg1 are golden images of the restated recursion on the reference's classes (cfg1: the recorded 1 048 576 /
+    2 028 213 rays); the sphere scenes ("6 quads + 1 Sphere" of BASELINE configs[0]) and the sky-lit box compare with the oracle."""
+    g = golden("render_whitted.npz")
+    if name == "cfg1":
+        img, st = gpu.WhittedIntegrator(5).Render(gpu.Scene(scenes.cornell()), 256, 256, 16)
+        assert (st["rays_closest"], st["rays_any"]) == (1048576, 2028213)
+        assert abs(float(img[..., :3].astype(np.float64).sum()) - float(g["cfg1_checksum"])) < 1e-6
+        assert biteq(img[::4, ::4, :3], g["cfg1_thumb"])
+        return
+    if name in ("cornell", "zoo"):
+        W, H, spp, depth = (int(v) for v in g[name + "_cfg"])
+        b = scenes.cornell() if name == "cornell" else scenes.material_zoo()
+        img, st = gpu.WhittedIntegrator(depth).Render(gpu.Scene(b), W, H, spp)
+        assert (st["rays_closest"], st["rays_any"]) == tuple(int(v) for v in g[name + "_rays"])
+        assert biteq(img[..., :3], g[name][..., :3])
+        return
+    b = scenes.cornell(sky=True) if name == "sky" else scenes.cornell_sphere(name.split("_")[1])
+    integ = gpu.WhittedIntegrator(5)
+    img, st = integ.Render(gpu.Scene(b), 96, 96, 16)
+    oimg, ost = ol.OracleScene(b).render(integ, 96, 96, 16)
+    assert (st["rays_closest"], st["rays_any"]) == (ost["rays_closest"], ost["rays_any"])
+    assert biteq(img[..., :3], oimg[..., :3])
+
+
 @pytest.mark.parametrize("kind", ["matte", "mirror", "glass", "medium"])
 def test_sphere_matches_oracle(gpu, kind):
     """pbrt-v3 quadratic sphere (parity with the reference unpinned: its Sphere is a stub).  The device is
