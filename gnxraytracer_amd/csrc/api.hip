@@ -368,7 +368,11 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
             int blocks = (int)std::min<long long>((long long)g_num_cus * per_cu, (total + kBlock - 1) / kBlock);
             if (s->trace_spill.alloc((size_t)g_num_cus * per_cu * kBlock * (size_t)std::max(1, entries - lds_entries)) != GNXR_OK) return;
             if (timing) timer.begin(0, stream);
-#define GX_TRACE(C, W, S) hipLaunchKernelGGL((k_trace<C, W, S>), dim3(blocks), dim3(kBlock), lds, stream, sc, pa, w, &dctr->cursor, dctr, lds_entries, s->trace_spill.p)
+            // rays per atomic: kTraceChunk for big launches; for thin ones (late bounces) small enough that every wave gets a chunk --
+            // the number of atomics stays <= the number of waves, well under the ~88/us a single address sustains
+            const long long waves = (long long)blocks * (kBlock / 64);
+            const int chunk = (int)std::min<long long>(kTraceChunk, std::max<long long>(64, ((total + waves - 1) / waves + 63) / 64 * 64));
+#define GX_TRACE(C, W, S) hipLaunchKernelGGL((k_trace<C, W, S>), dim3(blocks), dim3(kBlock), lds, stream, sc, pa, w, &dctr->cursor, dctr, lds_entries, s->trace_spill.p, chunk)
             if (spheres) {
                 if (counting) GX_TRACE(true, false, true); else if (wide) GX_TRACE(false, true, true); else GX_TRACE(false, false, true);
             } else {
@@ -436,7 +440,9 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
                     (void)hipMemsetAsync(&dctr->cursor, 0, sizeof(unsigned int), stream);
                     int blocks = (int)std::min<long long>((long long)g_num_cus * 8, ((long long)n_media + kBlock - 1) / kBlock);
                     if (timing) timer.begin(1, stream);
-                    hipLaunchKernelGGL(k_vol_media, dim3(blocks), dim3(kBlock), 0, stream, sc, mt, pa, va, q_media, n_media, &dctr->cursor);
+                    const long long mwaves = (long long)blocks * (kBlock / 64);
+                    const int mchunk = (int)std::min<long long>(kMediaChunk, std::max<long long>(64, ((n_media + mwaves - 1) / mwaves + 63) / 64 * 64));
+                    hipLaunchKernelGGL(k_vol_media, dim3(blocks), dim3(kBlock), 0, stream, sc, mt, pa, va, q_media, n_media, &dctr->cursor, mchunk);
                     if (timing) timer.end(stream);
                     ++launches;
                 }

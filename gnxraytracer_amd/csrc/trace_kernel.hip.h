@@ -28,7 +28,7 @@ struct TraceWork {
     const int *q_nee; int n_nee;           // paths with an NEE record: two work items each (shadow ray, MIS ray)
 };
 
-constexpr int kTraceChunk = 512;   // rays a wave takes per global atomic
+constexpr int kTraceChunk = 512;   // most rays a wave takes per global atomic (the host shrinks the chunk for thin launches so that every wave gets one)
 #ifndef GX_TRACE_LEAVE_MUL
 #define GX_TRACE_LEAVE_MUL 1
 #endif
@@ -136,7 +136,7 @@ __device__ unsigned long long g_trace_stats[16];
 // reference's binary nodes; the counting runs use WIDE = false so that the counts are those of the reference traversal.
 // SPH: the scene has spheres (a separate instantiation keeps their registers out of the triangle-only kernel).
 template <bool COUNT, bool WIDE, bool SPH>
-__global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, TraceWork w, unsigned int *cursor, Counters *ctr, int lds_entries, int *spill) {
+__global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, TraceWork w, unsigned int *cursor, Counters *ctr, int lds_entries, int *spill, int chunk) {
     extern __shared__ int stack_mem[];   // lds_entries * kBlock ints
     LaneStack stack;
     stack.lds = (lds_int *)&stack_mem[threadIdx.x];
@@ -175,10 +175,10 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
             GX_STAT(8, __popcll(needMask));
             if (poolCount == 0 && !exhausted) {
                 unsigned base = 0;
-                if (lane == 0) base = atomicAdd(cursor, (unsigned)kTraceChunk);
+                if (lane == 0) base = atomicAdd(cursor, (unsigned)chunk);
                 base = __shfl(base, 0);
                 if (base >= total) exhausted = true;
-                else { poolBase = base; poolCount = min((unsigned)kTraceChunk, total - base); }
+                else { poolBase = base; poolCount = min((unsigned)chunk, total - base); }
             }
             if (poolCount > 0) {
                 unsigned rank = (unsigned)__popcll(needMask & ((1ull << lane) - 1ull));

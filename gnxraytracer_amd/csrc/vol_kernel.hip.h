@@ -77,9 +77,9 @@ GX_DEV int hit_medium(const DScene &sc, const DMediaTables &mt, int leaf, int ra
 // Medium::Sample (state VS_MAIN) / Medium::Tr (VS_SHADOW, VS_MIS) for the rays that travel inside a medium.
 // `queue` lists those paths (pflags bit1 of the previous step, compacted).  Persistent waves; a lane runs one tracking
 // loop and refills from the wave's pool when it ends.  Results: va.mres[path], and the path's stream position va.vs[path].y.
-constexpr int kMediaChunk = 256;   // paths a wave takes per global atomic
+constexpr int kMediaChunk = 256;   // most paths a wave takes per global atomic (smaller for thin launches, chosen by the host)
 
-__global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt, PathArrays pa, VolArrays va, const int *__restrict__ queue, int n, unsigned int *cursor) {
+__global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt, PathArrays pa, VolArrays va, const int *__restrict__ queue, int n, unsigned int *cursor, int chunk) {
     const int lane = __lane_id();
     const unsigned total = (unsigned)n;
     unsigned poolBase = 0, poolCount = 0;
@@ -98,10 +98,10 @@ __global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt
         if (needMask) {
             if (poolCount == 0 && !exhausted) {
                 unsigned base = 0;
-                if (lane == 0) base = atomicAdd(cursor, (unsigned)kMediaChunk);
+                if (lane == 0) base = atomicAdd(cursor, (unsigned)chunk);
                 base = __shfl(base, 0);
                 if (base >= total) exhausted = true;
-                else { poolBase = base; poolCount = min((unsigned)kMediaChunk, total - base); }
+                else { poolBase = base; poolCount = min((unsigned)chunk, total - base); }
             }
             if (poolCount > 0) {
                 unsigned rank = (unsigned)__popcll(needMask & ((1ull << lane) - 1ull));
