@@ -13,7 +13,11 @@ therefore renders the full 1024 spp image and `wall_to_1024spp_s` is measured, n
 
 With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) image rows are interleaved over
 the ranks, no collective runs during rendering, and the final FrameBuffer is gathered to rank 0 with one
-RCCL gather inside the timed region.  value = rays traced by all ranks / max-over-ranks time.
+RCCL gather inside the timed region.  value = rays traced by all ranks / max-over-ranks time.  A rank owns
+1/N of the rows, so it submits N consecutive steps to the library as one pass (`steps_per_pass` in the
+JSON): the same samples of the same pixels with the same results, batched so that its kernel launches stay
+as thick as the single-GPU ones (measured on one GPU with rank 0's share: 75 % -> ~95 % per-rank efficiency
+at N = 8, tests/dev_shard_eff.py).
 
 Ray = one Scene::Intersect or Scene::IntersectP query (closest-hit, shadow and MIS rays), the unit the
 reference was profiled in.
@@ -45,6 +49,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--save-image", type=str, default="")
+    ap.add_argument("--fuse-steps", type=int, default=0, help="steps a rank submits as one pass (default: the number of ranks)")
     ap.add_argument("--workload", choices=["cfg3", "cfg5"], default="cfg3",
                     help="cfg3 (default, the headline metric) or cfg5: VolPathIntegrator + GridDensityMedium + HomogeneousMedium 512x512 @256spp")
     args = ap.parse_args()
@@ -117,16 +122,24 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     sps = args.spp_per_step
 
-    def step(i):
+    # With N ranks a rank owns 1/N of the rows, so one step is an N times thinner pass; a rank therefore submits up to N
+    # consecutive steps to the library as ONE pass (same samples, same pixels, same results -- only the batching differs),
+    # which keeps its kernel launches as thick as the single-GPU ones.  Exactly `steps` x `spp_per_step` samples of every
+    # pixel are rendered inside the timed region either way.
+    fuse = args.fuse_steps if args.fuse_steps > 0 else world
+
+    def step(i, g=1):
+        """steps i .. i+g-1 (g may shrink at the end of the Halton sample range); returns (stats, steps done)"""
         s0 = (i * sps) % args.spp
-        s1 = min(s0 + sps, args.spp)
+        s1 = min(s0 + g * sps, args.spp)
+        done = max(1, (s1 - s0 + sps - 1) // sps)
         st = integ.RenderDevice(scene, out.data_ptr(), W, H, args.spp, stream=stream, spp_begin=s0, spp_end=s1,
-                                samples_per_pass=sps, **shard)
+                                samples_per_pass=s1 - s0, **shard)
         acc.add_(out)
-        return st
+        return st, done
 
     for i in range(args.warmup):
-        step(i)
+        step(i, fuse)
     acc.zero_()
     if not args.no_kernel_timing:
         gx.lib().gnxr_set_profiling(1)
@@ -141,8 +154,10 @@ def main():
                launches_nee=0, rays_closest_nee=0, camera_samples=0, kernel_launches=0)
     sync()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        st = step(i)
+    i = 0
+    while i < args.steps:
+        st, done = step(i, min(fuse, args.steps - i))
+        i += done
         for k in tot:
             tot[k] += st[k]
     # final FrameBuffer gather: each rank owns rows y with y % world == rank (one RCCL gather, timed)
@@ -189,7 +204,7 @@ def main():
                                f"VolPathIntegrator maxDepth {args.max_depth} rr 1 spatial, Halton({args.spp}), {W}x{H}" if args.workload == "cfg5" else
                                f"cfg3: Cornell + synthetic {args.tris}-tri mesh (stand-in for absent dragon.3d), Glass+Metal, "
                                f"PathIntegrator maxDepth {args.max_depth} rr 1 spatial, Halton({args.spp}), {W}x{H}",
-                   "spp_per_step": sps, "spp_rendered": spp_done, "sharding": f"rows y % {world} == rank" if world > 1 else "none",
+                   "spp_per_step": sps, "steps_per_pass": fuse, "spp_rendered": spp_done, "sharding": f"rows y % {world} == rank" if world > 1 else "none",
                    "gather": "RCCL gather of row shards to rank 0 (in timed region)" if world > 1 else "n/a"},
         "wall_to_1024spp_s": dt_max * (1024.0 / spp_done),
         "wall_to_full_spp_s": dt_max * (float(args.spp) / spp_done),
