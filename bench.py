@@ -91,17 +91,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # GNXR_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: ranks share the visible devices and
+    # the collectives run on host copies.  The measured configuration is always nccl (= RCCL), one rank per GPU.
+    backend = os.environ.get("GNXR_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     import gnxraytracer_amd as gx
     import scenes
 
-    gx.init(local_rank)
+    gx.init(dev_index)
     W, H = args.width, args.height
     # every rank builds the same scene (replicated: ~12 MB of tables); rank 0 writes the mesh file once
     mesh_path = os.path.join(ROOT, "gpurun_out", "_meshes", f"synthetic_dragon_{args.tris}_1.3d")
@@ -163,15 +171,15 @@ def main():
     # final FrameBuffer gather: each rank owns rows y with y % world == rank (one RCCL gather, timed)
     if world > 1:
         from gnxraytracer_amd.distributed import gather_framebuffer
-        full = gather_framebuffer(acc, rank, world, 1, dst=0)
+        full = gather_framebuffer(acc.to(coll_dev), rank, world, 1, dst=0)
         if rank == 0:
-            acc = full
+            acc = full.to(dev)
     sync()
     dt = time.perf_counter() - t0
     gx.lib().gnxr_set_profiling(0)
 
     rays = tot["rays_closest"] + tot["rays_any"]
-    tvec = torch.tensor([dt, float(rays), float(tot["rays_closest"]), float(tot["rays_any"])], dtype=torch.float64, device=dev)
+    tvec = torch.tensor([dt, float(rays), float(tot["rays_closest"]), float(tot["rays_any"])], dtype=torch.float64, device=coll_dev)
     if world > 1:
         tmax = tvec.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
