@@ -59,6 +59,7 @@ struct CompiledScene {
     bool has_env = false;
     DEnv env;
     std::vector<float> env_texels;       // Lmap level 0, rgb
+    float env_power_lookup[3] = {0, 0, 0};   // Lmap->Lookup((.5,.5), .5), for InfiniteAreaLight::Power
     std::vector<float> env_cond_func, env_cond_cdf, env_cond_int;   // Distribution2D conditional rows
     std::vector<float> env_marg_func, env_marg_cdf;
     // media

@@ -567,6 +567,48 @@ static void build_env(const gnxr_scene_desc *d, const gnxr_light &l, bool flip_y
         rx = px; ry = py;
     }
     cs->env_texels = tex;
+    // InfiniteAreaLight::Power = Pi r^2 Lmap->Lookup((.5, .5), .5) (InfiniteAreaLight.cpp:84-89): the only consumer of the upper
+    // MIP levels (MIPMap.h:147-170 box-filter pyramid, :225-242 Lookup, :244-256 triangle).  Only the "power" light
+    // strategy reads it.
+    {
+        std::vector<std::vector<float>> pyr;
+        std::vector<int> lw, lh;
+        pyr.push_back(tex); lw.push_back(rx); lh.push_back(ry);
+        int nLevels = 1;
+        for (int m = std::max(rx, ry); m > 1; m >>= 1) ++nLevels;
+        auto tx = [&](int level, int s_, int t_, int c) { return pyr[level][((size_t)modi(t_, lh[level]) * lw[level] + modi(s_, lw[level])) * 3 + c]; };
+        for (int i = 1; i < nLevels; ++i) {
+            int sRes = std::max(1, lw[i - 1] / 2), tRes = std::max(1, lh[i - 1] / 2);
+            std::vector<float> lvl((size_t)sRes * tRes * 3);
+            for (int t = 0; t < tRes; ++t)
+                for (int s_ = 0; s_ < sRes; ++s_)
+                    for (int c = 0; c < 3; ++c)
+                        lvl[((size_t)t * sRes + s_) * 3 + c] = .25f * (tx(i - 1, 2 * s_, 2 * t, c) + tx(i - 1, 2 * s_ + 1, 2 * t, c) + tx(i - 1, 2 * s_, 2 * t + 1, c) +
+                                                                      tx(i - 1, 2 * s_ + 1, 2 * t + 1, c));
+            pyr.push_back(std::move(lvl)); lw.push_back(sRes); lh.push_back(tRes);
+        }
+        auto triangle = [&](int level, float sx, float ty, float *out) {
+            level = std::min(std::max(level, 0), nLevels - 1);
+            float s_ = sx * lw[level] - 0.5f, t_ = ty * lh[level] - 0.5f;
+            int s0 = (int)std::floor(s_), t0 = (int)std::floor(t_);
+            float ds = s_ - s0, dt = t_ - t0;
+            for (int c = 0; c < 3; ++c)
+                out[c] = (1 - ds) * (1 - dt) * tx(level, s0, t0, c) + (1 - ds) * dt * tx(level, s0, t0 + 1, c) + ds * (1 - dt) * tx(level, s0 + 1, t0, c) +
+                         ds * dt * tx(level, s0 + 1, t0 + 1, c);
+        };
+        const float invLog2 = 1.442695040888963387004650940071f;
+        float level = nLevels - 1 + std::log(std::max(.5f, 1e-8f)) * invLog2;
+        float *out = cs->env_power_lookup;
+        if (level < 0) triangle(0, .5f, .5f, out);
+        else if (level >= nLevels - 1) { for (int c = 0; c < 3; ++c) out[c] = tx(nLevels - 1, 0, 0, c); }
+        else {
+            int iLevel = (int)std::floor(level);
+            float delta = level - iLevel, a[3], b[3];
+            triangle(iLevel, .5f, .5f, a);
+            triangle(iLevel + 1, .5f, .5f, b);
+            for (int c = 0; c < 3; ++c) out[c] = (1 - delta) * a[c] + delta * b[c];
+        }
+    }
     DEnv &e = cs->env;
     memset(&e, 0, sizeof(e));
     e.w = rx; e.h = ry; e.dw = 2 * rx; e.dh = 2 * ry;
@@ -878,7 +920,11 @@ void build_light_grid(const CompiledScene &cs, int strategy, DLightGrid *grid, s
                 float rgb[3];
                 for (int c = 0; c < 3; ++c) rgb[c] = s * l.le[c] * l.area * kPi;
                 power[i] = 0.212671f * rgb[0] + 0.715160f * rgb[1] + 0.072169f * rgb[2];
-            } else power[i] = 0;  // SkyBox Power() = 0; InfiniteAreaLight::Power needs the MIP pyramid (not built)
+            } else if (l.type == GNXR_LIGHT_INFINITE && cs.has_env) {   // InfiniteAreaLight::Power, InfiniteAreaLight.cpp:84-89
+                float k = kPi * cs.env.world_radius * cs.env.world_radius;
+                float rgb[3] = {k * cs.env_power_lookup[0], k * cs.env_power_lookup[1], k * cs.env_power_lookup[2]};
+                power[i] = 0.212671f * rgb[0] + 0.715160f * rgb[1] + 0.072169f * rgb[2];
+            } else power[i] = 0;  // SkyBoxLight::Power() = 0
         }
         table->assign(grid->stride, 0.f);
         write_dist(power.data(), table->data());

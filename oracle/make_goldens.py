@@ -187,6 +187,9 @@ def main():
         imgs[name + "_cfg"] = np.array([W, H, spp, 8], np.int32)
     img, cnt = render(cornell_path, 64, 64, 8, strat=1)
     imgs["cornell_uniform"], imgs["cornell_uniform_rays"], imgs["cornell_uniform_cfg"] = img, cnt, np.array([64, 64, 8, 8], np.int32)
+    # "power" light strategy with an InfiniteAreaLight: pins InfiniteAreaLight::Power (upper MIP levels of Lmap)
+    img, cnt = render(env_path, 64, 64, 8, strat=2)
+    imgs["cornell_env_power"], imgs["cornell_env_power_rays"], imgs["cornell_env_power_cfg"] = img, cnt, np.array([64, 64, 8, 8], np.int32)
     save("render.npz", **imgs)
     # ---- 11: VolPathIntegrator (cfg 5).  The reference's density grid travels as a data fixture; the two volume
     # scenes keep sigma_t small enough that no sample reaches Halton dimension 1000 (reference UB beyond).

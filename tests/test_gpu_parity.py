@@ -139,11 +139,11 @@ def _render_case(gpu, name):
     else:
         b = scenes.cornell(sky=True)
         b.AddInfLight(os.path.join(GOLDEN, "env_100x50.hdr"))
-    integ = gpu.PathIntegrator(depth, 1.0, "uniform" if name == "cornell_uniform" else "spatial")
+    integ = gpu.PathIntegrator(depth, 1.0, {"cornell_uniform": "uniform", "cornell_env_power": "power"}.get(name, "spatial"))
     return b, integ, (W, H, spp), g[name], tuple(int(v) for v in g[name + "_rays"])
 
 
-@pytest.mark.parametrize("name", ["cornell", "zoo", "mesh2k", "cornell_env", "cornell_uniform"])
+@pytest.mark.parametrize("name", ["cornell", "zoo", "mesh2k", "cornell_env", "cornell_uniform", "cornell_env_power"])
 def test_render_matches_reference_images(gpu, name):
     b, integ, (W, H, spp), ref_img, ref_rays = _render_case(gpu, name)
     img, st = integ.Render(gpu.Scene(b), W, H, spp)

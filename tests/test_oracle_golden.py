@@ -115,7 +115,7 @@ def test_env_and_skybox_lights():
         assert biteq(osc.light_le(li, g[nm + "_rays"]), g[nm + "_le"]), nm
 
 
-@pytest.mark.parametrize("name", ["cornell", "zoo", "mesh2k", "cornell_env", "cornell_uniform"])
+@pytest.mark.parametrize("name", ["cornell", "zoo", "mesh2k", "cornell_env", "cornell_uniform", "cornell_env_power"])
 def test_render_images(name, gx):
     g = golden("render.npz")
     W, H, spp, depth = (int(v) for v in g[name + "_cfg"])
@@ -128,7 +128,7 @@ def test_render_images(name, gx):
     else:
         b = scenes.cornell(sky=True)
         b.AddInfLight(os.path.join(GOLDEN, "env_100x50.hdr"))
-    integ = gx.PathIntegrator(depth, 1.0, "uniform" if name == "cornell_uniform" else "spatial")
+    integ = gx.PathIntegrator(depth, 1.0, {"cornell_uniform": "uniform", "cornell_env_power": "power"}.get(name, "spatial"))
     img, st = ol.OracleScene(b).render(integ, W, H, spp)
     assert (st["rays_closest"], st["rays_any"]) == tuple(int(v) for v in g[name + "_rays"])
     assert biteq(img, g[name])
