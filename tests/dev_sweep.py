@@ -6,7 +6,6 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import gnxraytracer_amd as gx, oracle_lib as ol, scenes
 from conftest import GOLDEN
-gx.init(0)
 def env():
     b = scenes.cornell(sky=True); b.AddInfLight(os.path.join(GOLDEN, "env_100x50.hdr")); return b
 SCENES = {
@@ -17,30 +16,38 @@ SCENES = {
     "vol_synth": lambda: scenes.volume_cornell(sigma_a=(0.5,) * 3, sigma_s=(3.5,) * 3, g_grid=0.3),
     "vol_cfg5_thin": lambda: scenes.volume_cornell_cfg5(0.05), "vol_sphere": lambda: scenes.cornell_sphere("medium"),
 }
-rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
-ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-bad = 0
-names = list(SCENES)
-for c in range(ncase):
-    name = names[c % len(names)]
-    b = SCENES[name]()
-    vol = name.startswith("vol")
-    kind = "volpath" if vol else rng.choice(["path", "path", "whitted"]) if "env" not in name or True else "path"
-    depth = int(rng.integers(1, 11)); rr = float(rng.choice([0.25, 1.0, 4.0])); strat = str(rng.choice(["spatial", "uniform", "power"]))
-    W, H = int(rng.integers(17, 90)), int(rng.integers(17, 90)); spp = int(rng.choice([4, 8, 16, 64]))
-    s0 = int(rng.integers(0, spp)); s1 = int(rng.integers(s0 + 1, spp + 1))
-    shards = int(rng.choice([1, 1, 2, 3])); sr = int(rng.choice([1, 2, 5])); si = int(rng.integers(0, shards))
-    spp_pass = int(rng.choice([0, 1, 3]))
-    if kind == "whitted": integ = gx.WhittedIntegrator(min(depth, 6))
-    elif kind == "volpath": integ = gx.VolPathIntegrator(depth, rr, strat)
-    else: integ = gx.PathIntegrator(depth, rr, strat)
-    kw = dict(spp_begin=s0, spp_end=s1, shard_index=si, shard_count=shards, shard_rows=sr)
-    t0 = time.time()
-    img, st = integ.Render(gx.Scene(b), W, H, spp, samples_per_pass=spp_pass, **kw)
-    oimg, ost = ol.OracleScene(b).render(integ, W, H, spp, **kw)
-    ok = (img[..., :3].view(np.uint32) == oimg[..., :3].view(np.uint32)).all() and (st["rays_closest"], st["rays_any"]) == (ost["rays_closest"], ost["rays_any"])
-    frac = (img[..., :3].view(np.uint32) == oimg[..., :3].view(np.uint32)).mean()
-    bad += 0 if ok else 1
-    print(f"{'ok ' if ok else 'BAD'} {name:15s} {kind:8s} depth {depth:2d} rr {rr:4.2f} {strat:8s} {W}x{H} spp {spp} [{s0},{s1}) shard {si}/{shards}x{sr} pass {spp_pass}  identical {frac*100:.3f}% "
-          f"rays {st['rays_closest']}/{st['rays_any']} vs {ost['rays_closest']}/{ost['rays_any']}  {time.time()-t0:.1f}s", flush=True)
-print("mismatching cases:", bad, "of", ncase)
+def run_sweep(seed=1, ncase=40, verbose=True):
+    """returns the list of mismatching case descriptions"""
+    rng = np.random.default_rng(seed)
+    bad = []
+    names = list(SCENES)
+    for c in range(ncase):
+        name = names[c % len(names)]
+        b = SCENES[name]()
+        vol = name.startswith("vol")
+        kind = "volpath" if vol else str(rng.choice(["path", "path", "whitted"]))
+        depth = int(rng.integers(1, 11)); rr = float(rng.choice([0.25, 1.0, 4.0])); strat = str(rng.choice(["spatial", "uniform", "power"]))
+        W, H = int(rng.integers(17, 90)), int(rng.integers(17, 90)); spp = int(rng.choice([4, 8, 16, 64]))
+        s0 = int(rng.integers(0, spp)); s1 = int(rng.integers(s0 + 1, spp + 1))
+        shards = int(rng.choice([1, 1, 2, 3])); sr = int(rng.choice([1, 2, 5])); si = int(rng.integers(0, shards))
+        spp_pass = int(rng.choice([0, 1, 3]))
+        if kind == "whitted": integ = gx.WhittedIntegrator(min(depth, 6))
+        elif kind == "volpath": integ = gx.VolPathIntegrator(depth, rr, strat)
+        else: integ = gx.PathIntegrator(depth, rr, strat)
+        kw = dict(spp_begin=s0, spp_end=s1, shard_index=si, shard_count=shards, shard_rows=sr)
+        t0 = time.time()
+        img, st = integ.Render(gx.Scene(b), W, H, spp, samples_per_pass=spp_pass, **kw)
+        oimg, ost = ol.OracleScene(b).render(integ, W, H, spp, **kw)
+        same = img[..., :3].view(np.uint32) == oimg[..., :3].view(np.uint32)
+        ok = bool(same.all()) and (st["rays_closest"], st["rays_any"]) == (ost["rays_closest"], ost["rays_any"])
+        desc = (f"{name:15s} {kind:8s} depth {depth:2d} rr {rr:4.2f} {strat:8s} {W}x{H} spp {spp} [{s0},{s1}) shard {si}/{shards}x{sr} pass {spp_pass}  identical {same.mean()*100:.3f}% "
+                f"rays {st['rays_closest']}/{st['rays_any']} vs {ost['rays_closest']}/{ost['rays_any']}")
+        if not ok: bad.append(desc)
+        if verbose: print(("ok  " if ok else "BAD ") + desc + f"  {time.time()-t0:.1f}s", flush=True)
+    return bad
+
+
+if __name__ == "__main__":
+    gx.init(0)
+    bad = run_sweep(int(sys.argv[1]) if len(sys.argv) > 1 else 1, int(sys.argv[2]) if len(sys.argv) > 2 else 40)
+    print("mismatching cases:", len(bad))

@@ -298,6 +298,14 @@ def test_sphere_matches_oracle(gpu, kind):
     assert biteq(img[..., :3], oimg[..., :3])
 
 
+def test_randomised_sweep_against_oracle(gpu):
+    """30 random (scene, integrator, image size, depth, rr threshold, light strategy, sample range, shard, pass size) cases:
+    images and ray counts equal the oracle's bit for bit (tests/dev_sweep.py runs larger sweeps)."""
+    import dev_sweep
+    bad = dev_sweep.run_sweep(seed=7, ncase=30, verbose=False)
+    assert not bad, bad
+
+
 def test_edge_cases(gpu):
     scene = gpu.Scene(scenes.cornell())
     img, st = gpu.PathIntegrator(0).Render(scene, 8, 8, 2)               # maxDepth 0
