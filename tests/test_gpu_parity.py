@@ -201,6 +201,8 @@ def test_dragon_scene_against_oracle(gpu):
     integ = gpu.PathIntegrator(8, 1.0, "spatial")
     img, st = integ.Render(gpu.Scene(b), 240, 135, 1024, spp_begin=0, spp_end=8)
     oimg, ost = ol.OracleScene(b).render(integ, 240, 135, 1024, spp_begin=0, spp_end=8)
+    # Glass + Metal sample microfacet normals through the double-precision sin / cos of MicroFacet.cpp:220-223 (OCML on the
+    # device, glibc on the host): bit-identical in every run so far, but not restated like the float libm, hence the margin
     r, mx = rmse(img, oimg)
     assert r < RMSE_TOL, (r, mx)
     assert abs(st["rays_closest"] - ost["rays_closest"]) <= RAYS_TOL * ost["rays_closest"]
@@ -230,9 +232,8 @@ def test_volpath_cfg5_density_against_oracle(gpu):
     integ = gpu.VolPathIntegrator(8, 1.0, "spatial")
     img, st = integ.Render(gpu.Scene(b), 96, 96, 256, spp_begin=0, spp_end=8)
     oimg, ost = ol.OracleScene(b).render(integ, 96, 96, 256, spp_begin=0, spp_end=8)
-    r, mx = rmse(img, oimg)
-    assert r < 1e-3, (r, mx)          # north-star bar; a diverged tracking loop changes a whole sample
-    assert abs(st["rays_closest"] - ost["rays_closest"]) <= RAYS_TOL * ost["rays_closest"]
+    assert st["rays_closest"] == ost["rays_closest"]
+    assert biteq(img[..., :3], oimg[..., :3])
     # sharded and sample-range renders recombine exactly
     acc = np.zeros_like(img)
     for rk in range(2):
