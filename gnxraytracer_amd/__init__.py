@@ -165,6 +165,9 @@ class SceneBuilder:
         cam = Camera(_f3(eye), _f3(look), _f3(up), fov, lens_radius, focal_distance)
         _check(lib().gnxr_builder_set_camera(self._h, C.byref(cam)))
 
+    def set_camera_medium(self, medium):
+        _check(lib().gnxr_builder_set_camera_medium(self._h, int(medium)))
+
     def desc(self):
         """gnxr_scene_desc pointing into builder-owned memory (valid until the next builder call)."""
         d = SceneDesc()

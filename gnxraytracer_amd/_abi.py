@@ -115,6 +115,7 @@ PROTOTYPES = {
     "gnxr_framebuffer_update": (C.c_int, [P(f32), P(f32), i32, i32, i32, P(u8)]),
     "gnxr_eval_libm": (C.c_int, [i32, P(f32), P(f32), i64, P(f32)]),
     "gnxr_builder_create": (C.c_int, [P(VP)]),
+    "gnxr_builder_set_camera_medium": (C.c_int, [VP, i32]),
     "gnxr_builder_add_sphere": (C.c_int, [VP, P(f32), f32, i32, i32, i32]),
     "gnxr_builder_destroy": (None, [VP]),
     "gnxr_builder_add_material": (C.c_int, [VP, P(Material)]),

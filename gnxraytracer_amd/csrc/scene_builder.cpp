@@ -553,6 +553,12 @@ int gnxr_builder_set_camera(gnxr_builder *b, const gnxr_camera *cam) {
     return GNXR_OK;
 }
 
+int gnxr_builder_set_camera_medium(gnxr_builder *b, int32_t medium) {
+    if (!b || medium < -1 || medium >= (int)b->b.media.size()) return GNXR_ERR_INVALID;
+    b->b.camera_medium = medium;
+    return GNXR_OK;
+}
+
 int gnxr_builder_desc(gnxr_builder *b, gnxr_scene_desc *out) {
     if (!b || !out) return GNXR_ERR_INVALID;
     b->b.fill_desc(out);

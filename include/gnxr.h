@@ -314,7 +314,8 @@ int gnxr_builder_add_inf_light_data(gnxr_builder *b, const float *rgb, int32_t w
 int gnxr_builder_add_medium(gnxr_builder *b, const gnxr_medium *m, const float *density);
 int gnxr_builder_add_sphere(gnxr_builder *b, const float center[3], float radius, int32_t material, int32_t medium_inside,
                             int32_t medium_outside);                                      /* returns the sphere index */
-int gnxr_builder_set_camera(gnxr_builder *b, const gnxr_camera *cam);                 /* RenderThread.cpp:60-68 */
+int gnxr_builder_set_camera(gnxr_builder *b, const gnxr_camera *cam);
+int gnxr_builder_set_camera_medium(gnxr_builder *b, int32_t medium);                  /* Camera::medium, core/Camera.h; -1 == none */                 /* RenderThread.cpp:60-68 */
 /* The returned description points into builder-owned memory, valid until the next builder
  * call or gnxr_builder_destroy.                                                            */
 int gnxr_builder_desc(gnxr_builder *b, gnxr_scene_desc *out);

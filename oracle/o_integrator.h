@@ -160,7 +160,8 @@ struct RenderContext {
     // LightDistribution::Lookup.  The reference's lock-free hash (LightDistribution.cpp:109-204) only
     // memoises ComputeDistribution per voxel; a dense lazily-filled table returns the same object.
     const Distribution1D *Lookup(const V3 &p) const {
-        if (lightStrategy != GNXR_LIGHTS_SPATIAL) return &uniformOrPower;
+        // no lights: the integrators return before they read the distribution (Integrator.cpp:63-64)
+        if (scene->lights.empty() || lightStrategy != GNXR_LIGHTS_SPATIAL) return &uniformOrPower;
         V3 offset = worldBound.Offset(p);
         int pi[3];
         for (int i = 0; i < 3; ++i) pi[i] = Clamp(int(offset[i] * nVoxels[i]), 0, nVoxels[i] - 1);

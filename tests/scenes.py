@@ -220,3 +220,26 @@ def cornell_sphere(kind="matte", center=(0.6, -1.5, 0.2), radius=1.0):
         mi = b.add_medium(hom)
     b.AddSphere(center, radius, m, medium_inside=mi, medium_outside=-1)
     return b
+
+
+def cornell_no_lights():
+    """walls only: scene.lights is empty (UniformSampleOneLight returns 0, Integrator.cpp:63; Whitted's light loop is empty)."""
+    b = gx.SceneBuilder()
+    white = b.MatteMaterial(WHITE, 60.0)
+    b.AddCornell(b.MatteMaterial(RED, 60.0), b.MatteMaterial(BLUE, 60.0), white)
+    return b
+
+
+def cornell_in_fog():
+    """the camera sits inside a thin HomogeneousMedium bounded by a large null-material box (Camera::medium != nullptr)."""
+    b = cornell()
+    hom = gx.Medium()
+    hom.type = gx._abi.MEDIUM_HOMOGENEOUS
+    hom.sigma_a[:] = (0.02, 0.03, 0.04)
+    hom.sigma_s[:] = (0.10, 0.08, 0.06)
+    hom.g = -0.2
+    m = b.add_medium(hom)
+    v, i = box_mesh((-6.0, -6.0, -6.0), (6.0, 6.0, 8.0))
+    b.add_mesh(v, i, -1, medium_inside=m, medium_outside=-1)
+    b.set_camera_medium(m)
+    return b
