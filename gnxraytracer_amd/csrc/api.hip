@@ -313,6 +313,10 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
         AL(vol_n1) AL(vol_f) AL(vol_Li) AL(vol_Tr) AL(vol_Ld) AL(vol_mres) AL(vol_vs)
 #undef AL
     }
+    {   // global part of k_trace's traversal stacks (the deepest walk either BVH layout can need), sized for a full grid
+        const int entries = std::max(s->cs.stack4_need + 1, s->cs.bvh_max_depth + 2);
+        if ((rc = s->trace_spill.alloc((size_t)g_num_cus * g_trace_blocks_per_cu * kBlock * (size_t)entries)) != GNXR_OK) return rc;
+    }
     if ((rc = s->accum.alloc(r.npix)) != GNXR_OK) return rc;
     const int max_tiles = (int)((cap + kCompactBlock - 1) / kCompactBlock);
     if ((rc = s->tile_counts.alloc((size_t)4 * max_tiles)) != GNXR_OK) return rc;
@@ -366,7 +370,6 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
             size_t lds = (size_t)lds_entries * kBlock * sizeof(int);
             // persistent waves: enough blocks to fill the chip, never more than the work needs
             int blocks = (int)std::min<long long>((long long)g_num_cus * per_cu, (total + kBlock - 1) / kBlock);
-            if (s->trace_spill.alloc((size_t)g_num_cus * per_cu * kBlock * (size_t)std::max(1, entries - lds_entries)) != GNXR_OK) return;
             if (timing) timer.begin(0, stream);
             // rays per atomic: kTraceChunk for big launches; for thin ones (late bounces) small enough that every wave gets a chunk --
             // the number of atomics stays <= the number of waves, well under the ~88/us a single address sustains
