@@ -202,6 +202,15 @@ class Scene:
         return {"bvh_nodes": n.value, "bvh_max_depth": dmax.value, "light_voxels": nv.value}
 
     # Aggregate seam: Scene::Intersect / IntersectP, batched
+    def light_grid_table(self, strategy="spatial", on_host=False):
+        """Test hook: the light-selection table (device-built or host-built)."""
+        code = {"spatial": _abi.LIGHTS_SPATIAL, "uniform": _abi.LIGHTS_UNIFORM, "power": _abi.LIGHTS_POWER}[strategy]
+        n = C.c_int64(0)
+        _check(lib().gnxr_light_grid_table(self._h, code, int(on_host), None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.float32)
+        _check(lib().gnxr_light_grid_table(self._h, code, int(on_host), out.ctypes.data_as(C.POINTER(C.c_float)), n.value, C.byref(n)))
+        return out
+
     def Intersect(self, rays):
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 8)
         hits = np.zeros(len(rays), dtype=HIT_DTYPE)

@@ -176,13 +176,32 @@ struct gnxr_scene {
         m.tri_media = cs.tri_media.empty() ? nullptr : reinterpret_cast<const int2 *>(tri_media.p);
         return m;
     }
-    int ensure_grid(int strategy) {
-        if (grid_strategy == strategy) return GNXR_OK;
+    // light-selection table (core/LightDistribution.cpp).  The spatial strategy's dense voxel table is filled on the device
+    // (k_light_grid, ~1 ms instead of ~1 s of host threads for 64^3 voxels); GNXR_HOST_LIGHT_GRID=1 forces the host
+    // restatement, which produces the same bits (tests/test_gpu_parity.py::test_light_grid_device_equals_host).
+    int ensure_grid(int strategy, bool force_host = false) {
+        if (grid_strategy == strategy && !force_host) return GNXR_OK;
+        const int nl = (int)cs.desc_lights.size();
+        const bool on_device = strategy == GNXR_LIGHTS_SPATIAL && nl >= 2 && nl <= kGridMaxLights && !force_host && getenv("GNXR_HOST_LIGHT_GRID") == nullptr;
         std::vector<float> table;
-        build_light_grid(cs, strategy, &grid, &table);
-        int rc = grid_table.upload(table);
-        if (rc) return rc;
-        grid_strategy = strategy;
+        build_light_grid(cs, strategy, &grid, &table, on_device);
+        int rc;
+        if (on_device) {
+            const size_t nv = (size_t)grid.nvox[0] * grid.nvox[1] * grid.nvox[2];
+            if ((rc = grid_table.alloc(nv * grid.stride)) != GNXR_OK) return rc;
+            float ri[5 * 128];
+            light_grid_probes(cs, ri);
+            DevBuf<float> d_ri;
+            if ((rc = d_ri.upload(ri, 5 * 128)) != GNXR_OK) return rc;
+            DLightTables lt = device_scene(1, 1).lt;
+            bool area_only = true;
+            for (const gnxr_light &l : cs.desc_lights) if (l.type != GNXR_LIGHT_AREA_TRI) area_only = false;
+            const int blocks = (int)std::min<size_t>((nv + kBlock - 1) / kBlock, (size_t)g_num_cus * 8);
+            if (area_only) hipLaunchKernelGGL((k_light_grid<LT_AREA>), dim3(blocks), dim3(kBlock), 0, 0, lt, grid, (const float *)d_ri.p, grid_table.p);
+            else hipLaunchKernelGGL((k_light_grid<LT_ALL>), dim3(blocks), dim3(kBlock), 0, 0, lt, grid, (const float *)d_ri.p, grid_table.p);
+            HIP_TRY(hipDeviceSynchronize());
+        } else if ((rc = grid_table.upload(table)) != GNXR_OK) return rc;
+        grid_strategy = force_host ? -1 : strategy;
         return GNXR_OK;
     }
 };
@@ -643,6 +662,17 @@ int gnxr_camera_rays(const gnxr_camera *cam, int32_t width, int32_t height, cons
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(o_out, dob.p, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(d_out, dd.p, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
+    return GNXR_OK;
+}
+
+int gnxr_light_grid_table(gnxr_scene *s, int32_t strategy, int32_t on_host, float *out, int64_t capacity, int64_t *n_floats) {
+    if (!s || !n_floats) { set_error("null argument"); return GNXR_ERR_INVALID; }
+    std::lock_guard<std::mutex> lock(s->render_mutex);
+    int rc = s->ensure_grid(strategy, on_host != 0);
+    if (rc) return rc;
+    const int64_t n = (int64_t)s->grid.nvox[0] * s->grid.nvox[1] * s->grid.nvox[2] * s->grid.stride;
+    *n_floats = n;
+    if (out && capacity >= n) HIP_TRY(hipMemcpy(out, s->grid_table.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     return GNXR_OK;
 }
 

@@ -80,7 +80,8 @@ bool compile_scene(const gnxr_scene_desc *d, CompiledScene *out);
 DCamera make_camera(const gnxr_camera &c, int W, int H, int medium);      // camera/Perspective.cpp:114-135, core/Camera.h:54-75
 DHalton make_halton(int W, int H);                                          // samplers/HaltonSampler.cpp:33-60
 // light-selection table: dense restatement of core/LightDistribution.cpp (uniform / power / spatial)
-void build_light_grid(const CompiledScene &cs, int strategy, DLightGrid *grid, std::vector<float> *table);
+void build_light_grid(const CompiledScene &cs, int strategy, DLightGrid *grid, std::vector<float> *table, bool layout_only = false);
+void light_grid_probes(const CompiledScene &cs, float *ri /* [5][128] */);
 
 // host restatements used by probes and the light grid
 float host_radical_inverse(const CompiledScene &cs, int baseIndex, uint64_t a);

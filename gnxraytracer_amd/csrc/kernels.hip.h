@@ -415,6 +415,63 @@ __global__ void k_camera_probe(DSamplerTables st, DCamera cam, const int *px, co
     }
 }
 
+// SpatialLightDistribution::ComputeDistribution (core/LightDistribution.cpp:206-274) for every voxel at scene set-up: the
+// reference fills voxels lazily from the render threads; here one lane per voxel evaluates the 128 probe points x all lights
+// with the same light_sample<> the integrator uses, and writes the voxel's Distribution1D (cdf[1..n], func[0..n-1], funcInt).
+constexpr int kGridMaxLights = 16;
+template <int LT>
+__global__ void __launch_bounds__(kBlock) k_light_grid(DLightTables lt, DLightGrid g, const float *__restrict__ ri, float *__restrict__ table) {
+    const int nl = g.n_lights;
+    const long long nv = (long long)g.nvox[0] * g.nvox[1] * g.nvox[2];
+    for (long long idx = blockIdx.x * blockDim.x + threadIdx.x; idx < nv; idx += (long long)gridDim.x * blockDim.x) {
+        const int z = (int)(idx % g.nvox[2]), y = (int)((idx / g.nvox[2]) % g.nvox[1]), x = (int)(idx / ((long long)g.nvox[2] * g.nvox[1]));
+        V3 p0((float)x / (float)g.nvox[0], (float)y / (float)g.nvox[1], (float)z / (float)g.nvox[2]);
+        V3 p1((float)(x + 1) / (float)g.nvox[0], (float)(y + 1) / (float)g.nvox[1], (float)(z + 1) / (float)g.nvox[2]);
+        V3 lo(g.lo[0], g.lo[1], g.lo[2]), hi(g.hi[0], g.hi[1], g.hi[2]);
+        V3 a(lerpf(p0.x, lo.x, hi.x), lerpf(p0.y, lo.y, hi.y), lerpf(p0.z, lo.z, hi.z));   // Bounds3::Lerp
+        V3 b(lerpf(p1.x, lo.x, hi.x), lerpf(p1.y, lo.y, hi.y), lerpf(p1.z, lo.z, hi.z));
+        V3 vlo(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)), vhi(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z));
+        float contrib[kGridMaxLights];
+        for (int j = 0; j < kGridMaxLights; ++j) contrib[j] = 0.f;
+        for (int i = 0; i < 128; ++i) {
+            V3 po(lerpf(ri[i], vlo.x, vhi.x), lerpf(ri[128 + i], vlo.y, vhi.y), lerpf(ri[256 + i], vlo.z, vhi.z));
+            const float u0 = ri[384 + i], u1 = ri[512 + i];
+#pragma unroll
+            for (int j = 0; j < kGridMaxLights; ++j) {
+                if (j < nl) {
+                    LightSample ls = light_sample<LT>(lt, j, po, u0, u1);
+                    if (ls.pdf > 0) contrib[j] += ls.Li.y() / ls.pdf;
+                }
+            }
+        }
+        float sum = 0;
+#pragma unroll
+        for (int j = 0; j < kGridMaxLights; ++j) if (j < nl) sum += contrib[j];
+        const float avg = sum / (float)(128 * nl);
+        const float minC = (avg > 0) ? (float)(.001 * (double)avg) : 1.f;
+        float *dst = table + (size_t)idx * g.stride;
+        // Distribution1D ctor, Sampling.h:22-35
+        float cdf[kGridMaxLights + 1];
+        cdf[0] = 0;
+#pragma unroll
+        for (int j = 0; j < kGridMaxLights; ++j) {
+            if (j < nl) { contrib[j] = fmaxf(contrib[j], minC); cdf[j + 1] = cdf[j] + contrib[j] / (float)nl; }
+            else cdf[j + 1] = cdf[j];
+        }
+        float funcInt = 0;
+#pragma unroll
+        for (int j = 0; j < kGridMaxLights; ++j) if (j + 1 == nl) funcInt = cdf[j + 1];
+#pragma unroll
+        for (int j = 0; j < kGridMaxLights; ++j) {
+            if (j < nl) {
+                dst[j] = (funcInt == 0) ? (float)(j + 1) / (float)nl : cdf[j + 1] / funcInt;
+                dst[nl + j] = contrib[j];
+            }
+        }
+        dst[2 * nl] = funcInt;
+    }
+}
+
 // test hook: the device's float libm (device_math.h) on caller-supplied arguments
 __global__ void k_libm_probe(int fn, const float *x, const float *x2, long long n, float *out) {
     for (long long i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {

@@ -887,7 +887,7 @@ static float light_contrib(const CompiledScene &cs, int j, Vec3 ref, float u0, f
 }
 }  // namespace
 
-void build_light_grid(const CompiledScene &cs, int strategy, DLightGrid *grid, std::vector<float> *table) {
+void build_light_grid(const CompiledScene &cs, int strategy, DLightGrid *grid, std::vector<float> *table, bool layout_only) {
     int nl = (int)cs.desc_lights.size();
     memset(grid, 0, sizeof(*grid));
     grid->n_lights = nl;
@@ -936,7 +936,8 @@ void build_light_grid(const CompiledScene &cs, int strategy, DLightGrid *grid, s
     float bmax = diag[cs.world_bound.max_extent()];
     for (int i = 0; i < 3; ++i) grid->nvox[i] = std::max(1, int(std::round(diag[i] / bmax * 64)));
     size_t nv = (size_t)grid->nvox[0] * grid->nvox[1] * grid->nvox[2];
-    table->assign(nv * grid->stride, 0.f);
+    table->assign(layout_only ? 1 : nv * grid->stride, 0.f);
+    if (layout_only) return;   // the device fills the table (k_light_grid)
     // the 128 probe points of ComputeDistribution, LightDistribution.cpp:226-234
     const int nSamples = 128;
     float ri[5][nSamples];
@@ -973,6 +974,12 @@ void build_light_grid(const CompiledScene &cs, int strategy, DLightGrid *grid, s
     std::vector<std::thread> pool;
     for (int t = 0; t < nthreads; ++t) pool.emplace_back(work, nvx * t / nthreads, nvx * (t + 1) / nthreads);
     for (auto &t : pool) t.join();
+}
+
+// RadicalInverse(k, i), k = 0..4, i = 0..127: the probe points / light samples of ComputeDistribution (LightDistribution.cpp:226-234)
+void light_grid_probes(const CompiledScene &cs, float *ri /* [5][128] */) {
+    for (int i = 0; i < 128; ++i)
+        for (int k = 0; k < 5; ++k) ri[k * 128 + i] = host_radical_inverse(cs, k, i);
 }
 
 }  // namespace gnxr

@@ -274,6 +274,11 @@ int gnxr_sample_halton(int32_t width, int32_t height, const int32_t *px, const i
 int gnxr_camera_rays(const gnxr_camera *cam, int32_t width, int32_t height, const int32_t *px,
                      const int32_t *py, const int64_t *s, int64_t n, float *o_out, float *d_out);
 
+/* Unit-test hook: the light-selection table of `strategy` (core/LightDistribution.cpp; per voxel cdf[1..n], func[0..n-1],
+ * funcInt), built on the device (on_host == 0) or by the host restatement (on_host != 0).  *n_floats receives the table
+ * size; the table is copied when `out` has room for it. */
+int gnxr_light_grid_table(gnxr_scene *s, int32_t strategy, int32_t on_host, float *out, int64_t capacity, int64_t *n_floats);
+
 /* Unit-test hook: the device's float libm on caller-supplied arguments.  fn: 0 logf, 1 expf, 2 sinf, 3 cosf, 4 / 5 sinf / cosf
  * through the shared-reduction pair evaluation, 6 acosf, 7 atan2f(x, x2) (x2 may be NULL otherwise).  The
  * reference reaches these through std::log / std::exp / std::sin / std::cos on floats (core/Sampling.cpp:87-105,

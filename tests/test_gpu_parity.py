@@ -299,6 +299,24 @@ def test_sphere_matches_oracle(gpu, kind):
     assert biteq(img[..., :3], oimg[..., :3])
 
 
+@pytest.mark.parametrize("name", ["cornell", "env", "mesh"])
+def test_light_grid_device_equals_host(gpu, name):
+    """SpatialLightDistribution::ComputeDistribution for all voxels: the device kernel and the host restatement (which the
+    golden images pinned in earlier builds) produce the same table, bit for bit."""
+    if name == "cornell":
+        b = scenes.cornell()
+    elif name == "env":
+        b = scenes.cornell(sky=True)
+        b.AddInfLight(os.path.join(GOLDEN, "env_100x50.hdr"))
+    else:
+        b = _scene("mesh2k")
+    scene = gpu.Scene(b)
+    dev = scene.light_grid_table("spatial", on_host=False)
+    host = scene.light_grid_table("spatial", on_host=True)
+    assert dev.size == host.size and dev.size > 1000
+    assert biteq(dev, host)
+
+
 def test_randomised_sweep_against_oracle(gpu):
     """30 random (scene, integrator, image size, depth, rr threshold, light strategy, sample range, shard, pass size) cases:
     images and ray counts equal the oracle's bit for bit (tests/dev_sweep.py runs larger sweeps)."""
