@@ -324,7 +324,7 @@ def eval_libm(fn, x, x2=None):
     if x2 is not None:
         x2 = np.ascontiguousarray(x2, dtype=np.float32)
         p2 = x2.ctypes.data_as(C.POINTER(C.c_float))
-    code = {"log": 0, "exp": 1, "sin": 2, "cos": 3, "sincos.sin": 4, "sincos.cos": 5, "acos": 6, "atan2": 7}[fn]
+    code = {"log": 0, "exp": 1, "sin": 2, "cos": 3, "sincos.sin": 4, "sincos.cos": 5, "acos": 6, "atan2": 7, "pow": 8}[fn]
     _check(lib().gnxr_eval_libm(code, x.ctypes.data_as(C.POINTER(C.c_float)), p2, x.size, out.ctypes.data_as(C.POINTER(C.c_float))))
     return out
 

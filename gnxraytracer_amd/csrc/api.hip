@@ -677,7 +677,7 @@ int gnxr_light_grid_table(gnxr_scene *s, int32_t strategy, int32_t on_host, floa
 }
 
 int gnxr_eval_libm(int32_t fn, const float *x, const float *x2, int64_t n, float *out) {
-    if (!x || !out || n < 0 || fn < 0 || fn > 7 || (fn == 7 && !x2)) { set_error("bad argument"); return GNXR_ERR_INVALID; }
+    if (!x || !out || n < 0 || fn < 0 || fn > 8 || (fn >= 7 && !x2)) { set_error("bad argument"); return GNXR_ERR_INVALID; }
     int rc = ensure_device();
     if (rc) return rc;
     if (n == 0) return GNXR_OK;

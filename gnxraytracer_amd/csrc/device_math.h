@@ -37,7 +37,7 @@ static constexpr float GX_SHADOW_EPS = 0.0001f;
 // which GCC contracts a * b + c wherever every use of the product is an addition or subtraction; the explicit fma()
 // calls below are exactly those contractions (the plain products are the ones GCC leaves alone), e.g. in expf both
 // kd = z + Shift and r = z - kd take the unrounded product z = InvLn2N * x.
-// tan (host-side camera set-up only) and pow (Disney clearcoat sampling only) still go through double OCML.
+// powf is restated further below; tan is used by the host-side camera set-up only.
 __device__ static const double gx_logf_invc[16] = {
     0x1.661ec79f8f3bep+0, 0x1.571ed4aaf883dp+0, 0x1.49539f0f010bp+0, 0x1.3c995b0b80385p+0, 0x1.30d190c8864a5p+0, 0x1.25e227b0b8eap+0,
     0x1.1bb4a4a1a343fp+0, 0x1.12358f08ae5bap+0, 0x1.0953f419900a7p+0, 0x1p+0, 0x1.e608cfd9a47acp-1, 0x1.ca4b31f026aap-1,
@@ -284,7 +284,55 @@ GX_DEV float gx_atan2(float y, float x) {
     if (m == 2) return pi - (z - pi_lo);
     return (z - pi_lo) - pi;
 }
-GX_DEV float gx_pow(float x, float y) { return (float)pow((double)x, (double)y); }
+// powf: glibc 2.35 e_powf.c (ARM optimized routines; POWF_SCALE_BITS = 0 because TOINT_INTRINSICS is off on x86-64):
+// log2(x) from a 16-entry table + degree-5 polynomial, y * log2(x), then 2^z with expf's 32-entry table.  Arguments on this
+// path are x = alpha^2 in (0, 1], y = 1 - u in (0, 1] (DisneyClearcoat::Sample_f, DisneyMaterial.cpp:262); everything
+// else (x <= 0, subnormal, inf, nan) goes through double OCML.
+__device__ static const double gx_powf_logc[16] = {
+    -0x1.efec65b963019p-2, -0x1.b0b6832d4fca4p-2, -0x1.7418b0a1fb77bp-2, -0x1.39de91a6dcf7bp-2, -0x1.01d9bf3f2b631p-2, -0x1.97c1d1b3b7afp-3,
+    -0x1.2f9e393af3c9fp-3, -0x1.960cbbf788d5cp-4, -0x1.a6f9db6475fcep-5, 0x0p+0, 0x1.338ca9f24f53dp-4, 0x1.476a9543891bap-3,
+    0x1.e840b4ac4e4d2p-3, 0x1.40645f0c6651cp-2, 0x1.88e9c2c1b9ff8p-2, 0x1.ce0a44eb17bccp-2};
+GX_DEV float gx_pow(float x, float y) {
+    const uint32_t ix = __float_as_uint(x), iy = __float_as_uint(y);
+    const bool specialX = ix - 0x00800000u >= 0x7f800000u - 0x00800000u;   // x < 0x1p-126, inf or nan
+    const bool specialY = 2 * iy - 1 >= 2u * 0x7f800000u - 1;               // y is 0, inf or nan
+    if (specialX || specialY) return (float)pow((double)x, (double)y);
+    // log2_inline
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> 19) & 15u);
+    const uint32_t top = tmp & 0xff800000u;
+    const uint32_t iz = ix - top;
+    const int k = (int)top >> 23;
+    const double invc = gx_logf_invc[i], logc = gx_powf_logc[i];   // the same invc as logf's table
+    const double z = (double)__uint_as_float(iz);
+    const double r = fma(z, invc, -1.0);
+    const double y0 = logc + (double)k;
+    const double r2 = r * r;
+    double yy = fma(0x1.27616c9496e0bp-2, r, -0x1.71969a075c67ap-2);
+    const double p = fma(0x1.ec70a6ca7baddp-2, r, -0x1.7154748bef6c8p-1);
+    const double r4 = r2 * r2;
+    double q = fma(0x1.71547652ab82bp0, r, y0);
+    q = fma(p, r2, q);
+    yy = fma(yy, r4, q);
+    const double ylogx = (double)y * yy;
+    if (((unsigned long long)__double_as_longlong(ylogx) >> 47 & 0xffff) >= ((unsigned long long)__double_as_longlong(126.0) >> 47)) {
+        if (ylogx > 0x1.fffffffd1d571p+6) return __builtin_huge_valf();   // |y * log2(x)| >= 126
+        if (ylogx <= -150.0) return 0.f;
+    }
+    // exp2_inline (sign_bias = 0: x > 0)
+    double kd = ylogx + 0x1.8p+52 / 32;
+    const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+    kd -= 0x1.8p+52 / 32;
+    const double rr = ylogx - kd;
+    const unsigned long long t = gx_expf_tab[ki & 31u] + (ki << 47);
+    const double s = __longlong_as_double((long long)t);
+    const double zz = fma(0x1.c6af84b912394p-5, rr, 0x1.ebfce50fac4f3p-3);
+    const double rr2 = rr * rr;
+    double out = fma(0x1.62e42ff0c52d6p-1, rr, 1.0);
+    out = fma(zz, rr2, out);
+    out = out * s;
+    return (float)out;
+}
 // __fsqrt_rn maps to the *native* (not correctly rounded) sqrt in this ROCm; the builtin is IEEE under hipcc's default
 // -fhip-fp32-correctly-rounded-divide-sqrt.
 GX_DEV float gx_sqrt(float x) { return __builtin_sqrtf(x); }

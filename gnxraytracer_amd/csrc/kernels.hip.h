@@ -476,7 +476,8 @@ __global__ void __launch_bounds__(kBlock) k_light_grid(DLightTables lt, DLightGr
 __global__ void k_libm_probe(int fn, const float *x, const float *x2, long long n, float *out) {
     for (long long i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float v = x[i];
-        if (fn == 6) out[i] = gx_acos(v);
+        if (fn == 8) out[i] = gx_pow(v, x2 ? x2[i] : 1.0f);
+        else if (fn == 6) out[i] = gx_acos(v);
         else if (fn == 7) out[i] = gx_atan2(v, x2 ? x2[i] : 1.0f);
         else if (fn >= 4) { float sv, cv; gx_sincos(v, &sv, &cv); out[i] = fn == 4 ? sv : cv; }
         else out[i] = fn == 0 ? gx_log(v) : (fn == 1 ? gx_exp(v) : (fn == 2 ? gx_sin(v) : gx_cos(v)));

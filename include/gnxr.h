@@ -280,7 +280,7 @@ int gnxr_camera_rays(const gnxr_camera *cam, int32_t width, int32_t height, cons
 int gnxr_light_grid_table(gnxr_scene *s, int32_t strategy, int32_t on_host, float *out, int64_t capacity, int64_t *n_floats);
 
 /* Unit-test hook: the device's float libm on caller-supplied arguments.  fn: 0 logf, 1 expf, 2 sinf, 3 cosf, 4 / 5 sinf / cosf
- * through the shared-reduction pair evaluation, 6 acosf, 7 atan2f(x, x2) (x2 may be NULL otherwise).  The
+ * through the shared-reduction pair evaluation, 6 acosf, 7 atan2f(x, x2), 8 powf(x, x2) (x2 may be NULL otherwise).  The
  * reference reaches these through std::log / std::exp / std::sin / std::cos on floats (core/Sampling.cpp:87-105,
  * media/GridDensityMedium.cpp:41,67, media/HomogeneousMedium.cpp:13,24, core/Medium.cpp:187, core/Geometry.h:1436-1443);
  * the device restates glibc 2.35's algorithms so the results carry glibc's bits. */

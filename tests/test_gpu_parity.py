@@ -73,6 +73,11 @@ def test_acosf_atan2f_carry_glibc_bits(gpu):
     y = np.concatenate([rng.normal(size=200000), [0, 0, 1, -1, 1e-30, 1e30, 0.0, -0.0]]).astype(np.float32)
     x = np.concatenate([rng.normal(size=200000), [1, -1, 0, 0, 1e30, 1e-30, -0.0, 1.0]]).astype(np.float32)
     assert biteq(gpu.eval_libm("atan2", y, x), np.array([libm.atan2f(float(a), float(b)) for a, b in zip(y, x)], np.float32))
+    # powf(alpha^2, 1 - u): DisneyClearcoat::Sample_f
+    libm.powf.restype, libm.powf.argtypes = C.c_float, [C.c_float, C.c_float]
+    x = np.concatenate([rng.uniform(1e-6, 1, 150000), np.exp(rng.uniform(-20, 5, 50000)), [1.0, 0.5, 2.0, 1e-30]]).astype(np.float32)
+    y = np.concatenate([1 - rng.random(150000), rng.uniform(-8, 8, 50000), [0.3, 1.0, 0.0, 3.0]]).astype(np.float32)
+    assert biteq(gpu.eval_libm("pow", x, y), np.array([libm.powf(float(a), float(b)) for a, b in zip(x, y)], np.float32))
 
 
 @pytest.mark.parametrize("res", [(256, 256), (1920, 1080), (64, 64)])
