@@ -469,8 +469,10 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
                     ++launches;
                 }
                 if (timing) timer.begin(2, stream);
-                if (area_only) hipLaunchKernelGGL((k_vol_step<LT_AREA>), dim3(grid_for(n)), dim3(kBlock), 0, stream, sc, mt, r, pa, va, q_in, n);
-                else hipLaunchKernelGGL((k_vol_step<LT_ALL>), dim3(grid_for(n)), dim3(kBlock), 0, stream, sc, mt, r, pa, va, q_in, n);
+#define GX_VS(LMV, LTV) hipLaunchKernelGGL((k_vol_step<LMV, LTV>), dim3(grid_for(n)), dim3(kBlock), 0, stream, sc, mt, r, pa, va, q_in, n)
+                if (area_only) { if (class_mask <= 1) GX_VS(LM_DIFFUSE, LT_AREA); else if (class_mask <= 3) GX_VS(LM_GLOSSY, LT_AREA); else GX_VS(LM_ALL, LT_AREA); }
+                else { if (class_mask <= 1) GX_VS(LM_DIFFUSE, LT_ALL); else if (class_mask <= 3) GX_VS(LM_GLOSSY, LT_ALL); else GX_VS(LM_ALL, LT_ALL); }
+#undef GX_VS
                 ++launches;
                 compact(COMPACT_FLAGS, q_in, n, s->pflags.p, 4, 2, &dctr->q_next, q_cur, s->queue_nee.p, nullptr);
                 if (timing) timer.end(stream);

@@ -219,7 +219,9 @@ __global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt
     }
 }
 
-template <int LT>
+// LM: the lobe set every material of the scene fits in (device_bsdf.h LM_*): a scene of Matte walls and media runs the
+// diffuse-only instantiation, which needs far fewer registers than the Disney-capable one.
+template <uint32_t LM, int LT>
 __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt, DRender r, PathArrays pa, VolArrays va, const int *__restrict__ queue, int n) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int path = queue ? queue[i] : i;
@@ -388,7 +390,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
         SurfacePoint sp;
         sp.valid = true;
         const DMaterial *mat = nullptr;
-        Bsdf<LM_ALL> bsdf;
+        Bsdf<LM> bsdf;
         V3 itP, itPError, itN;
         int medIn = rayMedium, medOut = rayMedium;
         float g = 0;
