@@ -71,6 +71,41 @@ GX_DEV float halton_sample(const DSamplerTables &t, uint32_t index, int dim) {
     return scrambled_radical_inverse_base(index, base, M, s, t.perms + t.prime_sums[dim]);
 }
 
+// Two consecutive dimensions (both >= 2) of the same sample index at once: the two digit chains are independent, so their
+// permutation-table loads overlap (one memory round trip instead of two).  Same operations per dimension as
+// scrambled_radical_inverse_base, hence the same values.
+GX_DEV void halton_sample_pair(const DSamplerTables &t, uint32_t index, int dim, float *u0, float *u1) {
+    int d0 = dim, d1 = dim + 1;
+    if (d0 >= 1000) d0 = 2 + (d0 - 2) % 998;
+    if (d1 >= 1000) d1 = 2 + (d1 - 2) % 998;
+    if (d0 < 2 || d1 < 2) { *u0 = halton_sample(t, index, dim); *u1 = halton_sample(t, index, dim + 1); return; }
+    const uint32_t b0 = (uint32_t)t.primes[d0], M0 = t.prime_magic[2 * d0], s0 = t.prime_magic[2 * d0 + 1];
+    const uint32_t b1 = (uint32_t)t.primes[d1], M1 = t.prime_magic[2 * d1], s1 = t.prime_magic[2 * d1 + 1];
+    const uint16_t *__restrict__ perm0 = t.perms + t.prime_sums[d0], *__restrict__ perm1 = t.perms + t.prime_sums[d1];
+    const float inv0 = 1.f / (float)b0, inv1 = 1.f / (float)b1;
+    uint64_t rev0 = 0, rev1 = 0;
+    float invN0 = 1, invN1 = 1;
+    uint32_t a0 = index, a1 = index;
+    const uint32_t z0 = perm0[0], z1 = perm1[0];
+    while (a0 | a1) {
+        const uint32_t n01 = div_magic(a0, M0, s0), n02 = div_magic(n01, M0, s0), n03 = div_magic(n02, M0, s0), n04 = div_magic(n03, M0, s0);
+        const uint32_t n11 = div_magic(a1, M1, s1), n12 = div_magic(n11, M1, s1), n13 = div_magic(n12, M1, s1), n14 = div_magic(n13, M1, s1);
+        const uint32_t p00 = perm0[a0 - n01 * b0], p01 = perm0[n01 - n02 * b0], p02 = perm0[n02 - n03 * b0], p03 = perm0[n03 - n04 * b0];
+        const uint32_t p10 = perm1[a1 - n11 * b1], p11 = perm1[n11 - n12 * b1], p12 = perm1[n12 - n13 * b1], p13 = perm1[n13 - n14 * b1];
+        if (a0) { rev0 = rev0 * b0 + p00; invN0 *= inv0; }
+        if (n01) { rev0 = rev0 * b0 + p01; invN0 *= inv0; }
+        if (n02) { rev0 = rev0 * b0 + p02; invN0 *= inv0; }
+        if (n03) { rev0 = rev0 * b0 + p03; invN0 *= inv0; }
+        if (a1) { rev1 = rev1 * b1 + p10; invN1 *= inv1; }
+        if (n11) { rev1 = rev1 * b1 + p11; invN1 *= inv1; }
+        if (n12) { rev1 = rev1 * b1 + p12; invN1 *= inv1; }
+        if (n13) { rev1 = rev1 * b1 + p13; invN1 *= inv1; }
+        a0 = n04; a1 = n14;
+    }
+    *u0 = fminf(invN0 * ((float)rev0 + inv0 * (float)(int)z0 / (1 - inv0)), GX_ONE_MINUS_EPS);
+    *u1 = fminf(invN1 * ((float)rev1 + inv1 * (float)(int)z1 / (1 - inv1)), GX_ONE_MINUS_EPS);
+}
+
 // HaltonSampler::GetIndexForSample offset part, HaltonSampler.cpp:63-83 (kMaxResolution = 128)
 GX_DEV uint32_t halton_pixel_offset(const DHalton &h, int px, int py) {
     if (h.stride <= 1) return 0;

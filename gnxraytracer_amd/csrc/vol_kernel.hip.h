@@ -89,7 +89,8 @@ __global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt
     bool sampleMode = false;
     uint32_t index = 0;
     V3 o, d;
-    float t = 0, tMax = 0, Tr = 1, invMaxDensity = 0, stepScale = 0;
+    float t = 0, tMax = 0, Tr = 1, invMaxDensity = 0, stepScale = 0, cachedU = 0;
+    int cachedDim = -1;   // dimension whose value is already in cachedU (the second half of the last pair drawn)
     const float *__restrict__ dens = nullptr;
 
     while (true) {
@@ -153,7 +154,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt
                                 va.mres[p] = make_float4(1.f, 1.f, 1.f, -1.f);
                             } else {
                                 path = p; medium = med; sampleMode = vs.x == VS_MAIN;
-                                index = ss.index; dim = ss.dim;
+                                index = ss.index; dim = ss.dim; cachedDim = -1;
                                 o = oo; d = dd; t = tMin; tMax = tEnd; Tr = 1;
                                 nx = m.nx; ny = m.ny; nz = m.nz;
                                 invMaxDensity = m.inv_max_density;
@@ -175,7 +176,15 @@ __global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt
             bool done = false;
             float resW = 1.f, resT = -1.f;
             bool resSigma = false;
-            t -= gx_log(1 - halton_sample(sc.st, index, dim++)) * invMaxDensity / stepScale;
+            // samples are drawn in pairs (dimension dim and dim + 1 together): the second one is the next draw of this loop
+            auto draw = [&]() -> float {
+                if (dim == cachedDim) { ++dim; return cachedU; }
+                float ua, ub;
+                halton_sample_pair(sc.st, index, dim, &ua, &ub);
+                cachedU = ub; cachedDim = ++dim;
+                return ua;
+            };
+            t -= gx_log(1 - draw()) * invMaxDensity / stepScale;
             if (t >= tMax) { done = true; resW = sampleMode ? 1.f : Tr; }
             else {
                 // GridDensityMedium::Density, GridDensityMedium.cpp:14-29
@@ -193,13 +202,13 @@ __global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt
                 float d11 = lerpf(dl.x, D(px, py + 1, pz + 1), D(px + 1, py + 1, pz + 1));
                 float density = lerpf(dl.z, lerpf(dl.y, d00, d10), lerpf(dl.y, d01, d11));
                 if (sampleMode) {
-                    if (density * invMaxDensity > halton_sample(sc.st, index, dim++)) { done = true; resSigma = true; resT = t; }
+                    if (density * invMaxDensity > draw()) { done = true; resSigma = true; resT = t; }
                 } else {
                     Tr *= 1 - fmaxf(0.f, density * invMaxDensity);
                     const float rrThreshold = .1f;
                     if (Tr < rrThreshold) {
                         float q = fmaxf(.05f, 1 - Tr);
-                        if (halton_sample(sc.st, index, dim++) < q) { done = true; resW = 0.f; }
+                        if (draw() < q) { done = true; resW = 0.f; }
                         else Tr /= 1 - q;
                     }
                 }
