@@ -126,7 +126,7 @@ struct SampleStream {
     int dim;
     GX_DEV SampleStream(const DSamplerTables &t, uint32_t index, int dim) : t(t), index(index), dim(dim) {}
     GX_DEV float get1d() { return halton_sample(t, index, dim++); }
-    GX_DEV void get2d(float *u0, float *u1) { *u0 = halton_sample(t, index, dim); *u1 = halton_sample(t, index, dim + 1); dim += 2; }
+    GX_DEV void get2d(float *u0, float *u1) { halton_sample_pair(t, index, dim, u0, u1); dim += 2; }
 };
 
 // core/Sampling.cpp:87-105
