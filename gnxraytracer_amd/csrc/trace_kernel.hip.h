@@ -42,6 +42,9 @@ constexpr int kTraceChunk = 512;   // most rays a wave takes per global atomic (
 #define GX_SPECULATE 1
 #endif
 constexpr bool kSpeculate = GX_SPECULATE != 0;
+#ifndef GX_NEE_INTERLEAVED
+#define GX_NEE_INTERLEAVED 0
+#endif
 constexpr int kRefillMin = GX_REFILL_MIN;   // refill only when at least this many lanes are idle (or none is live)
 constexpr int kTraceLeaveMul = GX_TRACE_LEAVE_MUL, kTraceLeaveDiv = GX_TRACE_LEAVE_DIV;   // leave phase A when searching <= live * MUL / DIV
 
@@ -193,10 +196,13 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
                         o4 = pa.ray_o[path]; d4 = pa.ray_d[path];
                         tMax = o4.w;
                     } else {
+                        // NEE work items: first all shadow rays, then all MIS rays (a wave then holds rays of one kind that
+                        // start from neighbouring vertices and -- the shadow rays -- all head for the same few lights)
                         unsigned e = i - (unsigned)w.n_closest;
-                        path = w.q_nee[e >> 1];
+                        const bool isShadow = GX_NEE_INTERLEAVED ? (e & 1u) == 0 : e < (unsigned)w.n_nee;
+                        path = w.q_nee[GX_NEE_INTERLEAVED ? (e >> 1) : (isShadow ? e : e - (unsigned)w.n_nee)];
                         int nflags = __float_as_int(pa.sh_d[path].w);
-                        if ((e & 1u) == 0) {
+                        if (isShadow) {
                             kind = 1;
                             if (nflags & 1) { o4 = pa.sh_o[path]; d4 = pa.sh_d[path]; tMax = o4.w; }
                             else item = -1;     // this vertex spawned no shadow ray
