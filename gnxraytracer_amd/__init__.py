@@ -316,6 +316,13 @@ def camera_rays(camera, width, height, px, py, s):
     return o, d
 
 
+def save_png(path, rgba8):
+    """FrameBuffer::saveToFile (ui/FrameBuffer.cpp:6-9): rgba8 is a [H, W, 4] uint8 array."""
+    rgba8 = np.ascontiguousarray(rgba8, dtype=np.uint8)
+    h, w = rgba8.shape[:2]
+    _check(lib().gnxr_framebuffer_save_png(str(path).encode(), rgba8.ctypes.data_as(C.POINTER(C.c_uint8)), w, h))
+
+
 def eval_libm(fn, x, x2=None):
     """Test hook: the device's float libm (fn = "log" | "exp" | "sin" | "cos" | "acos" | "atan2") on the array x (atan2: y = x, x = x2)."""
     x = np.ascontiguousarray(x, dtype=np.float32)

@@ -113,6 +113,7 @@ PROTOTYPES = {
     "gnxr_sample_halton": (C.c_int, [i32, i32, P(i32), P(i32), P(i64), P(i32), i64, P(f32)]),
     "gnxr_camera_rays": (C.c_int, [P(Camera), i32, i32, P(i32), P(i32), P(i64), i64, P(f32), P(f32)]),
     "gnxr_framebuffer_update": (C.c_int, [P(f32), P(f32), i32, i32, i32, P(u8)]),
+    "gnxr_framebuffer_save_png": (C.c_int, [C.c_char_p, P(u8), i32, i32]),
     "gnxr_light_grid_table": (C.c_int, [VP, i32, i32, P(f32), i64, P(i64)]),
     "gnxr_eval_libm": (C.c_int, [i32, P(f32), P(f32), i64, P(f32)]),
     "gnxr_builder_create": (C.c_int, [P(VP)]),

@@ -570,6 +570,74 @@ int gnxr_write_synthetic_3d(const char *path, int32_t target_triangles, uint32_t
     return write_synthetic_3d(path, target_triangles, seed) ? GNXR_OK : GNXR_ERR_IO;
 }
 
+// ---- FrameBuffer::saveToFile: a minimal PNG encoder (RGBA8, filter 0, zlib stream of stored deflate blocks) ----
+namespace {
+uint32_t crc32_update(uint32_t crc, const uint8_t *p, size_t n) {
+    static uint32_t table[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        init = true;
+    }
+    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xff] ^ (crc >> 8);
+    return crc;
+}
+void put_be32(std::vector<uint8_t> &v, uint32_t x) { v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x); }
+void write_chunk(FILE *f, const char type[4], const std::vector<uint8_t> &data) {
+    std::vector<uint8_t> head;
+    put_be32(head, (uint32_t)data.size());
+    fwrite(head.data(), 1, 4, f);
+    fwrite(type, 1, 4, f);
+    if (!data.empty()) fwrite(data.data(), 1, data.size(), f);
+    uint32_t crc = crc32_update(0xffffffffu, (const uint8_t *)type, 4);
+    crc = crc32_update(crc, data.data(), data.size()) ^ 0xffffffffu;
+    std::vector<uint8_t> tail;
+    put_be32(tail, crc);
+    fwrite(tail.data(), 1, 4, f);
+}
+}  // namespace
+
+int gnxr_framebuffer_save_png(const char *path, const uint8_t *rgba8, int32_t width, int32_t height) {
+    if (!path || !rgba8 || width <= 0 || height <= 0) { set_error("bad argument"); return GNXR_ERR_INVALID; }
+    FILE *f = fopen(path, "wb");
+    if (!f) { set_error("cannot open %s", path); return GNXR_ERR_IO; }
+    const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    fwrite(sig, 1, 8, f);
+    std::vector<uint8_t> ihdr;
+    put_be32(ihdr, (uint32_t)width); put_be32(ihdr, (uint32_t)height);
+    ihdr.push_back(8); ihdr.push_back(6); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);   // 8 bit, RGBA, deflate, adaptive, no interlace
+    write_chunk(f, "IHDR", ihdr);
+    // raw scanlines: filter byte 0 + row
+    const size_t stride = (size_t)width * 4, raw_n = (stride + 1) * (size_t)height;
+    std::vector<uint8_t> raw(raw_n);
+    for (int y = 0; y < height; ++y) {
+        raw[(stride + 1) * y] = 0;
+        memcpy(&raw[(stride + 1) * y + 1], rgba8 + stride * y, stride);
+    }
+    std::vector<uint8_t> z;
+    z.reserve(raw_n + raw_n / 65535 * 5 + 16);
+    z.push_back(0x78); z.push_back(0x01);
+    uint32_t a = 1, b = 0;   // Adler-32
+    for (size_t pos = 0; pos < raw_n;) {
+        size_t n = std::min<size_t>(65535, raw_n - pos);
+        z.push_back(pos + n == raw_n ? 1 : 0);
+        z.push_back(n & 0xff); z.push_back(n >> 8); z.push_back(~n & 0xff); z.push_back((~n >> 8) & 0xff);
+        z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
+        for (size_t i = 0; i < n; ++i) { a = (a + raw[pos + i]) % 65521u; b = (b + a) % 65521u; }
+        pos += n;
+    }
+    put_be32(z, (b << 16) | a);
+    write_chunk(f, "IDAT", z);
+    write_chunk(f, "IEND", {});
+    bool ok = fclose(f) == 0;
+    if (!ok) { set_error("write to %s failed", path); return GNXR_ERR_IO; }
+    return GNXR_OK;
+}
+
 const char *gnxr_last_error(void) { return gnxr::get_error(); }
 // sizeof() of the ABI structs, in the order they appear in include/gnxr.h (binding self-check)
 int gnxr_abi_sizeof(int which) {

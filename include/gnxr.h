@@ -274,6 +274,11 @@ int gnxr_sample_halton(int32_t width, int32_t height, const int32_t *px, const i
 int gnxr_camera_rays(const gnxr_camera *cam, int32_t width, int32_t height, const int32_t *px,
                      const int32_t *py, const int64_t *s, int64_t n, float *o_out, float *d_out);
 
+/* FrameBuffer::saveToFile (ui/FrameBuffer.cpp:6-9: stbi_write_png of the RGBA8 plane): writes `rgba8` (width * height * 4
+ * bytes, row-major, as gnxr_framebuffer_update produces it) as an 8-bit RGBA PNG.  Host-only; the file decodes to the same
+ * pixels as the reference's (the zlib stream itself is not stb's). */
+int gnxr_framebuffer_save_png(const char *path, const uint8_t *rgba8, int32_t width, int32_t height);
+
 /* Unit-test hook: the light-selection table of `strategy` (core/LightDistribution.cpp; per voxel cdf[1..n], func[0..n-1],
  * funcInt), built on the device (on_host == 0) or by the host restatement (on_host != 0).  *n_floats receives the table
  * size; the table is copied when `out` has room for it. */

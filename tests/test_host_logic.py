@@ -142,3 +142,27 @@ def test_sphere_against_analytic_hits(gx):
     occ = osc.IntersectP(seg)
     full = osc.Intersect(seg)
     assert ((full["prim"] >= 0) == (occ != 0)).all()
+
+
+def test_framebuffer_save_png_round_trips(gx, tmp_path):
+    """FrameBuffer::saveToFile (ui/FrameBuffer.cpp:6-9): the PNG decodes to the RGBA8 plane that was handed in."""
+    import struct, zlib
+    rng = np.random.default_rng(2)
+    for (h, w) in [(1, 1), (37, 53), (300, 420)]:     # the last one spans several stored deflate blocks
+        img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        p = tmp_path / f"fb_{w}x{h}.png"
+        gx.save_png(p, img)
+        data = p.read_bytes()
+        assert data[:8] == bytes([0x89]) + b"PNG\r\n\x1a\n"
+        pos, idat, ihdr = 8, b"", None
+        while pos < len(data):
+            n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+            body = data[pos + 8:pos + 8 + n]
+            crc = struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0]
+            assert zlib.crc32(typ + body) & 0xffffffff == crc
+            if typ == b"IHDR": ihdr = struct.unpack(">IIBBBBB", body)
+            if typ == b"IDAT": idat += body
+            pos += 12 + n
+        assert ihdr == (w, h, 8, 6, 0, 0, 0)
+        raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, w * 4 + 1)
+        assert (raw[:, 0] == 0).all() and (raw[:, 1:].reshape(h, w, 4) == img).all()
