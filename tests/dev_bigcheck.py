@@ -20,3 +20,6 @@ check("cfg5 full sigma 128x128x16", scenes.volume_cornell_cfg5(1.0), gx.VolPathI
 check("cfg5 full sigma depth 20", scenes.volume_cornell_cfg5(1.0), gx.VolPathIntegrator(20, 1.0, "spatial"), 96, 96, 256, spp_begin=30, spp_end=38)
 check("cfg1 sphere whitted 256x256x16", scenes.cornell_sphere("glass"), gx.WhittedIntegrator(5), 256, 256, 16)
 check("cfg2 deep path depth 30", scenes.material_zoo(), gx.PathIntegrator(30, 1.0, "spatial"), 128, 128, 64, spp_begin=0, spp_end=16)
+if len(sys.argv) > 1 and sys.argv[1] == "full":
+    check("cfg3 FULL 1920x1080x4 (spp 500..503)", scenes.dragon_cornell(100000, "glass+metal"), gx.PathIntegrator(8, 1.0, "spatial"), 1920, 1080, 1024, spp_begin=500, spp_end=504)
+    check("cfg5 FULL 512x512x8", scenes.volume_cornell_cfg5(1.0), gx.VolPathIntegrator(8, 1.0, "spatial"), 512, 512, 256, spp_begin=100, spp_end=108)
