@@ -63,23 +63,50 @@ def parse():
 
 
 def cpu_baseline(builder, args):
-    """Oracle (CPU restatement of the reference path, OpenMP over pixel columns like Integrator.cpp:256)
-    on the host cores, on a bounded sample of the same workload."""
+    """CPU baseline on the box's host cores, on a bounded sample of the same workload.
+    kind "reference": oracle/_ref/gnx_ref, the reference's own translation units (BVHAccel, Triangle, BSDFs, lights, samplers,
+    media -- compiled from /root/reference in the development container, the binary travels with the snapshot) under the
+    restated Render / Li loop (integrators/*.cpp and core/Integrator.cpp need Qt and cannot be built).
+    kind "port": the oracle (plain CPU restatement), used when the reference binary is not there."""
+    import struct
+
+    import numpy as np
+
     import gnxraytracer_amd as gx
     import oracle_lib as ol
 
-    osc = ol.OracleScene(builder)
-    integ = (gx.VolPathIntegrator if args.workload == "cfg5" else gx.PathIntegrator)(args.max_depth, 1.0, "spatial")
-    w, h, spp = (args.width // 2, args.height // 2, 8) if args.workload == "cfg5" else (960, 540, 8)
-    # same scene / camera / sampler, 1/4 of the pixels, first 8 samples of the Halton sequence (~15-25 s of CPU work for cfg 3)
+    vol = args.workload == "cfg5"
+    integ = (gx.VolPathIntegrator if vol else gx.PathIntegrator)(args.max_depth, 1.0, "spatial")
+    # same scene / camera / sampler type on a bounded sample: cfg 3: 1/4 of the pixels x 24 spp, cfg 5: all pixels x 32 spp
+    # (10-15 s of CPU work for each of the two baselines)
+    w, h, spp = (args.width, args.height, 32) if vol else (960, 540, 24)
     # a 1-GPU box gives this job a 16-core share of the host (more OpenMP threads only oversubscribe it)
     cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    osc = ol.OracleScene(builder)
     osc.render(integ, 64, 36, args.spp, threads=cores, spp_begin=0, spp_end=1)   # touch the tables once
     img, st = osc.render(integ, w, h, args.spp, threads=cores, spp_begin=0, spp_end=spp)
     rays = st["rays_closest"] + st["rays_any"]
-    return {"value": rays / st["seconds_render"] / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+    port = {"value": rays / st["seconds_render"] / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": f"{w}x{h} px, samples 0..{spp - 1} of HaltonSampler({args.spp}), same scene; {rays} rays in {st['seconds_render']:.1f} s; "
                       "oracle = CPU restatement of the reference path, OpenMP over pixel columns (core/Integrator.cpp:256), no printf"}
+    if not os.path.exists(ol.REF_BIN):
+        return port
+    try:
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            sp = os.path.join(td, "scene.bin")
+            ol.write_scene_file(builder, sp)
+            raw = ol.run_ref(sp, "render", None, [w, h, spp, args.max_depth, 1.0, 0, cores, 1 if vol else 0])
+        cnt = np.frombuffer(raw[w * h * 16:w * h * 16 + 16], np.uint64)
+        secs = struct.unpack("<d", raw[w * h * 16 + 16:w * h * 16 + 24])[0]
+        rrays = int(cnt[0]) + int(cnt[1])
+        return {"value": rrays / secs / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "reference",
+                "sample": f"{w}x{h} px, {spp} spp (HaltonSampler({spp})), same scene; {rrays} rays in {secs:.1f} s; the reference's own classes "
+                          "(compiled from its sources) under the restated Render/Li loop, OpenMP over pixel columns, no printf",
+                "port": {"value": port["value"], "sample": port["sample"]}}
+    except Exception as e:   # the binary is optional: fall back to the port
+        port["reference_error"] = str(e)[:200]
+        return port
 
 
 def main():
