@@ -187,30 +187,37 @@ GX_DEV Spec lobe_f(const DLobe &l, V3 wo, V3 wi) {
         return spec3(l.R) * GX_INV_PI * (l.A + l.B * maxCos * sinAlpha * tanBeta);
     }
     break;
-    case LOBE_MICRO_REFL: if (GX_HAS_LOBE(LOBE_MICRO_REFL)) {  // Reflection.cpp:223-237
-        float cosThetaO = abs_cos_theta(wo), cosThetaI = abs_cos_theta(wi);
-        V3 wh = wi + wo;
-        if (cosThetaI == 0 || cosThetaO == 0) return Spec(0.f);
-        if (wh.x == 0 && wh.y == 0 && wh.z == 0) return Spec(0.f);
-        wh = normalize(wh);
-        Spec F = fresnel_eval<LM>(l, dot(wi, faceforward(wh, V3(0, 0, 1))));
-        return spec3(l.R) * tr_D(l.alphax, l.alphay, wh) * tr_G(l, wo, wi) * F / (4 * cosThetaI * cosThetaO);
-    }
-    break;
-    case LOBE_MICRO_TRANS: if (GX_HAS_LOBE(LOBE_MICRO_TRANS)) {  // Reflection.cpp:278-302 (TransportMode::Radiance)
-        if (same_hemisphere(wo, wi)) return Spec(0.f);
-        float cosThetaO = cos_theta(wo), cosThetaI = cos_theta(wi);
-        if (cosThetaI == 0 || cosThetaO == 0) return Spec(0.f);
-        float eta = cos_theta(wo) > 0 ? (l.etaB / l.etaA) : (l.etaA / l.etaB);
-        V3 wh = normalize(wo + wi * eta);
-        if (wh.z < 0) wh = -wh;
-        if (dot(wo, wh) * dot(wi, wh) > 0) return Spec(0.f);
-        Spec F = fresnel_eval<LM>(l, dot(wo, wh));
+    // MicrofacetReflection::f (Reflection.cpp:223-237) and MicrofacetTransmission::f (:278-302, TransportMode::Radiance): the
+    // half vector and the Fresnel argument are lobe-specific, D, G and F are evaluated once for whichever lobe a lane holds
+    // (rough glass puts both lobes into one wave).
+    case LOBE_MICRO_REFL: case LOBE_MICRO_TRANS: if (GX_HAS_LOBE(LOBE_MICRO_REFL) || GX_HAS_LOBE(LOBE_MICRO_TRANS)) {
+        const bool refl = l.kind == LOBE_MICRO_REFL;
+        float cosThetaO, cosThetaI, eta = 1, cosArg;
+        V3 wh;
+        if (refl) {
+            cosThetaO = abs_cos_theta(wo); cosThetaI = abs_cos_theta(wi);
+            wh = wi + wo;
+            if (cosThetaI == 0 || cosThetaO == 0) return Spec(0.f);
+            if (wh.x == 0 && wh.y == 0 && wh.z == 0) return Spec(0.f);
+            wh = normalize(wh);
+            cosArg = dot(wi, faceforward(wh, V3(0, 0, 1)));
+        } else {
+            if (same_hemisphere(wo, wi)) return Spec(0.f);
+            cosThetaO = cos_theta(wo); cosThetaI = cos_theta(wi);
+            if (cosThetaI == 0 || cosThetaO == 0) return Spec(0.f);
+            eta = cos_theta(wo) > 0 ? (l.etaB / l.etaA) : (l.etaA / l.etaB);
+            wh = normalize(wo + wi * eta);
+            if (wh.z < 0) wh = -wh;
+            if (dot(wo, wh) * dot(wi, wh) > 0) return Spec(0.f);
+            cosArg = dot(wo, wh);
+        }
+        const Spec F = fresnel_eval<LM>(l, cosArg);
+        const float D = tr_D(l.alphax, l.alphay, wh), G = tr_G(l, wo, wi);
+        if (refl) return spec3(l.R) * D * G * F / (4 * cosThetaI * cosThetaO);
         float sqrtDenom = dot(wo, wh) + eta * dot(wi, wh);
         float factor = (1 / eta);
         return (Spec(1.f) - F) * spec3(l.T) *
-               fabsf(tr_D(l.alphax, l.alphay, wh) * tr_G(l, wo, wi) * eta * eta * absdot(wi, wh) * absdot(wo, wh) * factor * factor /
-                     (cosThetaI * cosThetaO * sqrtDenom * sqrtDenom));
+               fabsf(D * G * eta * eta * absdot(wi, wh) * absdot(wo, wh) * factor * factor / (cosThetaI * cosThetaO * sqrtDenom * sqrtDenom));
     }
     break;
     case LOBE_DISNEY_DIFFUSE: if (GX_HAS_LOBE(LOBE_DISNEY_DIFFUSE)) {  // DisneyMaterial.cpp:64-72
@@ -267,20 +274,25 @@ GX_DEV float lobe_pdf(const DLobe &l, V3 wo, V3 wi) {
     switch (l.kind) {
     case LOBE_SPEC_REFL: case LOBE_SPEC_TRANS: case LOBE_FRESNEL_SPEC: return 0.f;
     case LOBE_LAMBERT_TRANS: if (GX_HAS_LOBE(LOBE_LAMBERT_TRANS)) return !same_hemisphere(wo, wi) ? abs_cos_theta(wi) * GX_INV_PI : 0.f; break;
-    case LOBE_MICRO_REFL: if (GX_HAS_LOBE(LOBE_MICRO_REFL)) {
-        if (!same_hemisphere(wo, wi)) return 0.f;
-        V3 wh = normalize(wo + wi);
-        return tr_pdf(l.alphax, l.alphay, wo, wh) / (4 * dot(wo, wh));
-    }
-    break;
-    case LOBE_MICRO_TRANS: if (GX_HAS_LOBE(LOBE_MICRO_TRANS)) {
-        if (same_hemisphere(wo, wi)) return 0.f;
-        float eta = cos_theta(wo) > 0 ? (l.etaB / l.etaA) : (l.etaA / l.etaB);
-        V3 wh = normalize(wo + wi * eta);
-        if (dot(wo, wh) * dot(wi, wh) > 0) return 0.f;
-        float sqrtDenom = dot(wo, wh) + eta * dot(wi, wh);
-        float dwh_dwi = fabsf((eta * eta * dot(wi, wh)) / (sqrtDenom * sqrtDenom));
-        return tr_pdf(l.alphax, l.alphay, wo, wh) * dwh_dwi;
+    // MicrofacetReflection::Pdf (Reflection.cpp:216-221) / MicrofacetTransmission::Pdf (:262-276): one distribution->Pdf call
+    case LOBE_MICRO_REFL: case LOBE_MICRO_TRANS: if (GX_HAS_LOBE(LOBE_MICRO_REFL) || GX_HAS_LOBE(LOBE_MICRO_TRANS)) {
+        const bool refl = l.kind == LOBE_MICRO_REFL;
+        V3 wh;
+        float scale;
+        if (refl) {
+            if (!same_hemisphere(wo, wi)) return 0.f;
+            wh = normalize(wo + wi);
+            scale = 4 * dot(wo, wh);
+        } else {
+            if (same_hemisphere(wo, wi)) return 0.f;
+            float eta = cos_theta(wo) > 0 ? (l.etaB / l.etaA) : (l.etaA / l.etaB);
+            wh = normalize(wo + wi * eta);
+            if (dot(wo, wh) * dot(wi, wh) > 0) return 0.f;
+            float sqrtDenom = dot(wo, wh) + eta * dot(wi, wh);
+            scale = fabsf((eta * eta * dot(wi, wh)) / (sqrtDenom * sqrtDenom));
+        }
+        const float p = tr_pdf(l.alphax, l.alphay, wo, wh);
+        return refl ? p / scale : p * scale;
     }
     break;
     case LOBE_DISNEY_CLEARCOAT: if (GX_HAS_LOBE(LOBE_DISNEY_CLEARCOAT)) {
@@ -336,23 +348,22 @@ GX_DEV Spec lobe_sample(const DLobe &l, V3 wo, V3 *wi, float u0, float u1, float
         }
     }
     break;
-    case LOBE_MICRO_REFL: if (GX_HAS_LOBE(LOBE_MICRO_REFL)) {  // Reflection.cpp:206-214
+    // MicrofacetReflection::Sample_f (Reflection.cpp:206-214) and MicrofacetTransmission::Sample_f (:249-260) start with the
+    // same visible-normal sample; rough glass picks one of the two lobes per path, so a wave holds both kinds -- sharing the
+    // (expensive) Sample_wh keeps that divergence out of it.
+    case LOBE_MICRO_REFL: case LOBE_MICRO_TRANS: if (GX_HAS_LOBE(LOBE_MICRO_REFL) || GX_HAS_LOBE(LOBE_MICRO_TRANS)) {
         if (wo.z == 0) return Spec(0.f);
         V3 wh = tr_sample_wh(l.alphax, l.alphay, wo, u0, u1);
         if (dot(wo, wh) < 0) return Spec(0.f);
-        *wi = reflect(wo, wh);
-        if (!same_hemisphere(wo, *wi)) return Spec(0.f);
-        *pdf = tr_pdf(l.alphax, l.alphay, wo, wh) / (4 * dot(wo, wh));
-        return lobe_f<LM>(l, wo, *wi);
-    }
-    break;
-    case LOBE_MICRO_TRANS: if (GX_HAS_LOBE(LOBE_MICRO_TRANS)) {  // Reflection.cpp:249-260
-        if (wo.z == 0) return Spec(0.f);
-        V3 wh = tr_sample_wh(l.alphax, l.alphay, wo, u0, u1);
-        if (dot(wo, wh) < 0) return Spec(0.f);
-        float eta = cos_theta(wo) > 0 ? (l.etaA / l.etaB) : (l.etaB / l.etaA);
-        if (!refract(wo, wh, eta, wi)) return Spec(0.f);
-        *pdf = lobe_pdf<LM>(l, wo, *wi);
+        if (l.kind == LOBE_MICRO_REFL) {
+            *wi = reflect(wo, wh);
+            if (!same_hemisphere(wo, *wi)) return Spec(0.f);
+            *pdf = tr_pdf(l.alphax, l.alphay, wo, wh) / (4 * dot(wo, wh));
+        } else {
+            float eta = cos_theta(wo) > 0 ? (l.etaA / l.etaB) : (l.etaB / l.etaA);
+            if (!refract(wo, wh, eta, wi)) return Spec(0.f);
+            *pdf = lobe_pdf<LM>(l, wo, *wi);
+        }
         return lobe_f<LM>(l, wo, *wi);
     }
     break;
