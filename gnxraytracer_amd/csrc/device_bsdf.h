@@ -418,10 +418,24 @@ struct Bsdf {
         V3 wi = to_local(wiW), wo = to_local(woW);
         if (wo.z == 0) return Spec(0.f);
         bool refl = dot(wiW, ng) * dot(woW, ng) > 0;
+        return sum_f(wo, wi, flags, refl);
+    }
+    // sum of lobe_f over the lobes that match `flags` and the reflect / transmit side, in lobe order (Reflection.cpp:458-463).
+    // Each lane walks ITS OWN list of applicable lobes: lanes of a wave whose applicable lobe differs (rough glass: the
+    // reflection lobe for some, the transmission lobe for others) evaluate them in the same iteration instead of in turn.
+    GX_DEV Spec sum_f(V3 wo, V3 wi, int flags, bool refl) const {
         Spec f(0.f);
-        for (int i = 0; i < mat->n_lobes; ++i) {
-            const DLobe &l = mat->lobes[i];
-            if (matches(l.type, flags) && ((refl && (l.type & BSDF_REFLECTION)) || (!refl && (l.type & BSDF_TRANSMISSION)))) f = f + lobe_f<LM>(l, wo, wi);
+        const int n = mat->n_lobes;
+        int i = 0;
+        while (true) {
+            while (i < n) {
+                const int t = mat->lobes[i].type;
+                if (matches(t, flags) && ((refl && (t & BSDF_REFLECTION)) || (!refl && (t & BSDF_TRANSMISSION)))) break;
+                ++i;
+            }
+            if (i >= n) break;
+            f = f + lobe_f<LM>(mat->lobes[i], wo, wi);
+            ++i;
         }
         return f;
     }
@@ -454,17 +468,20 @@ struct Bsdf {
         Spec f = lobe_sample<LM>(bx, wo, &wi, ur0, u1, pdf, sampledType);
         if (*pdf == 0) { *sampledType = 0; return Spec(0.f); }
         *wiW = to_world(wi);
-        if (!(bx.type & BSDF_SPECULAR) && matching > 1)
-            for (int i = 0; i < mat->n_lobes; ++i)
-                if (i != which && matches(mat->lobes[i].type, flags)) *pdf += lobe_pdf<LM>(mat->lobes[i], wo, wi);
+        if (!(bx.type & BSDF_SPECULAR) && matching > 1) {   // the other matching lobes' pdfs, in lobe order; per-lane walk as in sum_f
+            const int n = mat->n_lobes;
+            int i = 0;
+            while (true) {
+                while (i < n && !(i != which && matches(mat->lobes[i].type, flags))) ++i;
+                if (i >= n) break;
+                *pdf += lobe_pdf<LM>(mat->lobes[i], wo, wi);
+                ++i;
+            }
+        }
         if (matching > 1) *pdf /= matching;
         if (!(bx.type & BSDF_SPECULAR)) {
             bool refl = dot(*wiW, ng) * dot(woW, ng) > 0;
-            f = Spec(0.f);
-            for (int i = 0; i < mat->n_lobes; ++i) {
-                const DLobe &l = mat->lobes[i];
-                if (matches(l.type, flags) && ((refl && (l.type & BSDF_REFLECTION)) || (!refl && (l.type & BSDF_TRANSMISSION)))) f = f + lobe_f<LM>(l, wo, wi);
-            }
+            f = sum_f(wo, wi, flags, refl);
         }
         return f;
     }
