@@ -134,6 +134,7 @@ struct gnxr_scene {
     DevBuf<int> trace_spill;   // global part of k_trace's per-lane traversal stacks
     DevBuf<float4> vol_n1, vol_f, vol_Li, vol_Tr, vol_Ld, vol_mres;   // VolPath light-estimate records (vol_kernel.hip.h)
     DevBuf<int4> vol_vs;
+    DevBuf<unsigned char> vol_state;
     DevBuf<float4> wh_o, wh_d, wh_L, wh_w;   // Whitted recursion frames (whitted_kernel.hip.h)
     DevBuf<float> wh_pdf;
     DevBuf<int> wh_rec;
@@ -329,7 +330,7 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     }
     if (volpath) {
 #define AL(f) if ((rc = s->f.alloc(cap)) != GNXR_OK) return rc;
-        AL(vol_n1) AL(vol_f) AL(vol_Li) AL(vol_Tr) AL(vol_Ld) AL(vol_mres) AL(vol_vs)
+        AL(vol_n1) AL(vol_f) AL(vol_Li) AL(vol_Tr) AL(vol_Ld) AL(vol_mres) AL(vol_vs) AL(vol_state)
 #undef AL
     }
     {   // global part of k_trace's traversal stacks (the deepest walk either BVH layout can need), sized for a full grid
@@ -344,7 +345,7 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     pa.sh_o = s->sh_o.p; pa.sh_d = s->sh_d.p; pa.sh_X = s->sh_X.p; pa.mis_o = s->mis_o.p; pa.mis_d = s->mis_d.p; pa.mis_Y = s->mis_Y.p; pa.nbeta = s->nbeta.p;
     VolArrays va;
     va.vs = s->vol_vs.p; va.sv_o = s->sh_o.p; va.sv_d = s->sh_d.p; va.p1 = s->sh_X.p; va.p1e = s->nbeta.p; va.n1 = s->vol_n1.p; va.f = s->vol_f.p;
-    va.Li = s->vol_Li.p; va.Tr = s->vol_Tr.p; va.Ld = s->vol_Ld.p; va.mis_o = s->mis_o.p; va.mis_d = s->mis_d.p; va.mis_Y = s->mis_Y.p; va.mres = s->vol_mres.p;
+    va.Li = s->vol_Li.p; va.Tr = s->vol_Tr.p; va.Ld = s->vol_Ld.p; va.mis_o = s->mis_o.p; va.mis_d = s->mis_d.p; va.mis_Y = s->mis_Y.p; va.mres = s->vol_mres.p; va.state = s->vol_state.p;
     DMediaTables mt = s->media_tables();
     WhittedArrays wa;
     wa.ws = s->vol_vs.p; wa.fr_o = s->wh_o.p; wa.fr_d = s->wh_d.p; wa.fr_L = s->wh_L.p; wa.fr_w = s->wh_w.p; wa.fr_pdf = s->wh_pdf.p;
@@ -469,10 +470,18 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
                     ++launches;
                 }
                 if (timing) timer.begin(2, stream);
-#define GX_VS(LMV, LTV) hipLaunchKernelGGL((k_vol_step<LMV, LTV>), dim3(grid_for(n)), dim3(kBlock), 0, stream, sc, mt, r, pa, va, q_in, n)
-                if (area_only) { if (class_mask <= 1) GX_VS(LM_DIFFUSE, LT_AREA); else if (class_mask <= 3) GX_VS(LM_GLOSSY, LT_AREA); else GX_VS(LM_ALL, LT_AREA); }
-                else { if (class_mask <= 1) GX_VS(LM_DIFFUSE, LT_ALL); else if (class_mask <= 3) GX_VS(LM_GLOSSY, LT_ALL); else GX_VS(LM_ALL, LT_ALL); }
+// bin the live paths by state (main ray / shadow-ray segment / scattering-ray segment), one k_vol_step instantiation per bin
+                compact(COMPACT_CLASS, q_in, n, s->vol_state.p, 3, 3, &dctr->q_class[0], s->queue_c0.p, s->queue_c1.p, s->queue_c2.p);
+                {
+                    int *qc[3] = {s->queue_c0.p, s->queue_c1.p, s->queue_c2.p};
+#define GX_VS1(LMV, LTV, ST) hipLaunchKernelGGL((k_vol_step<LMV, LTV, ST>), dim3(grid_for(n)), dim3(kBlock), 0, stream, sc, mt, r, pa, va, (const int *)qc[ST], (const unsigned int *)&dctr->q_class[ST])
+#define GX_VS(LMV, LTV) do { GX_VS1(LMV, LTV, VS_MAIN); GX_VS1(LMV, LTV, VS_SHADOW); GX_VS1(LMV, LTV, VS_MIS); } while (0)
+                    if (area_only) { if (class_mask <= 1) GX_VS(LM_DIFFUSE, LT_AREA); else if (class_mask <= 3) GX_VS(LM_GLOSSY, LT_AREA); else GX_VS(LM_ALL, LT_AREA); }
+                    else { if (class_mask <= 1) GX_VS(LM_DIFFUSE, LT_ALL); else if (class_mask <= 3) GX_VS(LM_GLOSSY, LT_ALL); else GX_VS(LM_ALL, LT_ALL); }
 #undef GX_VS
+#undef GX_VS1
+                    launches += 2;
+                }
                 ++launches;
                 compact(COMPACT_FLAGS, q_in, n, s->pflags.p, 4, 2, &dctr->q_next, q_cur, s->queue_nee.p, nullptr);
                 if (timing) timer.end(stream);

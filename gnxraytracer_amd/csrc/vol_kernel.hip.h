@@ -44,6 +44,7 @@ struct VolArrays {
     float4 *mis_o;   // scattering ray origin, w: medium (int bits)
     float4 *mis_d;   // scattering ray direction, w: scattering pdf
     float4 *mis_Y;   // f * Li2
+    unsigned char *state;   // copy of vs.x for the live paths: key of the per-state binning before k_vol_step
     float4 *mres;    // k_vol_media result for the ray in flight: Medium::Sample weight / Medium::Tr (rgb), w: t of the sampled interaction or -1
 };
 
@@ -51,6 +52,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_init(PathArrays pa, VolArrays va
     for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_paths; slot += gridDim.x * blockDim.x) {
         uint2 m = pa.meta[slot];
         va.vs[slot] = make_int4(VS_MAIN, (int)m.y, -1, 0);
+        va.state[slot] = (unsigned char)VS_MAIN;
         pa.meta[slot] = make_uint2(m.x, 0u);   // y: bounces << 16 | specularBounce << 31
     }
 }
@@ -230,11 +232,15 @@ __global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt
 
 // LM: the lobe set every material of the scene fits in (device_bsdf.h LM_*): a scene of Matte walls and media runs the
 // diffuse-only instantiation, which needs far fewer registers than the Disney-capable one.
-template <uint32_t LM, int LT>
-__global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt, DRender r, PathArrays pa, VolArrays va, const int *__restrict__ queue, int n) {
+// ST: the state every path of `queue` is in (the host bins the live paths by state before each step, so a wave runs one
+// of the three phases instead of all of them in turn); `n_dev` is the bin's fill count written by the binning.
+template <uint32_t LM, int LT, int ST>
+__global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt, DRender r, PathArrays pa, VolArrays va, const int *__restrict__ queue, const unsigned int *n_dev) {
+    const int n = (int)*n_dev;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int path = queue ? queue[i] : i;
+        const int path = queue[i];
         int4 vs = va.vs[path];
+        vs.x = ST;   // == the stored state
         uint2 meta = pa.meta[path];
         const uint32_t index = meta.x;
         int bounces = (int)((meta.y >> 16) & 0xffu);
@@ -270,7 +276,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
         // hit point / error bound / normal of the traced ray's hit (no Bump: only p, pError, n are used)
         auto hit_geometry = [&]() { return leaf < -1 ? sphere_surface_point(sc.spheres[-2 - leaf], ro, rd, h.t, false) : surface_point(p0, p1, p2, h, false); };
 
-        if (vs.x != VS_MAIN) {
+        if (ST != VS_MAIN) {
             // ---------------- phase 1: one segment of the light-sample ray or of the scattering ray ----------------
             float4 T4 = va.Tr[path], Ld4 = va.Ld[path], f4 = va.f[path];
             Spec Tr(T4.x, T4.y, T4.z), Ld(Ld4.x, Ld4.y, Ld4.z);
@@ -280,7 +286,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
             if (found) { sp = hit_geometry(); found = sp.valid; }
             bool segDone = false;
             int segMedium = -1;        // medium of the next segment's ray
-            if (vs.x == VS_SHADOW) {   // VisibilityTester::Tr, Light.cpp:33-53
+            if (ST == VS_SHADOW) {   // VisibilityTester::Tr, Light.cpp:33-53
                 if (found && triMat >= 0) {
                     segDone = true;    // blocked: Tr = 0, Li becomes black, nothing is added
                 } else {
@@ -329,7 +335,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
                 va.Tr[path] = make_float4(Tr.r, Tr.g, Tr.b, T4.w);
                 va.Ld[path] = make_float4(Ld.r, Ld.g, Ld.b, Ld4.w);
                 vs.y = ss.dim;
-                va.vs[path] = vs;
+                va.vs[path] = vs; va.state[path] = (unsigned char)vs.x;
                 pa.pflags[path] = (unsigned char)(1 | (segMedium >= 0 ? 2 : 0));
                 continue;
             }
@@ -381,7 +387,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
                     pa.beta[path] = make_float4(beta.r, beta.g, beta.b, etaScale);
                     pa.L[path] = make_float4(L.r, L.g, L.b, 0.f);
                     vs.y = ss.dim;
-                    va.vs[path] = vs;
+                    va.vs[path] = vs; va.state[path] = (unsigned char)vs.x;
                     pa.pflags[path] = (unsigned char)(1 | (nm >= 0 ? 2 : 0));
                     continue;
                 } else vertexNew = true;
@@ -525,7 +531,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
                     }
                     vs.y = ss.dim;
                     vs.z = leaf;
-                    va.vs[path] = vs;
+                    va.vs[path] = vs; va.state[path] = (unsigned char)vs.x;
                     pa.beta[path] = make_float4(beta.r, beta.g, beta.b, etaScale);
                     pa.L[path] = make_float4(L.r, L.g, L.b, 0.f);
                     pa.pflags[path] = (unsigned char)(1 | (((nflags & 1) ? shMedium : misMedium) >= 0 ? 2 : 0));
@@ -577,7 +583,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
                     pa.meta[path] = make_uint2(index, ((uint32_t)(bounces + 1) << 16) | (specularBounce ? 0x80000000u : 0u));
                     vs.x = VS_MAIN;
                     vs.y = ss.dim;
-                    va.vs[path] = vs;
+                    va.vs[path] = vs; va.state[path] = (unsigned char)vs.x;
                 }
             }
         }
