@@ -258,7 +258,7 @@ class PathIntegrator:
     def params(self, width, height, spp, spp_begin=0, spp_end=0, shard_index=0, shard_count=1, shard_rows=1,
                samples_per_pass=0):
         return RenderParams(width, height, spp, spp_begin, spp_end, self.maxDepth, self.rrThreshold, self.integrator,
-                            self.strategy, shard_index, shard_count, shard_rows, samples_per_pass, 0)
+                            self.strategy, shard_index, shard_count, shard_rows, samples_per_pass, getattr(self, "directStrategy", 0))
 
     def Render(self, scene, width, height, spp, **kw):
         """Integrator::Render: returns (float32 image [H, W, 4], stats dict)."""
@@ -288,6 +288,17 @@ class WhittedIntegrator(PathIntegrator):
 
     def __init__(self, maxDepth=5):
         super().__init__(maxDepth, 1.0, "uniform")
+
+
+class DirectLightingIntegrator(PathIntegrator):
+    """pbr::DirectLightingIntegrator(strategy, maxDepth, ...) (integrators/DirectLightingIntegrator.h:16-38); strategy is the
+    reference's LightStrategy: "all" = UniformSampleAll (Light::nSamples array samples per light and vertex), "one" =
+    UniformSampleOne.  Shares the depth-first device state machine with Whitted (csrc/whitted_kernel.hip.h)."""
+    integrator = _abi.INTEGRATOR_DIRECT
+
+    def __init__(self, strategy="all", maxDepth=5):
+        super().__init__(maxDepth, 1.0, "uniform")
+        self.directStrategy = {"all": _abi.DIRECT_SAMPLE_ALL, "one": _abi.DIRECT_SAMPLE_ONE}[strategy]
 
 
 def sample_halton(width, height, px, py, s, dim):

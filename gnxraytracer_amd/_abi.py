@@ -14,7 +14,8 @@ MAT_NONE, MAT_MATTE, MAT_MIRROR, MAT_GLASS, MAT_METAL, MAT_PLASTIC, MAT_DISNEY =
 # gnxr_light_type
 LIGHT_AREA_TRI, LIGHT_INFINITE, LIGHT_SKYBOX = 1, 2, 3
 # gnxr_integrator / gnxr_light_strategy
-INTEGRATOR_PATH, INTEGRATOR_VOLPATH, INTEGRATOR_WHITTED = 0, 1, 2
+INTEGRATOR_PATH, INTEGRATOR_VOLPATH, INTEGRATOR_WHITTED, INTEGRATOR_DIRECT = 0, 1, 2, 3
+DIRECT_SAMPLE_ALL, DIRECT_SAMPLE_ONE = 0, 1
 LIGHTS_SPATIAL, LIGHTS_UNIFORM, LIGHTS_POWER = 0, 1, 2
 MEDIUM_HOMOGENEOUS, MEDIUM_GRID = 1, 2
 
@@ -35,7 +36,7 @@ class Material(C.Structure):
 
 class Light(C.Structure):
     _fields_ = [
-        ("type", i32), ("tri", i32), ("two_sided", i32), ("_pad", i32),
+        ("type", i32), ("tri", i32), ("two_sided", i32), ("n_samples", i32),
         ("le", f32 * 3), ("radius", f32), ("center", f32 * 3), ("_pad2", f32), ("light_to_world", f32 * 16),
     ]
 
@@ -70,7 +71,7 @@ class RenderParams(C.Structure):
     _fields_ = [
         ("width", i32), ("height", i32), ("spp", i32), ("spp_begin", i32), ("spp_end", i32), ("max_depth", i32),
         ("rr_threshold", f32), ("integrator", i32), ("light_strategy", i32),
-        ("shard_index", i32), ("shard_count", i32), ("shard_rows", i32), ("samples_per_pass", i32), ("_pad", i32),
+        ("shard_index", i32), ("shard_count", i32), ("shard_rows", i32), ("samples_per_pass", i32), ("direct_strategy", i32),
     ]
 
 

@@ -283,14 +283,30 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
         set_error("invalid render parameters");
         return GNXR_ERR_INVALID;
     }
-    if (p.integrator != GNXR_INTEGRATOR_PATH && p.integrator != GNXR_INTEGRATOR_VOLPATH && p.integrator != GNXR_INTEGRATOR_WHITTED) {
+    if (p.integrator != GNXR_INTEGRATOR_PATH && p.integrator != GNXR_INTEGRATOR_VOLPATH && p.integrator != GNXR_INTEGRATOR_WHITTED &&
+        p.integrator != GNXR_INTEGRATOR_DIRECT) {
         set_error("unknown integrator %d", p.integrator);
         return GNXR_ERR_UNSUPPORTED;
     }
-    const bool volpath = p.integrator == GNXR_INTEGRATOR_VOLPATH, whitted = p.integrator == GNXR_INTEGRATOR_WHITTED;
+    const bool direct = p.integrator == GNXR_INTEGRATOR_DIRECT;
+    if (direct && p.direct_strategy != GNXR_DIRECT_SAMPLE_ALL && p.direct_strategy != GNXR_DIRECT_SAMPLE_ONE) {
+        set_error("unknown direct-lighting strategy %d", p.direct_strategy);
+        return GNXR_ERR_INVALID;
+    }
+    // Whitted and DirectLighting share the depth-first state machine of whitted_kernel.hip.h
+    const bool volpath = p.integrator == GNXR_INTEGRATOR_VOLPATH, whitted = p.integrator == GNXR_INTEGRATOR_WHITTED || direct;
+    const int wmode = !direct ? WM_WHITTED : (p.direct_strategy == GNXR_DIRECT_SAMPLE_ONE ? WM_DIRECT_ONE : WM_DIRECT_ALL);
     const int nL = (int)s->cs.desc_lights.size();
-    if (whitted && (nL > 16 || p.max_depth > 32 || !s->cs.media.empty())) {
-        set_error("Whitted on the device: at most 16 lights (every light is sampled at every vertex), depth 32, no media");
+    // NEE records per vertex, and the largest Light::nSamples (the array samples multiply the Halton index by it)
+    int n_records = nL, max_light_samples = 1;
+    if (wmode == WM_DIRECT_ONE) n_records = 1;
+    if (wmode == WM_DIRECT_ALL) {
+        n_records = 0;
+        for (const gnxr_light &l : s->cs.desc_lights) { n_records += std::max(1, l.n_samples); max_light_samples = std::max(max_light_samples, l.n_samples); }
+        n_records = std::max(1, n_records);
+    }
+    if (whitted && (n_records > 64 || p.max_depth > 32 || !s->cs.media.empty())) {
+        set_error("Whitted / DirectLighting on the device: at most 64 light samples per vertex (every light is sampled at every vertex), depth 32, no media");
         return GNXR_ERR_UNSUPPORTED;
     }
     std::lock_guard<std::mutex> lock(s->render_mutex);
@@ -300,7 +316,7 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     if (rc) return rc;
     DScene sc = s->device_scene(p.width, p.height);
     // the device sampler keeps the Halton index in 32 bits
-    if ((unsigned long long)sc.st.h.stride * (unsigned long long)(p.spp + 1) >= (1ull << 32)) { set_error("spp too large for 32-bit Halton indices"); return GNXR_ERR_UNSUPPORTED; }
+    if ((unsigned long long)sc.st.h.stride * ((unsigned long long)p.spp * max_light_samples + 1) >= (1ull << 32)) { set_error("spp too large for 32-bit Halton indices"); return GNXR_ERR_UNSUPPORTED; }
     DRender r;
     memset(&r, 0, sizeof(r));
     r.cam = make_camera(s->cs.camera, p.width, p.height, s->cs.camera_medium);
@@ -312,7 +328,7 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     int nsamples = p.spp_end - p.spp_begin;
     int k = p.samples_per_pass;
     if (k <= 0) {  // auto: about 32M paths in flight (big passes keep the thin late bounces from under-filling the GPU)
-        long long target = whitted ? (4ll << 20) : (32ll << 20);   // Whitted keeps max_depth frames per path
+        long long target = whitted ? (4ll << 20) / std::max(1, n_records / 4) : (32ll << 20);   // Whitted keeps max_depth frames and n_records NEE records per path
         k = (int)std::max<long long>(1, std::min<long long>(nsamples, target / r.npix));
     }
     k = std::min(k, nsamples);
@@ -322,7 +338,8 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     AL(ray_o) AL(ray_d) AL(beta) AL(L) AL(sh_o) AL(sh_d) AL(sh_X) AL(mis_o) AL(mis_d) AL(mis_Y) AL(nbeta) AL(meta) AL(hit) AL(queue_a) AL(queue_b) AL(queue_nee) AL(queue_c0) AL(queue_c1) AL(queue_c2) AL(pflags) AL(pclass)
 #undef AL
     if (whitted) {
-        const size_t nl = (size_t)std::max(1, nL), md = (size_t)std::max(1, p.max_depth);
+        const size_t nl = (size_t)std::max(1, n_records), md = (size_t)std::max(1, p.max_depth);
+        if (direct && ((rc = s->mis_o.alloc(cap * nl)) || (rc = s->mis_d.alloc(cap * nl)) || (rc = s->mis_Y.alloc(cap * nl)))) return rc;
         if ((rc = s->sh_o.alloc(cap * nl)) || (rc = s->sh_d.alloc(cap * nl)) || (rc = s->sh_X.alloc(cap * nl)) || (rc = s->wh_rec.alloc(cap * nl)) ||
             (rc = s->wh_o.alloc(cap * md)) || (rc = s->wh_d.alloc(cap * md)) || (rc = s->wh_L.alloc(cap * md)) || (rc = s->wh_w.alloc(cap * md)) ||
             (rc = s->wh_pdf.alloc(cap * md)) || (rc = s->vol_vs.alloc(cap)))
@@ -349,8 +366,13 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     DMediaTables mt = s->media_tables();
     WhittedArrays wa;
     wa.ws = s->vol_vs.p; wa.fr_o = s->wh_o.p; wa.fr_d = s->wh_d.p; wa.fr_L = s->wh_L.p; wa.fr_w = s->wh_w.p; wa.fr_pdf = s->wh_pdf.p;
-    wa.cap = (int)cap; wa.n_lights = nL;
-    if (whitted) { sc.materials = s->materials_single.p; pa.sh_o = s->sh_o.p; pa.sh_d = s->sh_d.p; pa.sh_X = s->sh_X.p; }
+    wa.cap = (int)cap; wa.n_lights = nL; wa.n_records = n_records;
+    // DirectLightingIntegrator::Preprocess requests maxDepth x lights x 2 2D arrays (DirectLightingIntegrator.cpp:19-25)
+    wa.start_dim = wmode == WM_DIRECT_ALL ? 5 + 2 * (p.max_depth * nL * 2) : 5;
+    if (whitted) {
+        sc.materials = s->materials_single.p;
+        pa.sh_o = s->sh_o.p; pa.sh_d = s->sh_d.p; pa.sh_X = s->sh_X.p; pa.mis_o = s->mis_o.p; pa.mis_d = s->mis_d.p; pa.mis_Y = s->mis_Y.p;
+    }
 
     HIP_TRY(hipMemsetAsync(s->accum.p, 0, sizeof(float4) * r.npix, stream));
     HIP_TRY(hipMemsetAsync(s->counters.p, 0, sizeof(Counters), stream));
@@ -429,15 +451,17 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
             unsigned long long *d_shadow = &dctr->whitted_shadow;
             while (n > 0) {
                 if (n_shp > 0) {
-                    hipLaunchKernelGGL(k_whitted_expand, dim3(grid_for((long long)n_shp * nL)), dim3(kBlock), 0, stream, (const int *)s->queue_nee.p, n_shp, nL, (int)cap, s->wh_rec.p);
+                    hipLaunchKernelGGL(k_whitted_expand, dim3(grid_for((long long)n_shp * n_records)), dim3(kBlock), 0, stream, (const int *)s->queue_nee.p, n_shp, n_records, (int)cap, s->wh_rec.p);
                     ++launches;
                 }
-                launch_trace(TraceWork{q_cl, n_cl, s->wh_rec.p, n_shp * nL}, 0, 0);
+                launch_trace(TraceWork{q_cl, n_cl, s->wh_rec.p, n_shp * n_records}, 0, 0);
                 if (timing) timer.begin(2, stream);
-#define GX_WH(LTV, SPHV) hipLaunchKernelGGL((k_whitted_step<LTV, SPHV>), dim3(grid_for(n)), dim3(kBlock), 0, stream, sc, r, pa, wa, q_in, n, d_shadow)
+#define GX_WH2(MODEV, LTV, SPHV) hipLaunchKernelGGL((k_whitted_step<MODEV, LTV, SPHV>), dim3(grid_for(n)), dim3(kBlock), 0, stream, sc, r, pa, wa, q_in, n, d_shadow)
+#define GX_WH(LTV, SPHV) do { if (wmode == WM_WHITTED) GX_WH2(WM_WHITTED, LTV, SPHV); else if (wmode == WM_DIRECT_ONE) GX_WH2(WM_DIRECT_ONE, LTV, SPHV); else GX_WH2(WM_DIRECT_ALL, LTV, SPHV); } while (0)
                 if (area_only) { if (spheres) GX_WH(LT_AREA, true); else GX_WH(LT_AREA, false); }
                 else { if (spheres) GX_WH(LT_ALL, true); else GX_WH(LT_ALL, false); }
 #undef GX_WH
+#undef GX_WH2
                 ++launches;
                 compact(COMPACT_FLAGS, q_in, n, s->pflags.p, 4, 3, &dctr->q_next, q_cur, s->queue_nee.p, s->queue_c0.p);
                 if (timing) timer.end(stream);
@@ -555,7 +579,7 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     (void)hipEventDestroy(ev1);
     if (stats) {
         memset(stats, 0, sizeof(*stats));
-        stats->rays_closest = rays_closest;
+        stats->rays_closest = rays_closest + (whitted ? s->h_counters->whitted_mis : 0);
         stats->rays_any = whitted ? s->h_counters->whitted_shadow : rays_any;
         stats->camera_samples = (uint64_t)r.npix * nsamples;
         stats->nodes_visited = s->h_counters->nodes;

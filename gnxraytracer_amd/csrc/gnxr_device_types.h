@@ -90,7 +90,7 @@ struct DLight {
     float le[3]; float area;
     float p0[3]; float inv_area;
     float p1[3]; float radius;
-    float p2[3]; float _pad;
+    float p2[3]; int32_t n_samples;   // max(1, Light::nSamples), core/Light.cpp:19
     float n[3]; float _pad2;   // Normalize(Cross(p1-p0, p2-p0)), Triangle.cpp:473
     float center[3]; float _pad3;
 };

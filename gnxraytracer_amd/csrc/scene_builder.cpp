@@ -479,6 +479,7 @@ int gnxr_builder_add_area_light(gnxr_builder *b, int32_t material) {
         l.type = GNXR_LIGHT_AREA_TRI;
         l.tri = first + i;
         l.two_sided = 0;
+        l.n_samples = 5;
         l.le[0] = l.le[1] = l.le[2] = 5.0f;
         b->b.lights.push_back(l);
         b->b.tri_light[first + i] = (int)b->b.lights.size() - 1;
@@ -493,6 +494,7 @@ int gnxr_builder_add_sky_light(gnxr_builder *b) {
     memset(&l, 0, sizeof(l));
     l.type = GNXR_LIGHT_SKYBOX;
     l.tri = -1;
+    l.n_samples = 1;
     l.radius = 10.0f;
     for (int i = 0; i < 4; ++i) l.light_to_world[5 * i] = 1.f;
     b->b.lights.push_back(l);
@@ -508,6 +510,7 @@ int gnxr_builder_add_inf_light_data(gnxr_builder *b, const float *rgb, int32_t w
     memset(&l, 0, sizeof(l));
     l.type = GNXR_LIGHT_INFINITE;
     l.tri = -1;
+    l.n_samples = 10;
     for (int i = 0; i < 3; ++i) l.le[i] = power ? power[i] : 1.f;
     if (l2w16) memcpy(l.light_to_world, l2w16, 64);
     else for (int i = 0; i < 4; ++i) l.light_to_world[5 * i] = 1.f;

@@ -735,6 +735,7 @@ bool compile_scene(const gnxr_scene_desc *d, CompiledScene *cs) {
         const gnxr_light &l = d->lights[i];
         DLight &dl = cs->lights[i];
         dl.type = l.type; dl.two_sided = l.two_sided; dl.tri_leaf = -1;
+        dl.n_samples = std::max(1, l.n_samples);
         memcpy(dl.le, l.le, 12);
         if (l.type == GNXR_LIGHT_AREA_TRI) {
             if (l.tri < 0 || l.tri >= d->n_triangles) { set_error("light %d: triangle out of range", i); return false; }

@@ -10,14 +10,28 @@
 // Every light is sampled at every vertex (WhittedIntegrator.cpp:44-55); the shadow rays use the NEE records of
 // PathArrays at slot `light * cap + path` (shadow part only).  Ray differentials are not carried: they only feed texture
 // filtering and every texture on this path is constant.
+//
+// DirectLightingIntegrator::Li (integrators/DirectLightingIntegrator.cpp:30-64) is the same recursion with a different
+// direct-lighting term at each vertex, so it shares the state machine (MODE):
+//   WM_DIRECT_ONE  UniformSampleOneLight without a distribution (core/Integrator.cpp:57-79): one NEE record per vertex
+//   WM_DIRECT_ALL  UniformSampleAllLights (core/Integrator.cpp:25-55): Light::nSamples records per light, drawn from the
+//                  sampler's 2D ARRAYS (core/Sampler.cpp:52-72, 116-146).  Preprocess requests maxDepth x lights x 2 arrays;
+//                  they live in Halton dimensions [5, 5 + 4 * maxDepth * lights), which the regular stream skips, and element
+//                  k of an array for pixel sample s comes from Halton index GetIndexForSample(s * n + k).  The DFS can visit
+//                  more than maxDepth vertices; once the arrays are used up Get2DArray returns nullptr and the reference falls
+//                  back to one Get2D pair per light (Integrator.cpp:38-43) -- counted per path in ws.w.
+// Both use full EstimateDirect records (shadow ray + MIS closest-hit ray, estimate_direct_record in kernels.hip.h).
 #pragma once
 #include "kernels.hip.h"
 
 namespace gnxr {
 
+enum WhittedMode { WM_WHITTED = 0, WM_DIRECT_ONE = 1, WM_DIRECT_ALL = 2 };
+
 struct WhittedArrays {
     int4 *ws;        // x: frames on the stack (= recursion depth of the ray in flight), y: Halton dimension,
-                     // z: frame whose shadow rays are in flight (-1: none), w: 1 = no ray in flight, waiting for those shadow rays
+                     // z: frame whose shadow rays are in flight (-1: none), w: bit0 = no ray in flight, waiting for those shadow
+                     // rays; bit1 = those records were drawn from sample arrays; bits 2..: vertices that consumed arrays so far
     float4 *fr_o;    // [depth * cap + path] ray that reached the vertex: o.xyz, tMax
     float4 *fr_d;    // d.xyz, w: hit code (int bits)
     float4 *fr_L;    // radiance accumulated at the vertex, w: stage (int bits: 0 reflect next, 1 transmit next, 2 done)
@@ -25,12 +39,16 @@ struct WhittedArrays {
     float *fr_pdf;   // pdf of the pending child
     int cap;
     int n_lights;
+    int n_records;   // NEE records per vertex: lights (Whitted), 1 (DIRECT_ONE), sum of Light::nSamples (DIRECT_ALL)
+    int start_dim;   // first regular dimension after the camera sample: 5, or arrayEndDim when arrays were requested
 };
 
 __global__ void __launch_bounds__(kBlock) k_whitted_init(PathArrays pa, WhittedArrays wa, int n_paths) {
     for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_paths; slot += gridDim.x * blockDim.x) {
         uint2 m = pa.meta[slot];
-        wa.ws[slot] = make_int4(0, (int)m.y, -1, 0);
+        // GlobalSampler::Get1D / Get2D jump over [arrayStartDim, arrayEndDim) (core/Sampler.cpp:165-166, 173-174); the camera
+        // sample ends exactly at arrayStartDim = 5
+        wa.ws[slot] = make_int4(0, max((int)m.y, wa.start_dim), -1, 0);
     }
 }
 
@@ -43,25 +61,46 @@ __global__ void __launch_bounds__(kBlock) k_whitted_expand(const int *__restrict
 }
 
 // pflags: bit0 the path is still alive, bit1 it has shadow rays to trace this round, bit2 it has a closest-hit ray to trace.
-template <int LT, bool SPH>
+// ray_counts[0] += shadow rays, ray_counts[1] += MIS closest-hit rays spawned here
+template <int MODE, int LT, bool SPH>
 __global__ void __launch_bounds__(kBlock) k_whitted_step(DScene sc, DRender r, PathArrays pa, WhittedArrays wa, const int *__restrict__ queue, int n,
                                                          unsigned long long *ray_counts) {
-    unsigned long long nShadow = 0;
+    unsigned long long nShadow = 0, nMis = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int path = queue ? queue[i] : i;
         const size_t cap = (size_t)wa.cap;
         int4 ws = wa.ws[path];
         int top = ws.x, pend = ws.z;
+        bool pendArrays = (ws.w & 2) != 0;
+        int nArrayVertices = ws.w >> 2;
         const uint32_t index = pa.meta[path].x;
         SampleStream ss(sc.st, index, ws.y);
         // ---- (a) the shadow rays of the most recent vertex have been traced: lightL, then L += lightL
         if (pend >= 0) {
             Spec lightL(0.f);
-            for (int l = 0; l < wa.n_lights; ++l) {
-                const size_t rec = (size_t)l * cap + path;
-                if ((__float_as_int(pa.sh_d[rec].w) & 1) && pa.sh_o[rec].w == 1.f) {
-                    float4 X = pa.sh_X[rec];
-                    lightL = lightL + Spec(X.x, X.y, X.z);
+            if (MODE == WM_WHITTED) {
+                for (int l = 0; l < wa.n_lights; ++l) {
+                    const size_t rec = (size_t)l * cap + path;
+                    if ((__float_as_int(pa.sh_d[rec].w) & 1) && pa.sh_o[rec].w == 1.f) {
+                        float4 X = pa.sh_X[rec];
+                        lightL = lightL + Spec(X.x, X.y, X.z);
+                    }
+                }
+            } else if (MODE == WM_DIRECT_ONE) {   // EstimateDirect(...) / lightPdf, Integrator.cpp:78
+                float lightPdf;
+                Spec Ld = nee_record_Ld(pa, (size_t)path, &lightPdf);
+                lightL = Ld / lightPdf;
+            } else {                              // UniformSampleAllLights, Integrator.cpp:32-54
+                int base = 0;
+                float xw;
+                for (int l = 0; l < wa.n_lights; ++l) {
+                    const int nSamples = sc.lt.lights[l].n_samples;
+                    if (pendArrays) {
+                        Spec Ld(0.f);
+                        for (int k = 0; k < nSamples; ++k) Ld = Ld + nee_record_Ld(pa, (size_t)(base + k) * cap + path, &xw);
+                        lightL = lightL + Ld / (float)nSamples;
+                    } else lightL = lightL + nee_record_Ld(pa, (size_t)base * cap + path, &xw);
+                    base += nSamples;
                 }
             }
             float4 *Lp = &wa.fr_L[(size_t)pend * cap + path];
@@ -71,7 +110,7 @@ __global__ void __launch_bounds__(kBlock) k_whitted_step(DScene sc, DRender r, P
         }
         bool haveResult = false, traceClosest = false, traceShadow = false, done = false;
         Spec result(0.f);
-        if (ws.w == 0) {
+        if ((ws.w & 1) == 0) {
             // ---- (b) the ray in flight (recursion depth `top`) has been traced
             float4 o4 = pa.ray_o[path], d4 = pa.ray_d[path];
             V3 ro(o4.x, o4.y, o4.z), rd(d4.x, d4.y, d4.z);
@@ -110,26 +149,77 @@ __global__ void __launch_bounds__(kBlock) k_whitted_step(DScene sc, DRender r, P
                 const V3 woN = normalize(-rd);
                 Spec L(0.f);
                 if (triLight >= 0) L = L + area_L(sc.lt.lights[triLight], sp.n, woN);
-                for (int l = 0; l < wa.n_lights; ++l) {
-                    float u0, u1;
-                    ss.get2d(&u0, &u1);
-                    const size_t rec = (size_t)l * cap + path;
-                    int flag = 0;
-                    LightSample ls = light_sample<LT>(sc.lt, l, sp.p, u0, u1);
-                    if (!(ls.Li.is_black() || ls.pdf == 0)) {
-                        Spec f = bsdf.f(woN, ls.wi, BSDF_ALL);
-                        if (!f.is_black()) {
-                            V3 so, sd;
-                            spawn_ray_to(sp.p, sp.pError, sp.n, ls.p1, ls.p1Error, ls.n1, &so, &sd);
-                            Spec X = f * ls.Li * absdot(ls.wi, sp.ns) / ls.pdf;
-                            pa.sh_o[rec] = make_float4(so.x, so.y, so.z, 1 - GX_SHADOW_EPS);
-                            pa.sh_X[rec] = make_float4(X.r, X.g, X.b, 0.f);
-                            pa.sh_d[rec] = make_float4(sd.x, sd.y, sd.z, __int_as_float(1));
-                            flag = 1;
-                            ++nShadow;
+                if (MODE == WM_WHITTED) {
+                    for (int l = 0; l < wa.n_lights; ++l) {
+                        float u0, u1;
+                        ss.get2d(&u0, &u1);
+                        const size_t rec = (size_t)l * cap + path;
+                        int flag = 0;
+                        LightSample ls = light_sample<LT>(sc.lt, l, sp.p, u0, u1);
+                        if (!(ls.Li.is_black() || ls.pdf == 0)) {
+                            Spec f = bsdf.f(woN, ls.wi, BSDF_ALL);
+                            if (!f.is_black()) {
+                                V3 so, sd;
+                                spawn_ray_to(sp.p, sp.pError, sp.n, ls.p1, ls.p1Error, ls.n1, &so, &sd);
+                                Spec X = f * ls.Li * absdot(ls.wi, sp.ns) / ls.pdf;
+                                pa.sh_o[rec] = make_float4(so.x, so.y, so.z, 1 - GX_SHADOW_EPS);
+                                pa.sh_X[rec] = make_float4(X.r, X.g, X.b, 0.f);
+                                pa.sh_d[rec] = make_float4(sd.x, sd.y, sd.z, __int_as_float(1));
+                                flag = 1;
+                                ++nShadow;
+                            }
                         }
+                        if (!flag) pa.sh_d[rec] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
                     }
-                    if (!flag) pa.sh_d[rec] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
+                } else if (sc.lt.n_lights > 0) {
+                    auto record = [&](int slot, int lightNum, float ul0, float ul1, float us0, float us1, float xw) {
+                        const size_t rec = (size_t)slot * cap + path;
+                        const int nflags = estimate_direct_record<LM_ALL, LT>(sc, bsdf, sp, woN, lightNum, ul0, ul1, us0, us1, pa, rec, xw);
+                        if (!nflags) { pa.sh_d[rec] = make_float4(0.f, 0.f, 0.f, __int_as_float(0)); pa.sh_X[rec] = make_float4(0.f, 0.f, 0.f, xw); }
+                        nShadow += nflags & 1;
+                        nMis += (nflags >> 1) & 1;
+                    };
+                    if (MODE == WM_DIRECT_ONE) {
+                        const int nLights = sc.lt.n_lights;
+                        const int lightNum = min((int)(ss.get1d() * (float)nLights), nLights - 1);
+                        const float lightPdf = 1.f / (float)nLights;
+                        float ul0, ul1, us0, us1;
+                        ss.get2d(&ul0, &ul1);
+                        ss.get2d(&us0, &us1);
+                        record(0, lightNum, ul0, ul1, us0, us1, lightPdf);
+                    } else {
+                        pendArrays = nArrayVertices < r.max_depth;   // Get2DArray still has arrays to hand out
+                        const uint32_t stride = (uint32_t)max(1, sc.st.h.stride);
+                        const uint32_t sampleNum = index / stride, pixelOffset = index - sampleNum * stride;
+                        int base = 0;
+                        for (int l = 0; l < wa.n_lights; ++l) {
+                            const int nSamples = sc.lt.lights[l].n_samples;
+                            if (pendArrays) {
+                                const int arrayDim = 5 + 2 * ((nArrayVertices * wa.n_lights + l) * 2);   // uLightArray; uScatteringArray is the next one
+                                for (int k = 0; k < nSamples; ++k) {
+                                    const uint32_t idx = pixelOffset + (sampleNum * (uint32_t)nSamples + (uint32_t)k) * stride;
+                                    float ul0, ul1, us0, us1;
+                                    halton_sample_pair(sc.st, idx, arrayDim, &ul0, &ul1);
+                                    halton_sample_pair(sc.st, idx, arrayDim + 2, &us0, &us1);
+                                    record(base + k, l, ul0, ul1, us0, us1, 1.f);
+                                }
+                            } else {
+                                float ul0, ul1, us0, us1;
+                                ss.get2d(&ul0, &ul1);
+                                ss.get2d(&us0, &us1);
+                                record(base, l, ul0, ul1, us0, us1, 1.f);
+                                for (int k = 1; k < nSamples; ++k) pa.sh_d[(size_t)(base + k) * cap + path] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
+                            }
+                            base += nSamples;
+                        }
+                        if (pendArrays) ++nArrayVertices;
+                    }
+                } else {
+                    // `if (scene.lights.size() > 0)` (DirectLightingIntegrator.cpp:53): no direct term and no sample draws
+                    for (int k = 0; k < wa.n_records; ++k) {
+                        pa.sh_d[(size_t)k * cap + path] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
+                        pa.sh_X[(size_t)k * cap + path] = make_float4(0.f, 0.f, 0.f, 1.f);
+                    }
                 }
                 const size_t fi = (size_t)top * cap + path;
                 wa.fr_o[fi] = o4;
@@ -213,10 +303,11 @@ __global__ void __launch_bounds__(kBlock) k_whitted_step(DScene sc, DRender r, P
             haveResult = true;
         }
         const bool waiting = !traceClosest && !done;
-        wa.ws[path] = make_int4(top, ss.dim, pend, waiting ? 1 : 0);
+        wa.ws[path] = make_int4(top, ss.dim, pend, (waiting ? 1 : 0) | (pendArrays ? 2 : 0) | (nArrayVertices << 2));
         pa.pflags[path] = (unsigned char)(done ? 0 : (1 | (traceShadow ? 2 : 0) | (traceClosest ? 4 : 0)));
     }
     if (nShadow) atomicAdd(ray_counts, nShadow);
+    if (nMis) atomicAdd(ray_counts + 1, nMis);
 }
 
 }  // namespace gnxr

@@ -103,7 +103,7 @@ typedef struct gnxr_light {
     int32_t type;
     int32_t tri;        /* AREA_TRI: index into desc triangles (authoring order)          */
     int32_t two_sided;  /* kept for fidelity; has no effect (DiffuseAreaLight.h:24 quirk) */
-    int32_t _pad;
+    int32_t n_samples;  /* Light::nSamples (core/Light.cpp:19: max(1, n)); used by UniformSampleAllLights only */
     float le[3];        /* AREA_TRI: Lemit ; INFINITE: power scale L                      */
     float radius;       /* SKYBOX: sphere radius                                          */
     float center[3];    /* SKYBOX: sphere centre                                          */
@@ -178,8 +178,15 @@ typedef struct gnxr_scene_desc {
 typedef enum gnxr_integrator {
     GNXR_INTEGRATOR_PATH = 0,    /* integrators/PathIntegrator.cpp:62-208   */
     GNXR_INTEGRATOR_VOLPATH = 1, /* integrators/VolPathIntegrator.cpp:24-159 */
-    GNXR_INTEGRATOR_WHITTED = 2  /* integrators/WhittedIntegrator.cpp:14-68 */
+    GNXR_INTEGRATOR_WHITTED = 2, /* integrators/WhittedIntegrator.cpp:14-68 */
+    GNXR_INTEGRATOR_DIRECT = 3   /* integrators/DirectLightingIntegrator.cpp:11-67 */
 } gnxr_integrator;
+
+/* enum class LightStrategy, integrators/DirectLightingIntegrator.h:13 (same order) */
+typedef enum gnxr_direct_strategy {
+    GNXR_DIRECT_SAMPLE_ALL = 0, /* UniformSampleAllLights, core/Integrator.cpp:25-55: nSamples array samples per light */
+    GNXR_DIRECT_SAMPLE_ONE = 1  /* UniformSampleOneLight without a distribution, core/Integrator.cpp:57-79          */
+} gnxr_direct_strategy;
 
 typedef enum gnxr_light_strategy {
     GNXR_LIGHTS_SPATIAL = 0, /* core/LightDistribution.cpp:70-274 */
@@ -201,7 +208,7 @@ typedef struct gnxr_render_params {
     int32_t light_strategy;     /* gnxr_light_strategy                                       */
     int32_t shard_index, shard_count, shard_rows;
     int32_t samples_per_pass;   /* 0 = auto; samples of one pixel in flight per pass         */
-    int32_t _pad;
+    int32_t direct_strategy;    /* gnxr_direct_strategy (GNXR_INTEGRATOR_DIRECT only)        */
 } gnxr_render_params;
 
 typedef struct gnxr_stats {

@@ -64,6 +64,8 @@ int gnxo_render(gnxo_scene *s, const gnxr_render_params *p, float *rgba, gnxr_st
     camera.medium = scene.cameraMedium;
     Halton halton(p->spp, p->width, p->height, false);
     PathParams pp; pp.maxDepth = p->max_depth; pp.rrThreshold = p->rr_threshold;
+    DirectParams dp; dp.maxDepth = p->max_depth; dp.strategy = p->direct_strategy;
+    if (p->integrator == GNXR_INTEGRATOR_DIRECT) dp.Preprocess(scene);   // SamplerIntegrator::Render, core/Integrator.cpp:227
     VolContext vc;
     vc.rc = &rc;
     vc.media.Init(&scene);
@@ -81,6 +83,7 @@ int gnxo_render(gnxo_scene *s, const gnxr_render_params *p, float *rgba, gnxr_st
             Spec colObj(.0f);
             for (int sidx = sBegin; sidx < sEnd; ++sidx) {
                 SampleStream sampler(&halton, i, j, sidx);
+                if (!dp.arraySizes.empty()) sampler.Request2DArrays(&dp.arraySizes);
                 // Sampler::GetCameraSample, core/Sampler.cpp:14-20
                 P2 f2 = sampler.Get2D();
                 P2 pFilm((Float)i + f2.x, (Float)j + f2.y);
@@ -90,6 +93,7 @@ int gnxo_render(gnxo_scene *s, const gnxr_render_params *p, float *rgba, gnxr_st
                 Spec Li;
                 if (p->integrator == GNXR_INTEGRATOR_VOLPATH) Li = VolPathLi(rc, pp, ray, sampler);
                 else if (p->integrator == GNXR_INTEGRATOR_WHITTED) Li = WhittedLi(rc, pp, ray, sampler, 0);
+                else if (p->integrator == GNXR_INTEGRATOR_DIRECT) Li = DirectLi(rc, dp, ray, sampler, 0);
                 else Li = PathLi(rc, pp, ray, sampler);
                 colObj += Li;
             }

@@ -228,6 +228,7 @@ def main():
     wh["cfg1_checksum"] = np.float64(img[..., :3].astype(np.float64).sum())
     print("cfg1 (Whitted 256x256 @16spp): rays", wh["cfg1_rays"], "checksum %.6f" % float(wh["cfg1_checksum"]))
     save("render_whitted.npz", **wh)
+    direct_goldens(cornell_path, zoo_path)
     # cfg 2 at full size: the counts the survey recorded from the COMPLETE reference
     img, cnt = render(cornell_path, 256, 256, 64)
     checksum = float(img[..., :3].astype(np.float64).sum())
@@ -236,5 +237,28 @@ def main():
     save("cfg2_recorded.npz", rays=cnt, checksum=np.float64(checksum), thumb=img[::4, ::4, :3].copy())
 
 
+def direct_goldens(cornell_path, zoo_path):
+    # ---- 13: DirectLightingIntegrator (no scene of the reference instantiates it): both LightStrategy values,
+    # maxDepth 5 so that the zoo's mirror / glass subtrees use up the requested sample arrays and reach the Get2D fallback
+    dl = {}
+    for name, path, b in [("cornell", cornell_path, scenes.cornell()), ("zoo", zoo_path, scenes.material_zoo())]:
+        for strat, sname in [(0, "all"), (1, "one")]:
+            W, H, spp, depth = 64, 64, 8, 5
+            raw = ol.run_ref(path, "render", None, [W, H, spp, depth, 1.0, 0, 0, 3, strat])
+            key = f"{name}_{sname}"
+            dl[key] = np.frombuffer(raw[:W * H * 16], np.float32).reshape(H, W, 4).copy()
+            dl[key + "_rays"] = np.frombuffer(raw[W * H * 16:W * H * 16 + 16], np.uint64).copy()
+            dl[key + "_cfg"] = np.array([W, H, spp, depth], np.int32)
+            ol.olib().gnxo_max_dimension(1)
+            oimg, st = ol.OracleScene(b).render(gx.DirectLightingIntegrator(sname, depth), W, H, spp)
+            maxdim = ol.olib().gnxo_max_dimension(1)
+            print("direct", key, "rays", dl[key + "_rays"], "max dimension", maxdim)
+            assert maxdim < 1000 and (oimg.view(np.uint32) == dl[key].view(np.uint32)).all()
+    save("render_direct.npz", **dl)
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["direct"]:   # only section 13
+        direct_goldens(scene_file(scenes.cornell(), "cornell"), scene_file(scenes.material_zoo(), "zoo"))
+    else:
+        main()

@@ -386,4 +386,80 @@ inline Spec WhittedLi(const RenderContext &rc, const PathParams &pp, const Ray &
     return L;
 }
 
+// integrators/DirectLightingIntegrator.cpp:11-67 with UniformSampleAllLights (core/Integrator.cpp:25-55) and the specular
+// recursion of SamplerIntegrator (core/Integrator.cpp:321-442).  No scene of the reference instantiates this integrator; it
+// is the second half of SURVEY 8(f).1.
+struct DirectParams {
+    int maxDepth = 5;
+    int strategy = 0;                  // enum class LightStrategy { UniformSampleAll, UniformSampleOne }
+    std::vector<int> nLightSamples;    // Preprocess: sampler.RoundCount(light->nSamples) (Halton: identity)
+    std::vector<int> arraySizes;       // Preprocess: maxDepth x lights x {Request2DArray(n), Request2DArray(n)}
+    void Preprocess(const Scene &scene) {
+        nLightSamples.clear(); arraySizes.clear();
+        if (strategy != 0) return;
+        for (const gnxr_light &l : scene.lights) nLightSamples.push_back(std::max(1, l.n_samples));
+        for (int i = 0; i < maxDepth; ++i)
+            for (size_t j = 0; j < scene.lights.size(); ++j) { arraySizes.push_back(nLightSamples[j]); arraySizes.push_back(nLightSamples[j]); }
+    }
+};
+// core/Integrator.cpp:25-55 (handleMedia = false)
+inline Spec UniformSampleAllLights(const RenderContext &rc, const SurfaceInteraction &isect, const BSDF &bsdf, SampleStream &sampler,
+                                   const std::vector<int> &nLightSamples) {
+    Spec L(0.f);
+    std::vector<P2> uLightArray, uScatteringArray;
+    for (size_t j = 0; j < rc.scene->lights.size(); ++j) {
+        int nSamples = nLightSamples[j];
+        bool haveLight = sampler.Get2DArray(nSamples, &uLightArray);
+        bool haveScattering = sampler.Get2DArray(nSamples, &uScatteringArray);
+        if (!haveLight || !haveScattering) {
+            P2 uLight = sampler.Get2D();
+            P2 uScattering = sampler.Get2D();
+            L += EstimateDirect(rc, isect, bsdf, uScattering, (int)j, uLight);
+        } else {
+            Spec Ld(0.f);
+            for (int k = 0; k < nSamples; ++k) Ld += EstimateDirect(rc, isect, bsdf, uScatteringArray[k], (int)j, uLightArray[k]);
+            L += Ld / (Float)nSamples;
+        }
+    }
+    return L;
+}
+inline Spec DirectLi(const RenderContext &rc, const DirectParams &dp, const Ray &ray, SampleStream &sampler, int depth) {
+    const Scene &scene = *rc.scene;
+    Spec L(0.f);
+    SurfaceInteraction isect;
+    if (!scene.Intersect(ray, &isect)) {
+        for (int light = 0; light < (int)scene.lights.size(); ++light) L += rc.LightLe(light, ray);
+        return L;
+    }
+    BSDF bsdf;
+    if (!ComputeScatteringFunctions(scene, &isect, false, &bsdf)) return DirectLi(rc, dp, isect.SpawnRay(ray.d), sampler, depth);
+    V3 wo = isect.wo;
+    L += rc.Le(isect, wo);
+    if (scene.lights.size() > 0) {
+        if (dp.strategy == 0) L += UniformSampleAllLights(rc, isect, bsdf, sampler, dp.nLightSamples);
+        else L += UniformSampleOneLight(rc, isect, bsdf, sampler, nullptr);
+    }
+    if (depth + 1 < dp.maxDepth) {
+        const V3 ns = isect.sn;
+        {   // SpecularReflect, core/Integrator.cpp:321-371
+            V3 wi;
+            Float pdf;
+            int sampledType = 0;
+            Spec f = bsdf.Sample_f(wo, &wi, sampler.Get2D(), &pdf, BSDF_REFLECTION | BSDF_SPECULAR, &sampledType);
+            if (pdf > 0.f && !f.IsBlack() && AbsDot(wi, ns) != 0.f) L += f * DirectLi(rc, dp, isect.SpawnRay(wi), sampler, depth + 1) * AbsDot(wi, ns) / pdf;
+            else L += Spec(0.f);
+        }
+        {   // SpecularTransmit, core/Integrator.cpp:373-442
+            V3 wi;
+            Float pdf;
+            int sampledType = 0;
+            Spec f = bsdf.Sample_f(wo, &wi, sampler.Get2D(), &pdf, BSDF_TRANSMISSION | BSDF_SPECULAR, &sampledType);
+            Spec Lt(0.f);
+            if (pdf > 0.f && !f.IsBlack() && AbsDot(wi, ns) != 0.f) Lt = f * DirectLi(rc, dp, isect.SpawnRay(wi), sampler, depth + 1) * AbsDot(wi, ns) / pdf;
+            L += Lt;
+        }
+    }
+    return L;
+}
+
 }  // namespace gnxo

@@ -225,14 +225,43 @@ struct SampleStream {
     const Halton *h;
     int64_t index;
     int dimension;
-    SampleStream(const Halton *h, int px, int py, int64_t s) : h(h), index(h->IndexForSample(px, py, s)), dimension(0) {}
+    // array samples, core/Sampler.cpp:52-72 + GlobalSampler::StartPixel :116-146: the 2D arrays requested by the integrator's
+    // Preprocess occupy dimensions [arrayStartDim, arrayEndDim) and the regular stream skips that range (:161-179).  No
+    // integrator on this path requests 1D arrays.  Element k of array i for pixel sample s is drawn from Halton index
+    // GetIndexForSample(s * n + k), dimensions arrayStartDim + 2i and + 2i + 1.
+    static constexpr int arrayStartDim = 5;   // core/Sampler.h:92
+    int arrayEndDim = arrayStartDim;
+    int px = 0, py = 0;
+    int64_t sampleNum = 0;
+    const std::vector<int> *array2DSizes = nullptr;
+    size_t array2DOffset = 0;
+    SampleStream(const Halton *h, int px, int py, int64_t s) : h(h), index(h->IndexForSample(px, py, s)), dimension(0), px(px), py(py), sampleNum(s) {}
+    void Request2DArrays(const std::vector<int> *sizes) {
+        array2DSizes = sizes;
+        arrayEndDim = arrayStartDim + 2 * (int)sizes->size();
+    }
+    // Sampler::Get2DArray, core/Sampler.cpp:67-72; false stands for the nullptr return (all requested arrays consumed)
+    bool Get2DArray(int n, std::vector<P2> *out) {
+        if (!array2DSizes || array2DOffset == array2DSizes->size()) return false;
+        int i = (int)array2DOffset++;
+        out->resize(n);
+        for (int k = 0; k < n; ++k) {
+            int64_t idx = h->IndexForSample(px, py, sampleNum * n + k);
+            (*out)[k] = P2(h->SampleDimension(idx, arrayStartDim + 2 * i), h->SampleDimension(idx, arrayStartDim + 2 * i + 1));
+        }
+        return true;
+    }
     ~SampleStream() {  // highest dimension any sample used: fixtures must stay below PrimeTableSize (reference UB beyond)
         int cur = MaxDimensionSeen().load(std::memory_order_relaxed);
         while (dimension > cur && !MaxDimensionSeen().compare_exchange_weak(cur, dimension)) {}
     }
     static std::atomic<int> &MaxDimensionSeen() { static std::atomic<int> m{0}; return m; }
-    Float Get1D() { return h->SampleDimension(index, dimension++); }
+    Float Get1D() {
+        if (dimension >= arrayStartDim && dimension < arrayEndDim) dimension = arrayEndDim;
+        return h->SampleDimension(index, dimension++);
+    }
     P2 Get2D() {
+        if (dimension + 1 >= arrayStartDim && dimension < arrayEndDim) dimension = arrayEndDim;
         P2 p(h->SampleDimension(index, dimension), h->SampleDimension(index, dimension + 1));
         dimension += 2;
         return p;

@@ -174,7 +174,7 @@ struct RefScene {
             int li = sf.triLight[t];
             if (li >= 0) {
                 const gnxr_light &l = sf.lights[li];
-                area = std::make_shared<DiffuseAreaLight>(identity, MediumInterface(), S3(l.le), 5, tri, l.two_sided != 0);
+                area = std::make_shared<DiffuseAreaLight>(identity, MediumInterface(), S3(l.le), l.n_samples, tri, l.two_sided != 0);
                 lights[li] = area;
             }
             std::shared_ptr<Material> mat = sf.triMat[t] >= 0 ? materials[sf.triMat[t]] : nullptr;
@@ -188,9 +188,9 @@ struct RefScene {
             if (l.type == GNXR_LIGHT_INFINITE) {
                 Matrix4x4 m;
                 memcpy(m.m, l.light_to_world, 64);
-                lights[i] = std::make_shared<InfiniteAreaLight>(Transform(m), S3(l.le), 10, sf.hdrPath);
+                lights[i] = std::make_shared<InfiniteAreaLight>(Transform(m), S3(l.le), l.n_samples, sf.hdrPath);
             } else if (l.type == GNXR_LIGHT_SKYBOX) {
-                lights[i] = std::make_shared<SkyBoxLight>(Transform(), Point3f(l.center[0], l.center[1], l.center[2]), l.radius, "1", 1);
+                lights[i] = std::make_shared<SkyBoxLight>(Transform(), Point3f(l.center[0], l.center[1], l.center[2]), l.radius, "1", l.n_samples);
             }
         }
         bvh = std::make_shared<BVHAccel>(prims, 1);
@@ -579,6 +579,72 @@ Spectrum refWhittedLi(const RayDifferential &ray, const Scene &scene, Sampler &s
     return L;
 }
 
+// DirectLightingIntegrator::Li (integrators/DirectLightingIntegrator.cpp:30-64) with UniformSampleAllLights /
+// UniformSampleOneLight (core/Integrator.cpp:25-79) restated on the reference's classes; the sample arrays come from the
+// reference's own Sampler::Request2DArray / Get2DArray / GlobalSampler::StartPixel.
+Spectrum refDirectLi(const RayDifferential &ray, const Scene &scene, Sampler &sampler, MemoryArena &arena, int strategy,
+                     const std::vector<int> &nLightSamples, int maxDepth, int depth) {
+    Spectrum L(0.f);
+    SurfaceInteraction isect;
+    if (!scene.Intersect(ray, &isect)) {
+        for (const auto &light : scene.lights) L += light->Le(ray);
+        return L;
+    }
+    isect.ComputeScatteringFunctions(ray, arena);
+    if (!isect.bsdf) return refDirectLi(isect.SpawnRay(ray.d), scene, sampler, arena, strategy, nLightSamples, maxDepth, depth);
+    Vector3f wo = isect.wo;
+    L += isect.Le(wo);
+    if (scene.lights.size() > 0) {
+        if (strategy == 0) {   // UniformSampleAllLights
+            for (size_t j = 0; j < scene.lights.size(); ++j) {
+                const std::shared_ptr<Light> &light = scene.lights[j];
+                int nSamples = nLightSamples[j];
+                const Point2f *uLightArray = sampler.Get2DArray(nSamples);
+                const Point2f *uScatteringArray = sampler.Get2DArray(nSamples);
+                if (!uLightArray || !uScatteringArray) {
+                    Point2f uLight = sampler.Get2D();
+                    Point2f uScattering = sampler.Get2D();
+                    L += refEstimateDirect(isect, uScattering, *light, uLight, scene);
+                } else {
+                    Spectrum Ld(0.f);
+                    for (int k = 0; k < nSamples; ++k) Ld += refEstimateDirect(isect, uScatteringArray[k], *light, uLightArray[k], scene);
+                    L += Ld / nSamples;
+                }
+            }
+        } else {               // UniformSampleOneLight, lightDistrib == nullptr
+            int nLights = int(scene.lights.size());
+            int lightNum = std::min((int)(sampler.Get1D() * nLights), nLights - 1);
+            Float lightPdf = Float(1) / nLights;
+            const std::shared_ptr<Light> &light = scene.lights[lightNum];
+            Point2f uLight = sampler.Get2D();
+            Point2f uScattering = sampler.Get2D();
+            L += refEstimateDirect(isect, uScattering, *light, uLight, scene) / lightPdf;
+        }
+    }
+    if (depth + 1 < maxDepth) {
+        {
+            Vector3f wi;
+            Float pdf;
+            Spectrum f = isect.bsdf->Sample_f(wo, &wi, sampler.Get2D(), &pdf, BxDFType(BSDF_REFLECTION | BSDF_SPECULAR));
+            const Normal3f &ns = isect.shading.n;
+            if (pdf > 0.f && !f.IsBlack() && AbsDot(wi, ns) != 0.f)
+                L += f * refDirectLi(isect.SpawnRay(wi), scene, sampler, arena, strategy, nLightSamples, maxDepth, depth + 1) * AbsDot(wi, ns) / pdf;
+            else L += Spectrum(0.f);
+        }
+        {
+            Vector3f wi;
+            Float pdf;
+            Spectrum f = isect.bsdf->Sample_f(wo, &wi, sampler.Get2D(), &pdf, BxDFType(BSDF_TRANSMISSION | BSDF_SPECULAR));
+            Spectrum Lt = Spectrum(0.f);
+            Normal3f ns = isect.shading.n;
+            if (pdf > 0.f && !f.IsBlack() && AbsDot(wi, ns) != 0.f)
+                Lt = f * refDirectLi(isect.SpawnRay(wi), scene, sampler, arena, strategy, nLightSamples, maxDepth, depth + 1) * AbsDot(wi, ns) / pdf;
+            L += Lt;
+        }
+    }
+    return L;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -811,7 +877,8 @@ int main(int argc, char **argv) {
         Float rr = (Float)atof(argv[9]);
         int strat = atoi(argv[10]);
         if (argc > 11 && atoi(argv[11]) > 0) omp_set_num_threads(atoi(argv[11]));
-        const int integ = argc > 12 ? atoi(argv[12]) : 0;   // 0 Path, 1 VolPath, 2 Whitted
+        const int integ = argc > 12 ? atoi(argv[12]) : 0;   // 0 Path, 1 VolPath, 2 Whitted, 3 DirectLighting
+        const int directStrategy = argc > 13 ? atoi(argv[13]) : 0;   // LightStrategy: 0 UniformSampleAll, 1 UniformSampleOne
         const bool volpath = integ == 1;
         const gnxr_camera &c = rs.sf.cam;
         Transform lookat = LookAt(Point3f(c.eye[0], c.eye[1], c.eye[2]), Point3f(c.look[0], c.look[1], c.look[2]), Vector3f(c.up[0], c.up[1], c.up[2]));
@@ -820,6 +887,12 @@ int main(int argc, char **argv) {
         std::unique_ptr<PerspectiveCamera> cam(CreatePerspectiveCamera(W, H, anim));
         HaltonSampler proto(spp, Bounds2i(Point2i(0, 0), Point2i(W, H)), false);
         RefLightDistribution ld(scene, strat);
+        std::vector<int> nLightSamples;
+        if (integ == 3 && directStrategy == 0) {   // DirectLightingIntegrator::Preprocess, DirectLightingIntegrator.cpp:11-28
+            for (const auto &light : scene.lights) nLightSamples.push_back(proto.RoundCount(light->nSamples));
+            for (int i = 0; i < maxDepth; ++i)
+                for (size_t j = 0; j < scene.lights.size(); ++j) { proto.Request2DArray(nLightSamples[j]); proto.Request2DArray(nLightSamples[j]); }
+        }
         std::vector<float> img((size_t)W * H * 4, 0.f);
         rs.counting->nI = 0; rs.counting->nP = 0;
         auto t0 = std::chrono::steady_clock::now();
@@ -836,7 +909,7 @@ int main(int argc, char **argv) {
                     RayDifferential ray;
                     cam->GenerateRayDifferential(cs, &ray);
                     ray.ScaleDifferentials(1 / std::sqrt((Float)ps->samplesPerPixel));
-                    col += integ == 2 ? refWhittedLi(ray, scene, *ps, arena, maxDepth, 0)
+                    col += integ == 3 ? refDirectLi(ray, scene, *ps, arena, directStrategy, nLightSamples, maxDepth, 0) : integ == 2 ? refWhittedLi(ray, scene, *ps, arena, maxDepth, 0)
                                       : (volpath ? refVolPathLi(ray, scene, *ps, arena, ld, maxDepth, rr) : refPathLi(ray, scene, *ps, arena, ld, maxDepth, rr));
                 } while (ps->StartNextSample());
                 col = col / ps->samplesPerPixel;

@@ -26,13 +26,14 @@ def run_sweep(seed=1, ncase=40, verbose=True):
         name = names[c % len(names)]
         b = SCENES[name]()
         vol = name.startswith("vol")
-        kind = "volpath" if vol else str(rng.choice(["path", "path", "whitted"]))
+        kind = "volpath" if vol else str(rng.choice(["path", "path", "whitted", "direct"]))
         depth = int(rng.integers(1, 11)); rr = float(rng.choice([0.25, 1.0, 4.0])); strat = str(rng.choice(["spatial", "uniform", "power"]))
         W, H = int(rng.integers(17, 90)), int(rng.integers(17, 90)); spp = int(rng.choice([4, 8, 16, 64]))
         s0 = int(rng.integers(0, spp)); s1 = int(rng.integers(s0 + 1, spp + 1))
         shards = int(rng.choice([1, 1, 2, 3])); sr = int(rng.choice([1, 2, 5])); si = int(rng.integers(0, shards))
         spp_pass = int(rng.choice([0, 1, 3]))
         if kind == "whitted": integ = gx.WhittedIntegrator(min(depth, 6))
+        elif kind == "direct": integ = gx.DirectLightingIntegrator(str(rng.choice(["all", "one"])), min(depth, 6)); kind = "direct-" + {0: "all", 1: "one"}[integ.directStrategy]
         elif kind == "volpath": integ = gx.VolPathIntegrator(depth, rr, strat)
         else: integ = gx.PathIntegrator(depth, rr, strat)
         kw = dict(spp_begin=s0, spp_end=s1, shard_index=si, shard_count=shards, shard_rows=sr)
@@ -41,7 +42,7 @@ def run_sweep(seed=1, ncase=40, verbose=True):
         oimg, ost = ol.OracleScene(b).render(integ, W, H, spp, **kw)
         same = img[..., :3].view(np.uint32) == oimg[..., :3].view(np.uint32)
         ok = bool(same.all()) and (st["rays_closest"], st["rays_any"]) == (ost["rays_closest"], ost["rays_any"])
-        desc = (f"{name:15s} {kind:8s} depth {depth:2d} rr {rr:4.2f} {strat:8s} {W}x{H} spp {spp} [{s0},{s1}) shard {si}/{shards}x{sr} pass {spp_pass}  identical {same.mean()*100:.3f}% "
+        desc = (f"{name:15s} {kind:10s} depth {depth:2d} rr {rr:4.2f} {strat:8s} {W}x{H} spp {spp} [{s0},{s1}) shard {si}/{shards}x{sr} pass {spp_pass}  identical {same.mean()*100:.3f}% "
                 f"rays {st['rays_closest']}/{st['rays_any']} vs {ost['rays_closest']}/{ost['rays_any']}")
         if not ok: bad.append(desc)
         if verbose: print(("ok  " if ok else "BAD ") + desc + f"  {time.time()-t0:.1f}s", flush=True)

@@ -166,6 +166,21 @@ def test_whitted_images(name, gx):
     assert (st["rays_closest"], st["rays_any"]) == tuple(int(v) for v in g[name + "_rays"])
     assert biteq(img, g[name])
 
+@pytest.mark.parametrize("name", ["cornell_all", "cornell_one", "zoo_all", "zoo_one"])
+def test_direct_lighting_images(name, gx):
+    """DirectLightingIntegrator::Li with UniformSampleAllLights (Sampler::Request2DArray / Get2DArray sample arrays, nSamples = 5
+    per area light, Get2D fallback once the arrays are used up) and UniformSampleOneLight: the restated integrator running on the
+    reference's own Sampler, BSDF, Light and BVH classes produced these images and ray counts (oracle/ref_driver.cpp refDirectLi)."""
+    g = golden("render_direct.npz")
+    W, H, spp, depth = (int(v) for v in g[name + "_cfg"])
+    scene, strat = name.split("_")
+    b = scenes.cornell() if scene == "cornell" else scenes.material_zoo()
+    ol.olib().gnxo_max_dimension(1)
+    img, st = ol.OracleScene(b).render(gx.DirectLightingIntegrator(strat, depth), W, H, spp)
+    assert ol.olib().gnxo_max_dimension(1) < 1000
+    assert (st["rays_closest"], st["rays_any"]) == tuple(int(v) for v in g[name + "_rays"])
+    assert biteq(img, g[name])
+
 
 def test_cfg2_reproduces_the_recorded_reference_run(gx):
     """the complete reference traced 16 058 662 closest-hit and 12 329 468 any-hit rays
