@@ -21,7 +21,7 @@ import os
 import numpy as np
 
 from . import _abi
-from ._abi import (Camera, Hit, Light, Material, Medium, Ray, RenderParams, SceneDesc, Stats)  # noqa: F401
+from ._abi import (Camera, Hit, Light, Material, Medium, Ray, RenderParams, SceneDesc, Stats, Texture)  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GNXR_LIB", os.path.join(_HERE, "libgnxr.so"))   # GNXR_LIB: A/B builds during tuning
@@ -155,6 +155,29 @@ class SceneBuilder:
             density = np.ascontiguousarray(density, dtype=np.float32)
             d = density.ctypes.data_as(C.POINTER(C.c_float))
         return _check(lib().gnxr_builder_add_medium(self._h, C.byref(medium), d))
+
+    def add_image_texture(self, image, su=1.0, sv=1.0, du=0.0, dv=0.0, trilinear=False, max_aniso=8.0, wrap="repeat", scale=1.0, gamma=False):
+        """ImageTexture<RGBSpectrum, Spectrum>(UVMapping2D(su, sv, du, dv), file, doTrilinear, maxAniso, wrap, scale, gamma)
+        (textures/ImageTexture.h; the defaults are those of getSmileFacePlasticMaterial, ui/MaterialList.cpp:31-46).  `image` is
+        the path of a Radiance .hdr or an array [H, W, 3] of decoded texels (row 0 = top row, as stbi_loadf returns them)."""
+        t = Texture(0, 0, 0, su, sv, du, dv, max_aniso, scale, int(bool(trilinear)), {"repeat": 0, "black": 1, "clamp": 2}[wrap], int(bool(gamma)), 0)
+        if isinstance(image, (str, bytes, os.PathLike)):
+            self.texture_paths = getattr(self, "texture_paths", []) + [str(image)]
+            return _check(lib().gnxr_builder_add_texture_file(self._h, C.byref(t), os.fsencode(image)))
+        rgb = np.ascontiguousarray(image, dtype=np.float32)
+        self.texture_paths = getattr(self, "texture_paths", []) + [""]
+        return _check(lib().gnxr_builder_add_texture_data(self._h, C.byref(t), rgb.ctypes.data_as(C.POINTER(C.c_float)), rgb.shape[1], rgb.shape[0]))
+
+    def set_material_texture(self, material, slot, texture):
+        """slot "kd" / "ks": replace the material's constant Kd / Ks texture by image texture `texture`."""
+        return _check(lib().gnxr_builder_set_material_texture(self._h, int(material), {"kd": 0, "ks": 1}[slot], int(texture)))
+
+    def getSmileFacePlasticMaterial(self, image):     # ui/MaterialList.cpp:31-46 (Kd = Ks = the same ImageTexture, roughness 0.1, remap)
+        t = self.add_image_texture(image)
+        m = self.add_material(type=_abi.MAT_PLASTIC, kd=(0.5, 0.5, 0.5), ks=(0.5, 0.5, 0.5), urough=0.1, remap_roughness=1)
+        self.set_material_texture(m, "kd", t)
+        self.set_material_texture(m, "ks", t)
+        return m
 
     def AddSphere(self, center, radius, material, medium_inside=-1, medium_outside=-1):
         """pbrt-v3 quadratic sphere (the reference's shape/Sphere.h is an unfinished stub; see include/gnxr.h)."""

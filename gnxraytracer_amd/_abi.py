@@ -5,7 +5,7 @@ include/gnxr.h field for field (tests/test_abi.py checks sizes and exported symb
 """
 import ctypes as C
 
-GNXR_ABI_VERSION = 2
+GNXR_ABI_VERSION = 3
 
 # gnxr_status
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_OOM, ERR_UNSUPPORTED, ERR_IO = 0, -1, -2, -3, -4, -5
@@ -30,7 +30,7 @@ class Material(C.Structure):
         ("disney_metallic", f32), ("disney_spec_trans", f32), ("disney_spec_tint", f32), ("disney_sheen", f32),
         ("disney_sheen_tint", f32), ("disney_clearcoat", f32), ("disney_clearcoat_gloss", f32),
         ("disney_anisotropic", f32), ("disney_roughness", f32), ("disney_flatness", f32), ("disney_diff_trans", f32),
-        ("disney_scatter_distance", f32 * 3), ("_pad", f32 * 1),
+        ("disney_scatter_distance", f32 * 3), ("kd_texture", i32), ("ks_texture", i32),
     ]
 
 
@@ -55,6 +55,14 @@ class Sphere(C.Structure):
     _fields_ = [("center", f32 * 3), ("radius", f32), ("material", i32), ("medium_inside", i32), ("medium_outside", i32), ("_pad", i32)]
 
 
+class Texture(C.Structure):
+    _fields_ = [("width", i32), ("height", i32), ("texel_offset", i64), ("su", f32), ("sv", f32), ("du", f32), ("dv", f32),
+                ("max_aniso", f32), ("scale", f32), ("trilinear", i32), ("wrap", i32), ("gamma", i32), ("_pad", i32)]
+
+
+WRAP_REPEAT, WRAP_BLACK, WRAP_CLAMP = 0, 1, 2
+
+
 class SceneDesc(C.Structure):
     _fields_ = [
         ("abi_version", i32), ("n_vertices", i32), ("n_triangles", i32), ("n_materials", i32), ("n_lights", i32),
@@ -64,6 +72,7 @@ class SceneDesc(C.Structure):
         ("materials", C.POINTER(Material)), ("lights", C.POINTER(Light)), ("media", C.POINTER(Medium)),
         ("grid_density", C.POINTER(f32)), ("env_rgb", C.POINTER(f32)),
         ("camera", Camera), ("camera_medium", i32), ("n_spheres", i32), ("spheres", C.POINTER(Sphere)),
+        ("n_textures", i32), ("_pad", i32), ("textures", C.POINTER(Texture)), ("texels", C.POINTER(f32)),
     ]
 
 
@@ -136,13 +145,16 @@ PROTOTYPES = {
     "gnxr_builder_add_inf_light": (C.c_int, [VP, C.c_char_p]),
     "gnxr_builder_add_inf_light_data": (C.c_int, [VP, P(f32), i32, i32, P(f32), P(f32)]),
     "gnxr_builder_add_medium": (C.c_int, [VP, P(Medium), P(f32)]),
+    "gnxr_builder_add_texture_data": (C.c_int, [VP, P(Texture), P(f32), i32, i32]),
+    "gnxr_builder_add_texture_file": (C.c_int, [VP, P(Texture), C.c_char_p]),
+    "gnxr_builder_set_material_texture": (C.c_int, [VP, i32, i32, i32]),
     "gnxr_builder_set_camera": (C.c_int, [VP, P(Camera)]),
     "gnxr_builder_desc": (C.c_int, [VP, P(SceneDesc)]),
     "gnxr_write_synthetic_3d": (C.c_int, [C.c_char_p, i32, u32]),
 }
 
 
-ABI_STRUCTS = [Material, Light, Camera, Medium, SceneDesc, RenderParams, Stats, Ray, Hit, Sphere]
+ABI_STRUCTS = [Material, Light, Camera, Medium, SceneDesc, RenderParams, Stats, Ray, Hit, Sphere, Texture]
 
 
 def bind(lib):

@@ -22,6 +22,8 @@ struct Builder {
     std::vector<gnxr_medium> media;
     std::vector<gnxr_sphere> spheres;
     std::vector<float> grid_density;
+    std::vector<gnxr_texture> textures;
+    std::vector<float> texels;
     std::vector<float> env_rgb;
     int env_w = 0, env_h = 0;
     gnxr_camera camera;

@@ -172,6 +172,9 @@ void Builder::fill_desc(gnxr_scene_desc *d) const {
     d->camera_medium = camera_medium;
     d->n_spheres = (int)spheres.size();
     d->spheres = spheres.empty() ? nullptr : spheres.data();
+    d->n_textures = (int)textures.size();
+    d->textures = textures.empty() ? nullptr : textures.data();
+    d->texels = texels.empty() ? nullptr : texels.data();
 }
 
 // ---- `.3d` text meshes: shape/plyRead.h:19-48 ----
@@ -540,6 +543,33 @@ int gnxr_builder_add_medium(gnxr_builder *b, const gnxr_medium *m, const float *
     return (int)b->b.media.size() - 1;
 }
 
+// ImageTexture(UVMapping2D, filename, doTrilinear, maxAniso, wrapMode, scale, gamma), textures/ImageTexture.cpp:40-48
+int gnxr_builder_add_texture_data(gnxr_builder *b, const gnxr_texture *t, const float *rgb, int32_t w, int32_t h) {
+    if (!b || !t || !rgb || w <= 0 || h <= 0) return GNXR_ERR_INVALID;
+    if (t->wrap < GNXR_WRAP_REPEAT || t->wrap > GNXR_WRAP_CLAMP) { set_error("unknown ImageWrap %d", t->wrap); return GNXR_ERR_INVALID; }
+    gnxr_texture tt = *t;
+    tt.width = w; tt.height = h;
+    tt.texel_offset = (int64_t)b->b.texels.size();
+    b->b.texels.insert(b->b.texels.end(), rgb, rgb + (size_t)w * h * 3);
+    b->b.textures.push_back(tt);
+    return (int)b->b.textures.size() - 1;
+}
+int gnxr_builder_add_texture_file(gnxr_builder *b, const gnxr_texture *t, const char *hdr_path) {
+    if (!b || !t || !hdr_path) return GNXR_ERR_INVALID;
+    std::vector<float> rgb;
+    int w = 0, h = 0;
+    if (!read_rgbe(hdr_path, &rgb, &w, &h)) return GNXR_ERR_IO;
+    return gnxr_builder_add_texture_data(b, t, rgb.data(), w, h);
+}
+int gnxr_builder_set_material_texture(gnxr_builder *b, int32_t material, int32_t slot, int32_t texture) {
+    if (!b || material < 0 || material >= (int)b->b.materials.size() || texture < -1 || texture >= (int)b->b.textures.size() || slot < 0 || slot > 1)
+        return GNXR_ERR_INVALID;
+    gnxr_material &m = b->b.materials[material];
+    if (m.type != GNXR_MAT_PLASTIC && !(m.type == GNXR_MAT_MATTE && slot == 0)) { set_error("image textures: Kd of MATTE, Kd / Ks of PLASTIC"); return GNXR_ERR_UNSUPPORTED; }
+    (slot == 0 ? m.kd_texture : m.ks_texture) = texture + 1;
+    return GNXR_OK;
+}
+
 int gnxr_builder_add_sphere(gnxr_builder *b, const float center[3], float radius, int32_t material, int32_t medium_inside, int32_t medium_outside) {
     if (!b || !center || !(radius > 0)) return GNXR_ERR_INVALID;
     gnxr_sphere s;
@@ -655,6 +685,7 @@ int gnxr_abi_sizeof(int which) {
     case 7: return (int)sizeof(gnxr_ray);
     case 8: return (int)sizeof(gnxr_hit);
     case 9: return (int)sizeof(gnxr_sphere);
+    case 10: return (int)sizeof(gnxr_texture);
     default: return -1;
     }
 }

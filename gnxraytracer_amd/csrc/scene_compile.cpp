@@ -657,6 +657,13 @@ bool compile_scene(const gnxr_scene_desc *d, CompiledScene *cs) {
         set_error("scene description has no geometry");
         return false;
     }
+    for (int i = 0; i < d->n_materials; ++i)
+        if (d->materials[i].kd_texture > d->n_textures || d->materials[i].ks_texture > d->n_textures || d->materials[i].kd_texture < 0 || d->materials[i].ks_texture < 0) {
+            set_error("material %d: texture reference out of range", i);
+            return false;
+        }
+    for (int i = 0; i < d->n_materials; ++i)
+        if (d->materials[i].kd_texture || d->materials[i].ks_texture) { set_error("image textures are not on the device yet"); return false; }   // TEXTURE-GUARD
     for (int i = 0; i < 3 * d->n_triangles; ++i)
         if (d->indices[i] < 0 || d->indices[i] >= d->n_vertices) { set_error("triangle index out of range"); return false; }
     for (int i = 0; i < d->n_triangles; ++i) {

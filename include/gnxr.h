@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GNXR_ABI_VERSION 2
+#define GNXR_ABI_VERSION 3
 
 typedef enum gnxr_status {
     GNXR_OK = 0,
@@ -52,8 +52,10 @@ typedef enum gnxr_material_type {
     GNXR_MAT_DISNEY = 6    /* DisneyMaterial.cpp:467-581 (BSSRDF branch out of scope)    */
 } gnxr_material_type;
 
-/* All textures on the path are ConstantTexture (textures/ConstantTexture.h:13-23), so a
- * material is a POD of constants.  Field use per type:
+/* Textures are ConstantTexture (textures/ConstantTexture.h:13-23) except Kd / Ks of MATTE and
+ * PLASTIC, which may be an ImageTexture (kd_texture / ks_texture below; the reference's
+ * getSmileFacePlasticMaterial, ui/MaterialList.cpp:31-46), so a material is a POD of
+ * constants plus two texture references.  Field use per type:
  *   MATTE  : kd, sigma (degrees)
  *   MIRROR : kr
  *   GLASS  : kr, kt, eta[0] (index), urough, vrough, remap_roughness
@@ -89,8 +91,29 @@ typedef struct gnxr_material {
     float disney_flatness;
     float disney_diff_trans;
     float disney_scatter_distance[3];
-    float _pad[1];
+    int32_t kd_texture;     /* 1 + index into desc.textures, 0 == the constant kd (MATTE, PLASTIC) */
+    int32_t ks_texture;     /* 1 + index into desc.textures, 0 == the constant ks (PLASTIC)        */
 } gnxr_material;
+
+/* ---- ImageTexture<RGBSpectrum, Spectrum> + UVMapping2D + MIPMap: textures/ImageTexture.{h,cpp},
+ * core/Texture.cpp:163-175, core/MIPMap.h.  The texels cross the boundary decoded (what stbi_loadf
+ * returns in ImageTexture.cpp:12-38: row 0 is the TOP row; the library applies the y flip of :79-85,
+ * convertIn's scale / inverse gamma, the Lanczos resample to powers of two and the pyramid).  Triangles
+ * carry no per-vertex uv anywhere in the reference (ui/ModelList.cpp passes nullptr), so uv is the default
+ * (0,0),(1,0),(1,1) of Triangle::GetUVs (shape/Triangle.h:60-74).  Filtering needs the camera ray
+ * differentials (camera/Perspective.cpp:86-106, SurfaceInteraction::ComputeDifferentials). ---------- */
+typedef enum gnxr_image_wrap { GNXR_WRAP_REPEAT = 0, GNXR_WRAP_BLACK = 1, GNXR_WRAP_CLAMP = 2 } gnxr_image_wrap; /* enum class ImageWrap, core/MIPMap.h:18 */
+typedef struct gnxr_texture {
+    int32_t width, height;
+    int64_t texel_offset;   /* first float of this texture in desc.texels (RGB fp32, width*height*3)  */
+    float su, sv, du, dv;   /* UVMapping2D(su, sv, du, dv)                                          */
+    float max_aniso;        /* MIPMap::maxAnisotropy (EWA)                                          */
+    float scale;            /* convertIn scale                                                      */
+    int32_t trilinear;      /* doTrilinear: 0 == EWA                                                */
+    int32_t wrap;           /* gnxr_image_wrap                                                      */
+    int32_t gamma;          /* convertIn: InverseGammaCorrect                                       */
+    int32_t _pad;
+} gnxr_texture;
 
 /* ---- lights: lights/{DiffuseAreaLight,InfiniteAreaLight,SkyBoxLight}.cpp ---------- */
 typedef enum gnxr_light_type {
@@ -173,6 +196,10 @@ typedef struct gnxr_scene_desc {
     int32_t camera_medium;      /* medium the camera sits in, -1 == none                     */
     int32_t n_spheres;
     const gnxr_sphere *spheres; /* tested before the triangle BVH; gnxr_hit.prim = n_triangles + sphere index */
+    int32_t n_textures;
+    int32_t _pad;
+    const gnxr_texture *textures;
+    const float *texels;
 } gnxr_scene_desc;
 
 typedef enum gnxr_integrator {
@@ -329,6 +356,12 @@ int gnxr_builder_add_inf_light(gnxr_builder *b, const char *hdr_path);          
 int gnxr_builder_add_inf_light_data(gnxr_builder *b, const float *rgb, int32_t w, int32_t h,
                                     const float *light_to_world16, const float power[3]);
 int gnxr_builder_add_medium(gnxr_builder *b, const gnxr_medium *m, const float *density);
+/* ImageTexture: `t` carries the mapping / filter parameters (width, height, texel_offset are filled in); returns the texture
+ * index.  _file decodes a Radiance .hdr like stbi_loadf; other formats (the reference's awesomeface.jpg) must be decoded by the
+ * caller and passed as texels. */
+int gnxr_builder_add_texture_data(gnxr_builder *b, const gnxr_texture *t, const float *rgb, int32_t w, int32_t h);
+int gnxr_builder_add_texture_file(gnxr_builder *b, const gnxr_texture *t, const char *hdr_path);
+int gnxr_builder_set_material_texture(gnxr_builder *b, int32_t material, int32_t slot /* 0 Kd, 1 Ks */, int32_t texture);
 int gnxr_builder_add_sphere(gnxr_builder *b, const float center[3], float radius, int32_t material, int32_t medium_inside,
                             int32_t medium_outside);                                      /* returns the sphere index */
 int gnxr_builder_set_camera(gnxr_builder *b, const gnxr_camera *cam);

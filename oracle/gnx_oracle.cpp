@@ -90,6 +90,7 @@ int gnxo_render(gnxo_scene *s, const gnxr_render_params *p, float *rgba, gnxr_st
                 (void)sampler.Get1D();  // time
                 P2 pLens = sampler.Get2D();
                 Ray ray = camera.GenerateRay(pFilm, pLens);
+                ray.ScaleDifferentials(1 / std::sqrt((Float)(int64_t)p->spp));   // core/Integrator.cpp:283
                 Spec Li;
                 if (p->integrator == GNXR_INTEGRATOR_VOLPATH) Li = VolPathLi(rc, pp, ray, sampler);
                 else if (p->integrator == GNXR_INTEGRATOR_WHITTED) Li = WhittedLi(rc, pp, ray, sampler, 0);
@@ -183,17 +184,26 @@ void gnxo_primes(int32_t *primes, int32_t *sums) {
 
 // ---- BSDF probe: build the BSDF at a hit of ray (o,d) and evaluate / sample it ----
 // out layout per query (16 floats): f[3], pdf, sample_f[3], sample_pdf, wi[3], sampledType, nComponents, hit, 0, 0
-int gnxo_bsdf_probe(gnxo_scene *s, const gnxr_ray *rays, const float *wiW, const float *u2, int64_t n, int flags, float *out) {
+// flags: BxDFType in the low byte; bits 8.. = 1000 * eps of synthetic ray differentials (0: none; texture-filter probe)
+int gnxo_bsdf_probe(gnxo_scene *s, const gnxr_ray *rays, const float *wiW, const float *u2, int64_t n, int flagsIn, float *out) {
     const Scene &scene = s->scene;
+    const int flags = flagsIn & 0xff;
+    const float diffEps = (float)(flagsIn >> 8) / 1000.f;
     for (int64_t i = 0; i < n; ++i) {
         float *o = out + 16 * i;
         for (int k = 0; k < 16; ++k) o[k] = 0;
         Ray r(V3(rays[i].o[0], rays[i].o[1], rays[i].o[2]), V3(rays[i].d[0], rays[i].d[1], rays[i].d[2]), rays[i].tmax);
+        if (diffEps > 0) {
+            r.hasDifferentials = true;
+            r.rxOrigin = r.ryOrigin = r.o;
+            r.rxDirection = r.d + V3(diffEps, 0, 0);
+            r.ryDirection = r.d + V3(0, diffEps, 0);
+        }
         SurfaceInteraction isect;
         if (!scene.Intersect(r, &isect)) continue;
         BSDF bsdf;
-        if (!ComputeScatteringFunctions(scene, &isect, true, &bsdf)) continue;
-        o[13] = 1;
+        if (!ComputeScatteringFunctions(scene, r, &isect, true, &bsdf)) continue;
+        o[13] = 1; o[14] = isect.dudx; o[15] = isect.dvdy;
         V3 wi(wiW[3 * i], wiW[3 * i + 1], wiW[3 * i + 2]);
         Spec f = bsdf.f(isect.wo, wi, flags);
         o[0] = f[0]; o[1] = f[1]; o[2] = f[2];

@@ -229,6 +229,7 @@ def main():
     print("cfg1 (Whitted 256x256 @16spp): rays", wh["cfg1_rays"], "checksum %.6f" % float(wh["cfg1_checksum"]))
     save("render_whitted.npz", **wh)
     direct_goldens(cornell_path, zoo_path)
+    texture_goldens()
     # cfg 2 at full size: the counts the survey recorded from the COMPLETE reference
     img, cnt = render(cornell_path, 256, 256, 64)
     checksum = float(img[..., :3].astype(np.float64).sum())
@@ -257,8 +258,52 @@ def direct_goldens(cornell_path, zoo_path):
     save("render_direct.npz", **dl)
 
 
+def smile_texture(w=96, h=80):
+    """Synthetic stand-in for the reference's Resources/awesomeface.jpg: a face with black (0) eyes and mouth so that texels
+    switch Plastic's lobes off, on a graded, slightly noisy background; non-power-of-two so that the MIPMap resamples."""
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    u, v = (x + 0.5) / w, (y + 0.5) / h
+    rng = np.random.default_rng(7)
+    img = np.stack([0.95 - 0.3 * v, 0.8 - 0.35 * u * v, 0.15 + 0.25 * u], -1) + rng.uniform(-0.03, 0.03, (h, w, 3))
+    r2 = (u - 0.5) ** 2 + (v - 0.5) ** 2
+    img[r2 > 0.23] = (0.05, 0.12, 0.35)
+    for cx in (0.33, 0.67):
+        img[((u - cx) / 0.07) ** 2 + ((v - 0.38) / 0.11) ** 2 < 1] = 0.0
+    mouth = (np.abs(r2 - 0.09) < 0.012) & (v > 0.55)
+    img[mouth] = 0.0
+    return np.clip(img, 0, 1).astype(np.float32)
+
+
+def texture_goldens():
+    # ---- 14: image-textured materials (SURVEY 8(f).3): ImageTexture / UVMapping2D / MIPMap (Lanczos resample, pyramid, EWA and
+    # trilinear filters, Repeat / Clamp wrap, gamma, scale) + camera ray differentials + ComputeDifferentials, all four
+    # integrators (Whitted / DirectLighting carry the differentials through the mirror and the glass sheet)
+    tex_path = os.path.join(G, "tex_smile_96x80.hdr")
+    if not os.path.exists(tex_path): write_rgbe(tex_path, smile_texture())
+    b = scenes.textured_cornell(tex_path)
+    path = scene_file(b, "textured")
+    out = {}
+    W, H, spp, depth = 72, 64, 8, 5
+    for name, integ, args in [("path", gx.PathIntegrator(depth, 1.0, "spatial"), [0, 0, 0]), ("whitted", gx.WhittedIntegrator(depth), [0, 0, 2]),
+                              ("direct_all", gx.DirectLightingIntegrator("all", depth), [0, 0, 3, 0]), ("volpath", gx.VolPathIntegrator(depth, 1.0, "spatial"), [0, 0, 1])]:
+        raw = ol.run_ref(path, "render", None, [W, H, spp, depth, 1.0] + args)
+        out[name] = np.frombuffer(raw[:W * H * 16], np.float32).reshape(H, W, 4).copy()
+        out[name + "_rays"] = np.frombuffer(raw[W * H * 16:W * H * 16 + 16], np.uint64).copy()
+        ol.olib().gnxo_max_dimension(1)
+        oimg, st = ol.OracleScene(b).render(integ, W, H, spp)
+        maxdim = ol.olib().gnxo_max_dimension(1)
+        same = oimg.view(np.uint32) == out[name].view(np.uint32)
+        print("textured", name, "rays", out[name + "_rays"], (st["rays_closest"], st["rays_any"]), "max dimension", maxdim, "identical %.3f%%" % (100 * same.mean()),
+              "maxabs", float(np.abs(oimg - out[name]).max()))
+        assert maxdim < 1000 and same.all()
+    out["cfg"] = np.array([W, H, spp, depth], np.int32)
+    save("render_textured.npz", **out)
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["direct"]:   # only section 13
         direct_goldens(scene_file(scenes.cornell(), "cornell"), scene_file(scenes.material_zoo(), "zoo"))
+    elif sys.argv[1:] == ["textured"]:   # only section 14
+        texture_goldens()
     else:
         main()

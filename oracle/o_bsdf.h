@@ -499,7 +499,9 @@ inline void Bump(SurfaceInteraction *si) {
 
 // <Material>::ComputeScatteringFunctions(si, arena, TransportMode::Radiance, allowMultipleLobes)
 // Returns false for a null material (no BSDF: PathIntegrator.cpp:121-126).
-inline bool ComputeScatteringFunctions(const Scene &scene, SurfaceInteraction *si, bool allowMultipleLobes, BSDF *out) {
+// SurfaceInteraction::ComputeScatteringFunctions(ray, ...) computes the uv differentials first (Interaction.cpp:56-63).
+inline bool ComputeScatteringFunctions(const Scene &scene, const Ray &ray, SurfaceInteraction *si, bool allowMultipleLobes, BSDF *out) {
+    si->ComputeDifferentials(ray);
     int mi = scene.triMaterial[si->prim];
     if (mi < 0) return false;
     const gnxr_material &m = scene.materials[mi];
@@ -508,7 +510,7 @@ inline bool ComputeScatteringFunctions(const Scene &scene, SurfaceInteraction *s
     switch (m.type) {
     case GNXR_MAT_MATTE: {  // MatteMaterial.cpp:14-32
         BSDF b(*si);
-        Spec r = S3(m.kd).Clamp();
+        Spec r = (m.kd_texture > 0 ? scene.textures[m.kd_texture - 1].Evaluate(si->uv, si->dudx, si->dvdx, si->dudy, si->dvdy) : S3(m.kd)).Clamp();
         Float sig = Clamp(m.sigma, 0, 90);
         if (!r.IsBlack()) {
             Lobe l;
@@ -581,9 +583,10 @@ inline bool ComputeScatteringFunctions(const Scene &scene, SurfaceInteraction *s
     }
     case GNXR_MAT_PLASTIC: {  // PlasticMaterial.cpp:15-41
         BSDF b(*si);
-        Spec kd = S3(m.kd).Clamp();
+        auto tex = [&](int t, const float *c) { return t > 0 ? scene.textures[t - 1].Evaluate(si->uv, si->dudx, si->dvdx, si->dudy, si->dvdy) : S3(c); };
+        Spec kd = tex(m.kd_texture, m.kd).Clamp();
         if (!kd.IsBlack()) { Lobe l; l.kind = L_LAMBERT; l.type = BSDF_REFLECTION | BSDF_DIFFUSE; l.R = kd; b.Add(l); }
-        Spec ks = S3(m.ks).Clamp();
+        Spec ks = tex(m.ks_texture, m.ks).Clamp();
         if (!ks.IsBlack()) {
             Lobe l; l.kind = L_MICRO_REFL; l.type = BSDF_REFLECTION | BSDF_GLOSSY; l.R = ks;
             l.fresnel.kind = F_DIELECTRIC; l.fresnel.etaI = 1.5f; l.fresnel.etaT = 1.f;

@@ -6,117 +6,9 @@
 //   Lanczos                                                    core/Texture.cpp:152-161
 //   SkyBoxLight::Le / Sample_Li (image load failed)            lights/SkyBoxLight.cpp:43-85
 #pragma once
-#include "o_scene.h"
+#include "o_scene.h"   // o_texture.h (MIPMap) comes with it
 
 namespace gnxo {
-
-inline Float Lanczos(Float x, Float tau = 2) {
-    x = std::abs(x);
-    if (x < 1e-5f) return 1;
-    if (x > 1.f) return 0;
-    x *= Pi;
-    Float s = std::sin(x * tau) / (x * tau);
-    Float lanczos = std::sin(x) / x;
-    return s * lanczos;
-}
-inline bool IsPowerOf2(int v) { return v && !(v & (v - 1)); }
-inline int RoundUpPow2(int v) { v--; v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16; return v + 1; }
-inline int Log2Int(uint32_t v) { return 31 - __builtin_clz(v); }
-inline Float Log2(Float x) { const Float invLog2 = 1.442695040888963387004650940071; return std::log(x) * invLog2; }
-inline int ModI(int a, int b) { int r = a - (a / b) * b; return (r < 0) ? r + b : r; }
-
-// MIPMap<RGBSpectrum> with doTrilinear=false, wrapMode=Repeat (the only instantiation on the path)
-struct MIPMapRGB {
-    int resX = 0, resY = 0;
-    std::vector<std::vector<Spec>> pyramid;
-    std::vector<int> lw, lh;
-    struct ResampleWeight { int firstTexel; Float weight[4]; };
-    static std::vector<ResampleWeight> resampleWeights(int oldRes, int newRes) {
-        std::vector<ResampleWeight> wt(newRes);
-        Float filterwidth = 2.f;
-        for (int i = 0; i < newRes; ++i) {
-            Float center = (i + .5f) * oldRes / newRes;
-            wt[i].firstTexel = std::floor((center - filterwidth) + 0.5f);
-            for (int j = 0; j < 4; ++j) {
-                Float pos = wt[i].firstTexel + j + .5f;
-                wt[i].weight[j] = Lanczos((pos - center) / filterwidth);
-            }
-            Float invSumWts = 1 / (wt[i].weight[0] + wt[i].weight[1] + wt[i].weight[2] + wt[i].weight[3]);
-            for (int j = 0; j < 4; ++j) wt[i].weight[j] *= invSumWts;
-        }
-        return wt;
-    }
-    void Build(int rx, int ry, const Spec *img) {
-        resX = rx; resY = ry;
-        std::vector<Spec> resampled;
-        if (!IsPowerOf2(resX) || !IsPowerOf2(resY)) {
-            int px = RoundUpPow2(resX), py = RoundUpPow2(resY);
-            std::vector<ResampleWeight> sWeights = resampleWeights(resX, px);
-            resampled.assign((size_t)px * py, Spec(0.f));
-            for (int64_t t = 0; t < resY; ++t)
-                for (int s = 0; s < px; ++s) {
-                    resampled[t * px + s] = Spec(0.f);
-                    for (int j = 0; j < 4; ++j) {
-                        int origS = sWeights[s].firstTexel + j;
-                        origS = ModI(origS, resX);
-                        if (origS >= 0 && origS < resX) resampled[t * px + s] += sWeights[s].weight[j] * img[t * resX + origS];
-                    }
-                }
-            std::vector<ResampleWeight> tWeights = resampleWeights(resY, py);
-            std::vector<Spec> workData(py);
-            for (int64_t s = 0; s < px; ++s) {
-                for (int t = 0; t < py; ++t) {
-                    workData[t] = Spec(0.f);
-                    for (int j = 0; j < 4; ++j) {
-                        int offset = tWeights[t].firstTexel + j;
-                        offset = ModI(offset, resY);
-                        if (offset >= 0 && offset < resY) workData[t] += tWeights[t].weight[j] * resampled[offset * px + s];
-                    }
-                }
-                for (int t = 0; t < py; ++t) resampled[t * px + s] = workData[t].Clamp(0.f, Infinity);
-            }
-            resX = px; resY = py;
-        }
-        int nLevels = 1 + Log2Int(std::max(resX, resY));
-        pyramid.resize(nLevels); lw.resize(nLevels); lh.resize(nLevels);
-        lw[0] = resX; lh[0] = resY;
-        if (!resampled.empty()) pyramid[0] = resampled;
-        else pyramid[0].assign(img, img + (size_t)resX * resY);
-        for (int i = 1; i < nLevels; ++i) {
-            int sRes = std::max(1, lw[i - 1] / 2), tRes = std::max(1, lh[i - 1] / 2);
-            lw[i] = sRes; lh[i] = tRes;
-            pyramid[i].resize((size_t)sRes * tRes);
-            for (int t = 0; t < tRes; t++)
-                for (int s = 0; s < sRes; ++s)
-                    pyramid[i][t * sRes + s] = .25f * (Texel(i - 1, 2 * s, 2 * t) + Texel(i - 1, 2 * s + 1, 2 * t) +
-                                                       Texel(i - 1, 2 * s, 2 * t + 1) + Texel(i - 1, 2 * s + 1, 2 * t + 1));
-        }
-    }
-    int Levels() const { return (int)pyramid.size(); }
-    const Spec &Texel(int level, int s, int t) const {
-        s = ModI(s, lw[level]); t = ModI(t, lh[level]);
-        return pyramid[level][(size_t)t * lw[level] + s];
-    }
-    Spec triangle(int level, const P2 &st) const {
-        level = Clamp(level, 0, Levels() - 1);
-        Float s = st.x * lw[level] - 0.5f;
-        Float t = st.y * lh[level] - 0.5f;
-        int s0 = std::floor(s), t0 = std::floor(t);
-        Float ds = s - s0, dt = t - t0;
-        return (1 - ds) * (1 - dt) * Texel(level, s0, t0) + (1 - ds) * dt * Texel(level, s0, t0 + 1) +
-               ds * (1 - dt) * Texel(level, s0 + 1, t0) + ds * dt * Texel(level, s0 + 1, t0 + 1);
-    }
-    Spec Lookup(const P2 &st, Float width = 0.f) const {
-        Float level = Levels() - 1 + Log2(std::max(width, (Float)1e-8));
-        if (level < 0) return triangle(0, st);
-        else if (level >= Levels() - 1) return Texel(Levels() - 1, 0, 0);
-        else {
-            int iLevel = std::floor(level);
-            Float delta = level - iLevel;
-            return Lerp(delta, triangle(iLevel, st), triangle(iLevel + 1, st));
-        }
-    }
-};
 
 }  // namespace gnxo
 

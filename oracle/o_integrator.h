@@ -259,6 +259,7 @@ inline Spec PathLi(const RenderContext &rc, const PathParams &pp, const Ray &r, 
     const Scene &scene = *rc.scene;
     Spec L(0.f), beta(1.f);
     Ray ray(r);
+    ray.hasDifferentials = false;   // `Ray ray(r);` (PathIntegrator.cpp:67) slices the RayDifferential: Path never filters textures
     bool specularBounce = false;
     int bounces;
     Float etaScale = 1;
@@ -271,7 +272,7 @@ inline Spec PathLi(const RenderContext &rc, const PathParams &pp, const Ray &r, 
         }
         if (!foundIntersection || bounces >= pp.maxDepth) break;
         BSDF bsdf;
-        if (!ComputeScatteringFunctions(scene, &isect, true, &bsdf)) {
+        if (!ComputeScatteringFunctions(scene, ray, &isect, true, &bsdf)) {
             ray = isect.SpawnRay(ray.d);
             bounces--;
             continue;

@@ -293,6 +293,16 @@ struct Ray {
     Ray() : tMax(Infinity), medium(-1) {}
     Ray(const V3 &o, const V3 &d, Float tMax = Infinity, int medium = -1) : o(o), d(d), tMax(tMax), medium(medium) {}
     V3 operator()(Float t) const { return o + d * t; }
+    // RayDifferential, core/Geometry.h:855-892: only camera rays and the specular children of Whitted / DirectLighting carry
+    // differentials; every other ray is a plain Ray (hasDifferentials == false)
+    bool hasDifferentials = false;
+    V3 rxOrigin, ryOrigin, rxDirection, ryDirection;
+    void ScaleDifferentials(Float s) {   // Geometry.h:874-880
+        rxOrigin = o + (rxOrigin - o) * s;
+        ryOrigin = o + (ryOrigin - o) * s;
+        rxDirection = d + (rxDirection - d) * s;
+        ryDirection = d + (ryDirection - d) * s;
+    }
 };
 
 struct Bounds3 {

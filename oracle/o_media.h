@@ -306,7 +306,7 @@ inline Spec VolPathLi(const RenderContext &rc, const PathParams &pp, const Ray &
             }
             if (!foundIntersection || bounces >= pp.maxDepth) break;
             BSDF bsdf;
-            if (!ComputeScatteringFunctions(scene, &isect, true, &bsdf)) {
+            if (!ComputeScatteringFunctions(scene, ray, &isect, true, &bsdf)) {
                 ray = isect.SpawnRay(ray.d);
                 bounces--;
                 continue;
@@ -336,9 +336,51 @@ inline Spec VolPathLi(const RenderContext &rc, const PathParams &pp, const Ray &
     return L;
 }
 
+// Ray differentials of the specular children, SamplerIntegrator::SpecularReflect / SpecularTransmit (core/Integrator.cpp:335-354,
+// 376-436).  shading.dndu / dndv are zero (no per-vertex normals on this path) but the products are kept: an infinite uv
+// differential turns them into NaN exactly as in the reference.
+inline void ReflectDifferentials(const Ray &ray, const SurfaceInteraction &isect, const V3 &wo, const V3 &wi, Ray *rd) {
+    if (!ray.hasDifferentials) return;
+    const V3 ns = isect.sn, dndu(0, 0, 0), dndv(0, 0, 0);
+    rd->hasDifferentials = true;
+    rd->rxOrigin = isect.p + isect.dpdx;
+    rd->ryOrigin = isect.p + isect.dpdy;
+    V3 dndx = dndu * isect.dudx + dndv * isect.dvdx;
+    V3 dndy = dndu * isect.dudy + dndv * isect.dvdy;
+    V3 dwodx = -ray.rxDirection - wo, dwody = -ray.ryDirection - wo;
+    Float dDNdx = Dot(dwodx, ns) + Dot(wo, dndx);
+    Float dDNdy = Dot(dwody, ns) + Dot(wo, dndy);
+    rd->rxDirection = wi - dwodx + 2.f * V3(Dot(wo, ns) * dndx + dDNdx * ns);
+    rd->ryDirection = wi - dwody + 2.f * V3(Dot(wo, ns) * dndy + dDNdy * ns);
+}
+inline void TransmitDifferentials(const Ray &ray, const SurfaceInteraction &isect, Float bsdfEta, const V3 &wo, const V3 &wi, Ray *rd) {
+    if (!ray.hasDifferentials) return;
+    V3 ns = isect.sn;
+    const V3 dndu(0, 0, 0), dndv(0, 0, 0);
+    rd->hasDifferentials = true;
+    rd->rxOrigin = isect.p + isect.dpdx;
+    rd->ryOrigin = isect.p + isect.dpdy;
+    V3 dndx = dndu * isect.dudx + dndv * isect.dvdx;
+    V3 dndy = dndu * isect.dudy + dndv * isect.dvdy;
+    Float eta = 1 / bsdfEta;
+    if (Dot(wo, ns) < 0) {
+        eta = 1 / eta;
+        ns = -ns;
+        dndx = -dndx;
+        dndy = -dndy;
+    }
+    V3 dwodx = -ray.rxDirection - wo, dwody = -ray.ryDirection - wo;
+    Float dDNdx = Dot(dwodx, ns) + Dot(wo, dndx);
+    Float dDNdy = Dot(dwody, ns) + Dot(wo, dndy);
+    Float mu = eta * Dot(wo, ns) - AbsDot(wi, ns);
+    Float dmudx = (eta - (eta * eta * Dot(wo, ns)) / AbsDot(wi, ns)) * dDNdx;
+    Float dmudy = (eta - (eta * eta * Dot(wo, ns)) / AbsDot(wi, ns)) * dDNdy;
+    rd->rxDirection = wi - eta * dwodx + V3(mu * dndx + dmudx * ns);
+    rd->ryDirection = wi - eta * dwody + V3(mu * dndy + dmudy * ns);
+}
+
 // integrators/WhittedIntegrator.cpp:14-68 + SamplerIntegrator::SpecularReflect / SpecularTransmit, core/Integrator.cpp:321-442
-// (BASELINE config 1: the reference's CPU-only path).  Ray differentials are carried by the reference but feed only texture
-// filtering, and every texture on this path is a ConstantTexture, so they do not reach the radiance and are not restated.
+// (BASELINE config 1: the reference's CPU-only path).
 // The depth-first recursion consumes the sample stream in DFS order: all lights of a vertex, then the reflected subtree,
 // then the transmitted subtree.
 inline Spec WhittedLi(const RenderContext &rc, const PathParams &pp, const Ray &ray, SampleStream &sampler, int depth) {
@@ -351,7 +393,7 @@ inline Spec WhittedLi(const RenderContext &rc, const PathParams &pp, const Ray &
     }
     V3 wo = isect.wo;
     BSDF bsdf;
-    if (!ComputeScatteringFunctions(scene, &isect, false, &bsdf)) return WhittedLi(rc, pp, isect.SpawnRay(ray.d), sampler, depth);
+    if (!ComputeScatteringFunctions(scene, ray, &isect, false, &bsdf)) return WhittedLi(rc, pp, isect.SpawnRay(ray.d), sampler, depth);
     const V3 n = isect.sn;   // `const Normal3f &n = isect.shading.n` is read after Bump ran
     L += rc.Le(isect, wo);
     Spec lightL(0.f);
@@ -369,8 +411,11 @@ inline Spec WhittedLi(const RenderContext &rc, const PathParams &pp, const Ray &
             int sampledType = 0;
             Spec f = bsdf.Sample_f(wo, &wi, sampler.Get2D(), &pdf, BSDF_REFLECTION | BSDF_SPECULAR, &sampledType);
             const V3 ns = isect.sn;
-            if (pdf > 0.f && !f.IsBlack() && AbsDot(wi, ns) != 0.f) L += f * WhittedLi(rc, pp, isect.SpawnRay(wi), sampler, depth + 1) * AbsDot(wi, ns) / pdf;
-            else L += Spec(0.f);
+            if (pdf > 0.f && !f.IsBlack() && AbsDot(wi, ns) != 0.f) {
+                Ray rd = isect.SpawnRay(wi);
+                ReflectDifferentials(ray, isect, wo, wi, &rd);
+                L += f * WhittedLi(rc, pp, rd, sampler, depth + 1) * AbsDot(wi, ns) / pdf;
+            } else L += Spec(0.f);
         }
         {   // SpecularTransmit
             V3 wi;
@@ -379,7 +424,11 @@ inline Spec WhittedLi(const RenderContext &rc, const PathParams &pp, const Ray &
             Spec f = bsdf.Sample_f(wo, &wi, sampler.Get2D(), &pdf, BSDF_TRANSMISSION | BSDF_SPECULAR, &sampledType);
             const V3 ns = isect.sn;
             Spec Lt(0.f);
-            if (pdf > 0.f && !f.IsBlack() && AbsDot(wi, ns) != 0.f) Lt = f * WhittedLi(rc, pp, isect.SpawnRay(wi), sampler, depth + 1) * AbsDot(wi, ns) / pdf;
+            if (pdf > 0.f && !f.IsBlack() && AbsDot(wi, ns) != 0.f) {
+                Ray rd = isect.SpawnRay(wi);
+                TransmitDifferentials(ray, isect, bsdf.eta, wo, wi, &rd);
+                Lt = f * WhittedLi(rc, pp, rd, sampler, depth + 1) * AbsDot(wi, ns) / pdf;
+            }
             L += Lt;
         }
     }
@@ -432,7 +481,7 @@ inline Spec DirectLi(const RenderContext &rc, const DirectParams &dp, const Ray 
         return L;
     }
     BSDF bsdf;
-    if (!ComputeScatteringFunctions(scene, &isect, false, &bsdf)) return DirectLi(rc, dp, isect.SpawnRay(ray.d), sampler, depth);
+    if (!ComputeScatteringFunctions(scene, ray, &isect, false, &bsdf)) return DirectLi(rc, dp, isect.SpawnRay(ray.d), sampler, depth);
     V3 wo = isect.wo;
     L += rc.Le(isect, wo);
     if (scene.lights.size() > 0) {
@@ -446,8 +495,11 @@ inline Spec DirectLi(const RenderContext &rc, const DirectParams &dp, const Ray 
             Float pdf;
             int sampledType = 0;
             Spec f = bsdf.Sample_f(wo, &wi, sampler.Get2D(), &pdf, BSDF_REFLECTION | BSDF_SPECULAR, &sampledType);
-            if (pdf > 0.f && !f.IsBlack() && AbsDot(wi, ns) != 0.f) L += f * DirectLi(rc, dp, isect.SpawnRay(wi), sampler, depth + 1) * AbsDot(wi, ns) / pdf;
-            else L += Spec(0.f);
+            if (pdf > 0.f && !f.IsBlack() && AbsDot(wi, ns) != 0.f) {
+                Ray rd = isect.SpawnRay(wi);
+                ReflectDifferentials(ray, isect, wo, wi, &rd);
+                L += f * DirectLi(rc, dp, rd, sampler, depth + 1) * AbsDot(wi, ns) / pdf;
+            } else L += Spec(0.f);
         }
         {   // SpecularTransmit, core/Integrator.cpp:373-442
             V3 wi;
@@ -455,7 +507,11 @@ inline Spec DirectLi(const RenderContext &rc, const DirectParams &dp, const Ray 
             int sampledType = 0;
             Spec f = bsdf.Sample_f(wo, &wi, sampler.Get2D(), &pdf, BSDF_TRANSMISSION | BSDF_SPECULAR, &sampledType);
             Spec Lt(0.f);
-            if (pdf > 0.f && !f.IsBlack() && AbsDot(wi, ns) != 0.f) Lt = f * DirectLi(rc, dp, isect.SpawnRay(wi), sampler, depth + 1) * AbsDot(wi, ns) / pdf;
+            if (pdf > 0.f && !f.IsBlack() && AbsDot(wi, ns) != 0.f) {
+                Ray rd = isect.SpawnRay(wi);
+                TransmitDifferentials(ray, isect, bsdf.eta, wo, wi, &rd);
+                Lt = f * DirectLi(rc, dp, rd, sampler, depth + 1) * AbsDot(wi, ns) / pdf;
+            }
             L += Lt;
         }
     }

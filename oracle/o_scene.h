@@ -14,6 +14,7 @@
 
 #include "../include/gnxr.h"
 #include "o_sampler.h"
+#include "o_texture.h"
 
 namespace gnxo {
 
@@ -49,6 +50,51 @@ struct SurfaceInteraction : Interaction {
     V3 sn, sdpdu, sdpdv;  // shading.n / dpdu / dpdv
     int prim = -1;         // triangle index in AUTHORING order (desc order)
     Float b0 = 0, b1 = 0, b2 = 0, t = 0;
+    // SurfaceInteraction::ComputeDifferentials, Interaction.cpp:65-112 (mutable members there)
+    V3 dpdx, dpdy;
+    Float dudx = 0, dvdx = 0, dudy = 0, dvdy = 0;
+    static bool SolveLinearSystem2x2(const Float A[2][2], const Float B[2], Float *x0, Float *x1) {   // Transform.cpp:12-20
+        Float det = A[0][0] * A[1][1] - A[0][1] * A[1][0];
+        if (std::abs(det) < 1e-10f) return false;
+        *x0 = (A[1][1] * B[0] - A[0][1] * B[1]) / det;
+        *x1 = (A[0][0] * B[1] - A[1][0] * B[0]) / det;
+        if (std::isnan(*x0) || std::isnan(*x1)) return false;
+        return true;
+    }
+    void ComputeDifferentials(const Ray &ray) {
+        bool ok = ray.hasDifferentials;
+        if (ok) {
+            Float d = Dot(n, V3(p.x, p.y, p.z));
+            Float tx = -(Dot(n, ray.rxOrigin) - d) / Dot(n, ray.rxDirection);
+            Float ty = 0;
+            if (std::isinf(tx) || std::isnan(tx)) ok = false;
+            V3 px, py;
+            if (ok) {
+                px = ray.rxOrigin + tx * ray.rxDirection;
+                ty = -(Dot(n, ray.ryOrigin) - d) / Dot(n, ray.ryDirection);
+                if (std::isinf(ty) || std::isnan(ty)) ok = false;
+            }
+            if (ok) {
+                py = ray.ryOrigin + ty * ray.ryDirection;
+                dpdx = px - p;
+                dpdy = py - p;
+                int dim[2];
+                if (std::abs(n.x) > std::abs(n.y) && std::abs(n.x) > std::abs(n.z)) { dim[0] = 1; dim[1] = 2; }
+                else if (std::abs(n.y) > std::abs(n.z)) { dim[0] = 0; dim[1] = 2; }
+                else { dim[0] = 0; dim[1] = 1; }
+                Float A[2][2] = {{dpdu[dim[0]], dpdv[dim[0]]}, {dpdu[dim[1]], dpdv[dim[1]]}};
+                Float Bx[2] = {px[dim[0]] - p[dim[0]], px[dim[1]] - p[dim[1]]};
+                Float By[2] = {py[dim[0]] - p[dim[0]], py[dim[1]] - p[dim[1]]};
+                if (!SolveLinearSystem2x2(A, Bx, &dudx, &dvdx)) dudx = dvdx = 0;
+                if (!SolveLinearSystem2x2(A, By, &dudy, &dvdy)) dudy = dvdy = 0;
+                return;
+            }
+        }
+        // no differentials, or the `fail:` label (an auxiliary ray parallel to the surface)
+        dudx = dvdx = 0;
+        dudy = dvdy = 0;
+        dpdx = dpdy = V3(0, 0, 0);
+    }
     // Interaction.cpp:36-54 (dndu/dndv are zero on this path)
     void SetShadingGeometry(const V3 &dpdus, const V3 &dpdvs, bool orientationIsAuthoritative) {
         sn = Normalize(Cross(dpdus, dpdvs));
@@ -84,6 +130,7 @@ struct Scene {
     gnxr_camera camera;
     int cameraMedium = -1;
     std::vector<gnxr_sphere> spheres;   // prim index = nTriangles() + sphere index; tested before the triangle BVH
+    std::vector<ImageTexture> textures; // gnxr_material::kd_texture / ks_texture - 1
     // BVH
     std::vector<LinearBVHNode> nodes;
     std::vector<int> orderedPrims;  // BVH leaf order -> authoring index (primitives.swap(orderedPrims), BVHAccel.cpp:171)
@@ -123,6 +170,8 @@ struct Scene {
         if (envW && envH) envRgb.assign(d->env_rgb, d->env_rgb + (size_t)envW * envH * 3);
         camera = d->camera;
         cameraMedium = d->camera_medium;
+        textures.resize(d->n_textures);
+        for (int i = 0; i < d->n_textures; ++i) textures[i].Build(d->textures[i], d->texels + d->textures[i].texel_offset);
         if (d->n_spheres > 0) {
             spheres.assign(d->spheres, d->spheres + d->n_spheres);
             for (const gnxr_sphere &sp : spheres) {   // per-primitive tables continue past the triangles
@@ -556,8 +605,7 @@ struct Camera {
         dxCamera = XPoint(rasterToCamera, V3(1, 0, 0)) - XPoint(rasterToCamera, V3(0, 0, 0));
         dyCamera = XPoint(rasterToCamera, V3(0, 1, 0)) - XPoint(rasterToCamera, V3(0, 0, 0));
     }
-    // Perspective.cpp:62-112 (main ray only; differentials are dropped by PathIntegrator's Ray copy,
-    // PathIntegrator.cpp:67) + Transform::operator()(Ray), Transform.h:230-244
+    // GenerateRayDifferential, Perspective.cpp:62-112 + Transform::operator()(RayDifferential), Transform.h:246-256
     Ray GenerateRay(const P2 &pFilm, const P2 &pLens) const {
         V3 pCamera = XPoint(rasterToCamera, V3(pFilm.x, pFilm.y, 0));
         V3 dir = Normalize(V3(pCamera.x, pCamera.y, pCamera.z));
@@ -580,7 +628,33 @@ struct Camera {
             ow += dw * dt;
             tMax -= dt;
         }
-        return Ray(ow, dw, tMax, medium);
+        Ray ray(ow, dw, tMax, medium);
+        // offset rays, Perspective.cpp:86-106 (camera space), then CameraToWorld: plain point / vector transforms
+        V3 rxO, ryO, rxD, ryD;
+        if (lensRadius > 0) {
+            P2 dsk = ConcentricSampleDisk(pLens);
+            P2 pl(lensRadius * dsk.x, lensRadius * dsk.y);
+            V3 dx = Normalize(pCamera + dxCamera);
+            Float ft = focalDistance / dx.z;
+            V3 pFocus = V3(0, 0, 0) + (ft * dx);
+            rxO = V3(pl.x, pl.y, 0);
+            rxD = Normalize(pFocus - rxO);
+            V3 dy = Normalize(pCamera + dyCamera);
+            ft = focalDistance / dy.z;
+            pFocus = V3(0, 0, 0) + (ft * dy);
+            ryO = V3(pl.x, pl.y, 0);
+            ryD = Normalize(pFocus - ryO);
+        } else {
+            rxO = ryO = o;
+            rxD = Normalize(pCamera + dxCamera);
+            ryD = Normalize(pCamera + dyCamera);
+        }
+        ray.rxOrigin = XPoint(cameraToWorld, rxO);
+        ray.ryOrigin = XPoint(cameraToWorld, ryO);
+        ray.rxDirection = XVector(cameraToWorld, rxD);
+        ray.ryDirection = XVector(cameraToWorld, ryD);
+        ray.hasDifferentials = true;
+        return ray;
     }
 };
 

@@ -47,6 +47,7 @@
 #include "samplers/LowDiscrepancy.h"
 #include "shape/Triangle.h"
 #include "textures/ConstantTexture.h"
+#include "textures/ImageTexture.h"
 
 #include "include/gnxr.h"
 
@@ -86,6 +87,8 @@ struct SceneFile {
     std::vector<gnxr_medium> media;
     std::vector<float> density, env;
     std::string hdrPath;
+    std::vector<gnxr_texture> textures;        // file version 2
+    std::vector<std::string> texturePaths;     // the image file each ImageTexture loads (the texels themselves stay behind)
 };
 
 bool readScene(const char *path, SceneFile *s) {
@@ -105,6 +108,16 @@ bool readScene(const char *path, SceneFile *s) {
     ok = ok && fread(&nd, 8, 1, f) == 1 && rd(s->density, (size_t)nd) && rd(s->env, 3 * (size_t)s->envw * s->envh);
     int32_t plen = 0;
     if (ok && fread(&plen, 4, 1, f) == 1 && plen > 0) { s->hdrPath.resize(plen); ok = fread(&s->hdrPath[0], 1, plen, f) == (size_t)plen; }
+    if (ok && ver >= 2) {
+        int32_t ntex = 0;
+        ok = fread(&ntex, 4, 1, f) == 1 && rd(s->textures, (size_t)ntex);
+        for (int i = 0; ok && i < ntex; ++i) {
+            std::string tp;
+            ok = fread(&plen, 4, 1, f) == 1;
+            if (ok && plen > 0) { tp.resize(plen); ok = fread(&tp[0], 1, plen, f) == (size_t)plen; }
+            s->texturePaths.push_back(tp);
+        }
+    }
     fclose(f);
     return ok;
 }
@@ -112,16 +125,26 @@ bool readScene(const char *path, SceneFile *s) {
 template <typename T> std::shared_ptr<Texture<T>> C(const T &v) { return std::make_shared<ConstantTexture<T>>(v); }
 Spectrum S3(const float *p) { Spectrum s; s[0] = p[0]; s[1] = p[1]; s[2] = p[2]; return s; }
 
-std::shared_ptr<Material> makeMaterial(const gnxr_material &m) {
+// the reference's own ImageTexture / UVMapping2D / MIPMap, loading the file through its stb_image path
+std::shared_ptr<Texture<Spectrum>> imageOrConstant(const SceneFile &sf, int texture, const float *constant) {
+    if (texture <= 0) return C(S3(constant));
+    const gnxr_texture &t = sf.textures[texture - 1];
+    std::unique_ptr<TextureMapping2D> map = std::make_unique<UVMapping2D>(t.su, t.sv, t.du, t.dv);
+    ImageWrap wrap = t.wrap == GNXR_WRAP_REPEAT ? ImageWrap::Repeat : (t.wrap == GNXR_WRAP_BLACK ? ImageWrap::Black : ImageWrap::Clamp);
+    return std::make_shared<ImageTexture<RGBSpectrum, Spectrum>>(std::move(map), sf.texturePaths[texture - 1], t.trilinear != 0, t.max_aniso, wrap, t.scale, t.gamma != 0);
+}
+
+std::shared_ptr<Material> makeMaterial(const SceneFile &sf, const gnxr_material &m) {
     std::shared_ptr<Texture<Float>> bump = m.has_bump ? C<Float>(0.0f) : nullptr;
     switch (m.type) {
-    case GNXR_MAT_MATTE: return std::make_shared<MatteMaterial>(C(S3(m.kd)), C<Float>(m.sigma), bump);
+    case GNXR_MAT_MATTE: return std::make_shared<MatteMaterial>(imageOrConstant(sf, m.kd_texture, m.kd), C<Float>(m.sigma), bump);
     case GNXR_MAT_MIRROR: return std::make_shared<MirrorMaterial>(C(S3(m.kr)), bump);
     case GNXR_MAT_GLASS:
         return std::make_shared<GlassMaterial>(C(S3(m.kr)), C(S3(m.kt)), C<Float>(m.urough), C<Float>(m.vrough), C<Float>(m.eta[0]), bump, m.remap_roughness != 0);
     case GNXR_MAT_METAL:
         return std::make_shared<MetalMaterial>(C(S3(m.eta)), C(S3(m.k)), C<Float>(m.urough), C<Float>(m.urough), C<Float>(m.vrough), bump, m.remap_roughness != 0);
-    case GNXR_MAT_PLASTIC: return std::make_shared<PlasticMaterial>(C(S3(m.kd)), C(S3(m.ks)), C<Float>(m.urough), bump, m.remap_roughness != 0);
+    case GNXR_MAT_PLASTIC:
+        return std::make_shared<PlasticMaterial>(imageOrConstant(sf, m.kd_texture, m.kd), imageOrConstant(sf, m.ks_texture, m.ks), C<Float>(m.urough), bump, m.remap_roughness != 0);
     case GNXR_MAT_DISNEY:
         return std::make_shared<DisneyMaterial>(C(S3(m.kd)), C<Float>(m.disney_metallic), C<Float>(m.eta[0]), C<Float>(m.disney_roughness),
                                                 C<Float>(m.disney_spec_tint), C<Float>(m.disney_anisotropic), C<Float>(m.disney_sheen),
@@ -147,7 +170,7 @@ struct RefScene {
     std::unique_ptr<Scene> scene;
 
     void build() {
-        for (auto &m : sf.mats) materials.push_back(makeMaterial(m));
+        for (auto &m : sf.mats) materials.push_back(makeMaterial(sf, m));
         for (auto &m : sf.media) {
             if (m.type == GNXR_MEDIUM_HOMOGENEOUS) media.push_back(std::make_shared<HomogeneousMedium>(S3(m.sigma_a), S3(m.sigma_s), m.g));
             else {
@@ -525,9 +548,49 @@ Spectrum refVolPathLi(const RayDifferential &r, const Scene &scene, Sampler &sam
     return L;
 }
 
+// Ray differentials of the specular children, SamplerIntegrator::SpecularReflect / SpecularTransmit (core/Integrator.cpp:335-354,
+// 376-436), on the reference's classes.  They reach the radiance only through image-texture filtering.
+void refReflectDifferentials(const RayDifferential &ray, const SurfaceInteraction &isect, const Vector3f &wo, const Vector3f &wi, RayDifferential *rd) {
+    if (!ray.hasDifferentials) return;
+    const Normal3f &ns = isect.shading.n;
+    rd->hasDifferentials = true;
+    rd->rxOrigin = isect.p + isect.dpdx;
+    rd->ryOrigin = isect.p + isect.dpdy;
+    Normal3f dndx = isect.shading.dndu * isect.dudx + isect.shading.dndv * isect.dvdx;
+    Normal3f dndy = isect.shading.dndu * isect.dudy + isect.shading.dndv * isect.dvdy;
+    Vector3f dwodx = -ray.rxDirection - wo, dwody = -ray.ryDirection - wo;
+    Float dDNdx = Dot(dwodx, ns) + Dot(wo, dndx);
+    Float dDNdy = Dot(dwody, ns) + Dot(wo, dndy);
+    rd->rxDirection = wi - dwodx + 2.f * Vector3f(Dot(wo, ns) * dndx + dDNdx * ns);
+    rd->ryDirection = wi - dwody + 2.f * Vector3f(Dot(wo, ns) * dndy + dDNdy * ns);
+}
+void refTransmitDifferentials(const RayDifferential &ray, const SurfaceInteraction &isect, const Vector3f &wo, const Vector3f &wi, RayDifferential *rd) {
+    if (!ray.hasDifferentials) return;
+    Normal3f ns = isect.shading.n;
+    rd->hasDifferentials = true;
+    rd->rxOrigin = isect.p + isect.dpdx;
+    rd->ryOrigin = isect.p + isect.dpdy;
+    Normal3f dndx = isect.shading.dndu * isect.dudx + isect.shading.dndv * isect.dvdx;
+    Normal3f dndy = isect.shading.dndu * isect.dudy + isect.shading.dndv * isect.dvdy;
+    Float eta = 1 / isect.bsdf->eta;
+    if (Dot(wo, ns) < 0) {
+        eta = 1 / eta;
+        ns = -ns;
+        dndx = -dndx;
+        dndy = -dndy;
+    }
+    Vector3f dwodx = -ray.rxDirection - wo, dwody = -ray.ryDirection - wo;
+    Float dDNdx = Dot(dwodx, ns) + Dot(wo, dndx);
+    Float dDNdy = Dot(dwody, ns) + Dot(wo, dndy);
+    Float mu = eta * Dot(wo, ns) - AbsDot(wi, ns);
+    Float dmudx = (eta - (eta * eta * Dot(wo, ns)) / AbsDot(wi, ns)) * dDNdx;
+    Float dmudy = (eta - (eta * eta * Dot(wo, ns)) / AbsDot(wi, ns)) * dDNdy;
+    rd->rxDirection = wi - eta * dwodx + Vector3f(mu * dndx + dmudx * ns);
+    rd->ryDirection = wi - eta * dwody + Vector3f(mu * dndy + dmudy * ns);
+}
+
 // WhittedIntegrator::Li + SamplerIntegrator::SpecularReflect / SpecularTransmit (integrators/WhittedIntegrator.cpp:14-68,
-// core/Integrator.cpp:321-442) restated on the reference's classes; the ray-differential bookkeeping is left out (it does
-// not reach the radiance with constant textures).
+// core/Integrator.cpp:321-442) restated on the reference's classes.
 Spectrum refWhittedLi(const RayDifferential &ray, const Scene &scene, Sampler &sampler, MemoryArena &arena, int maxDepth, int depth) {
     Spectrum L(0.);
     SurfaceInteraction isect;
@@ -560,6 +623,7 @@ Spectrum refWhittedLi(const RayDifferential &ray, const Scene &scene, Sampler &s
             const Normal3f &ns = isect.shading.n;
             if (pdf > 0.f && !f.IsBlack() && AbsDot(wi, ns) != 0.f) {
                 RayDifferential rd = isect.SpawnRay(wi);
+                refReflectDifferentials(ray, isect, wo, wi, &rd);
                 L += f * refWhittedLi(rd, scene, sampler, arena, maxDepth, depth + 1) * AbsDot(wi, ns) / pdf;
             } else L += Spectrum(0.f);
         }
@@ -571,6 +635,7 @@ Spectrum refWhittedLi(const RayDifferential &ray, const Scene &scene, Sampler &s
             Normal3f ns = isect.shading.n;
             if (pdf > 0.f && !f.IsBlack() && AbsDot(wi, ns) != 0.f) {
                 RayDifferential rd = isect.SpawnRay(wi);
+                refTransmitDifferentials(ray, isect, wo, wi, &rd);
                 Lt = f * refWhittedLi(rd, scene, sampler, arena, maxDepth, depth + 1) * AbsDot(wi, ns) / pdf;
             }
             L += Lt;
@@ -627,9 +692,11 @@ Spectrum refDirectLi(const RayDifferential &ray, const Scene &scene, Sampler &sa
             Float pdf;
             Spectrum f = isect.bsdf->Sample_f(wo, &wi, sampler.Get2D(), &pdf, BxDFType(BSDF_REFLECTION | BSDF_SPECULAR));
             const Normal3f &ns = isect.shading.n;
-            if (pdf > 0.f && !f.IsBlack() && AbsDot(wi, ns) != 0.f)
-                L += f * refDirectLi(isect.SpawnRay(wi), scene, sampler, arena, strategy, nLightSamples, maxDepth, depth + 1) * AbsDot(wi, ns) / pdf;
-            else L += Spectrum(0.f);
+            if (pdf > 0.f && !f.IsBlack() && AbsDot(wi, ns) != 0.f) {
+                RayDifferential rd = isect.SpawnRay(wi);
+                refReflectDifferentials(ray, isect, wo, wi, &rd);
+                L += f * refDirectLi(rd, scene, sampler, arena, strategy, nLightSamples, maxDepth, depth + 1) * AbsDot(wi, ns) / pdf;
+            } else L += Spectrum(0.f);
         }
         {
             Vector3f wi;
@@ -637,8 +704,11 @@ Spectrum refDirectLi(const RayDifferential &ray, const Scene &scene, Sampler &sa
             Spectrum f = isect.bsdf->Sample_f(wo, &wi, sampler.Get2D(), &pdf, BxDFType(BSDF_TRANSMISSION | BSDF_SPECULAR));
             Spectrum Lt = Spectrum(0.f);
             Normal3f ns = isect.shading.n;
-            if (pdf > 0.f && !f.IsBlack() && AbsDot(wi, ns) != 0.f)
-                Lt = f * refDirectLi(isect.SpawnRay(wi), scene, sampler, arena, strategy, nLightSamples, maxDepth, depth + 1) * AbsDot(wi, ns) / pdf;
+            if (pdf > 0.f && !f.IsBlack() && AbsDot(wi, ns) != 0.f) {
+                RayDifferential rd = isect.SpawnRay(wi);
+                refTransmitDifferentials(ray, isect, wo, wi, &rd);
+                Lt = f * refDirectLi(rd, scene, sampler, arena, strategy, nLightSamples, maxDepth, depth + 1) * AbsDot(wi, ns) / pdf;
+            }
             L += Lt;
         }
     }
@@ -793,6 +863,7 @@ int main(int argc, char **argv) {
     }
     if (!strcmp(cmd, "bsdf")) {  // args: flags ; in: n * (gnxr_ray, wi[3], u[2]) packed as arrays: rays | wi | u
         int flags = atoi(argv[5]);
+        const float diffEps = argc > 6 ? (float)atof(argv[6]) : 0.f;
         size_t n = in.size() / (sizeof(gnxr_ray) + 12 + 8);
         const gnxr_ray *rays = (const gnxr_ray *)in.data();
         const float *wiW = (const float *)(in.data() + n * sizeof(gnxr_ray));
@@ -800,13 +871,19 @@ int main(int argc, char **argv) {
         std::vector<float> out(16 * n, 0.f);
         for (size_t i = 0; i < n; ++i) {
             float *o = &out[16 * i];
-            Ray r(Point3f(rays[i].o[0], rays[i].o[1], rays[i].o[2]), Vector3f(rays[i].d[0], rays[i].d[1], rays[i].d[2]), rays[i].tmax);
+            RayDifferential r(Point3f(rays[i].o[0], rays[i].o[1], rays[i].o[2]), Vector3f(rays[i].d[0], rays[i].d[1], rays[i].d[2]), rays[i].tmax);
+            if (diffEps > 0) {   // synthetic offset rays (texture filtering probe): same origin, directions nudged along x / y
+                r.hasDifferentials = true;
+                r.rxOrigin = r.ryOrigin = r.o;
+                r.rxDirection = r.d + Vector3f(diffEps, 0, 0);
+                r.ryDirection = r.d + Vector3f(0, diffEps, 0);
+            }
             SurfaceInteraction isect;
             if (!scene.Intersect(r, &isect)) continue;
             MemoryArena arena;
             isect.ComputeScatteringFunctions(r, arena, true);
             if (!isect.bsdf) continue;
-            o[13] = 1;
+            o[13] = 1; o[14] = isect.dudx; o[15] = isect.dvdy;
             Vector3f wi(wiW[3 * i], wiW[3 * i + 1], wiW[3 * i + 2]);
             Spectrum f = isect.bsdf->f(isect.wo, wi, BxDFType(flags));
             o[0] = f[0]; o[1] = f[1]; o[2] = f[2];

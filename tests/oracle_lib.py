@@ -174,7 +174,7 @@ def write_scene_file(builder, path):
         return C.string_at(ptr, n * C.sizeof(ct))
 
     with open(path, "wb") as f:
-        f.write(b"GNXS" + struct.pack("<i", 1))
+        f.write(b"GNXS" + struct.pack("<i", 2))
         f.write(struct.pack("<8i", nv, nt, d.n_materials, d.n_lights, d.n_media, d.env_width, d.env_height, d.camera_medium))
         f.write(bytes(d.camera))
         f.write(arr(d.vertices, 3 * nv, C.c_float))
@@ -196,6 +196,14 @@ def write_scene_file(builder, path):
         f.write(arr(d.env_rgb, 3 * d.env_width * d.env_height, C.c_float))
         hp = (builder.hdr_path or "").encode()
         f.write(struct.pack("<i", len(hp)) + hp)
+        # image textures: parameters + the FILE the reference's ImageTexture loads (array textures cannot be handed over)
+        f.write(struct.pack("<i", d.n_textures))
+        f.write(arr(d.textures, d.n_textures, _abi.Texture))
+        paths = getattr(builder, "texture_paths", [])
+        for i in range(d.n_textures):
+            tp = os.path.abspath(paths[i]).encode() if paths[i] else b""
+            assert tp, "the reference loads image textures from files: use add_image_texture(path)"
+            f.write(struct.pack("<i", len(tp)) + tp)
 
 
 def run_ref(scene_path, cmd, in_bytes, args=(), stderr=None):

@@ -243,3 +243,32 @@ def cornell_in_fog():
     b.add_mesh(v, i, -1, medium_inside=m, medium_outside=-1)
     b.set_camera_medium(m)
     return b
+
+
+def textured_cornell(tex_path, glass_sheet=True):
+    """image-textured materials.  Back wall = the reference's getSmileFacePlasticMaterial (ui/MaterialList.cpp:31-46:
+    Kd = Ks = one ImageTexture, EWA, Repeat) on `tex_path`; floor = Matte whose Kd is the same image tiled 3 x 3 through the
+    trilinear filter with Clamp wrap, gamma and scale; left wall = mirror and a free-standing smooth-glass sheet so that Whitted /
+    DirectLighting carry ray differentials through specular reflection and transmission onto the textures.  Triangles have no
+    per-vertex uv in the reference, so every triangle shows the lower-right half of the image (Triangle::GetUVs defaults)."""
+    b = gx.SceneBuilder()
+    white = b.MatteMaterial(WHITE, 60.0)
+    blue = b.MatteMaterial(BLUE, 60.0)
+    mirror = b.MirrorMaterial((0.9, 0.9, 0.9))
+    smile = b.getSmileFacePlasticMaterial(tex_path)
+    floor_tex = b.add_image_texture(tex_path, su=3.0, sv=3.0, du=0.25, dv=0.1, trilinear=True, wrap="clamp", scale=0.8, gamma=True)
+    floor = b.MatteMaterial(WHITE, 0.0)
+    b.set_material_texture(floor, "kd", floor_tex)
+    first = b.AddCornell(mirror, blue, white)
+    d = b.desc()
+    mats = np.ctypeslib.as_array(d.tri_material, shape=(d.n_triangles,))
+    mats[first + 0] = floor
+    mats[first + 1] = floor
+    mats[first + 4] = smile
+    mats[first + 5] = smile
+    if glass_sheet:
+        sglass = b.add_material(type=gx._abi.MAT_GLASS, kr=(0.98,) * 3, kt=(0.98,) * 3, eta=(1.5, 0, 0), urough=0.0, vrough=0.0)
+        v = np.array([[0.3, -2.5, 0.4], [1.9, -2.5, -0.6], [1.9, 0.4, -0.6], [0.3, 0.4, 0.4]], np.float32)
+        b.add_mesh(v, np.array([[0, 1, 2], [0, 2, 3]], np.int32), sglass)
+    b.AddAreaLight(white)
+    return b

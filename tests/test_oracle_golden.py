@@ -181,6 +181,25 @@ def test_direct_lighting_images(name, gx):
     assert (st["rays_closest"], st["rays_any"]) == tuple(int(v) for v in g[name + "_rays"])
     assert biteq(img, g[name])
 
+def _textured_integrator(gx, name, depth):
+    return {"path": lambda: gx.PathIntegrator(depth, 1.0, "spatial"), "whitted": lambda: gx.WhittedIntegrator(depth),
+            "direct_all": lambda: gx.DirectLightingIntegrator("all", depth), "volpath": lambda: gx.VolPathIntegrator(depth, 1.0, "spatial")}[name]()
+
+
+@pytest.mark.parametrize("name", ["path", "whitted", "direct_all", "volpath"])
+def test_textured_images(name, gx):
+    """ImageTexture / UVMapping2D / MIPMap (Lanczos resample of the 96x80 image, pyramid, EWA and trilinear filters,
+    Repeat / Clamp wrap, gamma, scale) behind Plastic (the reference's getSmileFacePlasticMaterial) and Matte, with the camera ray
+    differentials, ComputeDifferentials and -- Whitted / DirectLighting -- their propagation through a mirror and a glass sheet.
+    The reference's own ImageTexture, MIPMap, camera and Interaction code produced these images and ray counts; its PathIntegrator
+    slices the RayDifferential (`Ray ray(r)`), so Path looks every texture up unfiltered, which the fixture also pins."""
+    g = golden("render_textured.npz")
+    W, H, spp, depth = (int(v) for v in g["cfg"])
+    b = scenes.textured_cornell(os.path.join(GOLDEN, "tex_smile_96x80.hdr"))
+    img, st = ol.OracleScene(b).render(_textured_integrator(gx, name, depth), W, H, spp)
+    assert (st["rays_closest"], st["rays_any"]) == tuple(int(v) for v in g[name + "_rays"])
+    assert biteq(img, g[name])
+
 
 def test_cfg2_reproduces_the_recorded_reference_run(gx):
     """the complete reference traced 16 058 662 closest-hit and 12 329 468 any-hit rays
