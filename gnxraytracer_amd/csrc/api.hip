@@ -113,6 +113,8 @@ struct gnxr_scene {
     DevBuf<DTri> tris;
     DevBuf<DSphere> spheres;
     DevBuf<DMaterial> materials, materials_single;
+    DevBuf<DTexture> textures;
+    DevBuf<float> tex_texels, ewa_lut;
     DevBuf<DLight> lights;
     DevBuf<int32_t> infinite;
     DevBuf<uint16_t> perms;
@@ -128,7 +130,7 @@ struct gnxr_scene {
     // per-render state (grown on demand)
     DevBuf<float4> ray_o, ray_d, beta, L, sh_o, sh_d, sh_X, mis_o, mis_d, mis_Y, nbeta, accum, out;
     DevBuf<uint2> meta;
-    DevBuf<int> hit, queue_a, queue_b, queue_nee, queue_c0, queue_c1, queue_c2;
+    DevBuf<int> hit, queue_a, queue_b, queue_nee, queue_c0, queue_c1, queue_c2, queue_c3;
     DevBuf<unsigned char> pflags, pclass;
     DevBuf<unsigned int> tile_counts;
     DevBuf<int> trace_spill;   // global part of k_trace's per-lane traversal stacks
@@ -136,6 +138,7 @@ struct gnxr_scene {
     DevBuf<int4> vol_vs;
     DevBuf<unsigned char> vol_state;
     DevBuf<float4> wh_o, wh_d, wh_L, wh_w;   // Whitted recursion frames (whitted_kernel.hip.h)
+    DevBuf<float4> wh_rxo, wh_rxd, wh_ryo, wh_ryd;   // their ray differentials (scenes with image textures)
     DevBuf<float> wh_pdf;
     DevBuf<int> wh_rec;
     DevBuf<Counters> counters;
@@ -154,7 +157,7 @@ struct gnxr_scene {
         d.tris = tris.p;
         d.spheres = spheres.p;
         d.n_spheres = cs.n_spheres;
-        d.materials = materials.p;
+        d.materials = materials.p + 1;   // [0] carries the texture tables
         d.lt.lights = lights.p;
         d.lt.n_lights = (int)cs.desc_lights.size();
         d.lt.infinite = infinite.p;
@@ -242,10 +245,22 @@ int gnxr_scene_create(const gnxr_scene_desc *desc, gnxr_scene **out) {
     s->wide_ok = cs.tris.size() < (1u << 24) && cs.stack4_need + 1 <= 128 && getenv("GNXR_BINARY_BVH") == nullptr;
     for (const DNode &n : cs.nodes) if ((n.meta & 0xffffu) > 127) s->wide_ok = false;
 #define UP(field) if ((rc = s->field.upload(cs.field)) != GNXR_OK) { delete s; return rc; }
-    UP(nodes) UP(nodes4) UP(tris) UP(materials) UP(lights) UP(perms) UP(primes) UP(prime_sums) UP(prime_magic)
-    UP(dmedia) UP(grid_density) UP(tri_media) UP(spheres) UP(materials_single)
+    UP(nodes) UP(nodes4) UP(tris) UP(lights) UP(perms) UP(primes) UP(prime_sums) UP(prime_magic)
+    UP(dmedia) UP(grid_density) UP(tri_media) UP(spheres) UP(textures) UP(tex_texels) UP(ewa_lut)
     UP(env_texels) UP(env_cond_func) UP(env_cond_cdf) UP(env_cond_int) UP(env_marg_func) UP(env_marg_cdf)
 #undef UP
+    {   // materials, preceded by one record that carries the texture tables (tex_tables(), device_texture.h)
+        DTexTables tt;
+        tt.textures = s->textures.p; tt.texels = reinterpret_cast<const float4 *>(s->tex_texels.p); tt.ewa_lut = s->ewa_lut.p;
+        for (int k = 0; k < 2; ++k) {
+            const std::vector<DMaterial> &src = k == 0 ? cs.materials : cs.materials_single;
+            std::vector<DMaterial> up(src.size() + 1);
+            memset(&up[0], 0, sizeof(DMaterial));
+            memcpy(&up[0], &tt, sizeof(tt));
+            std::copy(src.begin(), src.end(), up.begin() + 1);
+            if ((rc = (k == 0 ? s->materials : s->materials_single).upload(up)) != GNXR_OK) { delete s; return rc; }
+        }
+    }
     if ((rc = s->infinite.upload(cs.infinite_lights)) != GNXR_OK) { delete s; return rc; }
     if ((rc = s->counters.alloc(1)) != GNXR_OK) { delete s; return rc; }
     if (hipHostMalloc((void **)&s->h_counters, sizeof(Counters)) != hipSuccess) { set_error("hipHostMalloc failed"); delete s; return GNXR_ERR_OOM; }
@@ -309,6 +324,8 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
         set_error("Whitted / DirectLighting on the device: at most 64 light samples per vertex (every light is sampled at every vertex), depth 32, no media");
         return GNXR_ERR_UNSUPPORTED;
     }
+    bool textured_scene = false;
+    for (const DMaterial &m : s->cs.materials) if (m.shade_class == 3) textured_scene = true;
     std::lock_guard<std::mutex> lock(s->render_mutex);
     auto t_start = std::chrono::steady_clock::now();
     hipStream_t stream = (hipStream_t)hip_stream;
@@ -335,7 +352,7 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     size_t cap = (size_t)r.npix * k;
     if (cap >= (1ull << 31)) { set_error("pass too large"); return GNXR_ERR_INVALID; }
 #define AL(f) if ((rc = s->f.alloc(cap)) != GNXR_OK) return rc;
-    AL(ray_o) AL(ray_d) AL(beta) AL(L) AL(sh_o) AL(sh_d) AL(sh_X) AL(mis_o) AL(mis_d) AL(mis_Y) AL(nbeta) AL(meta) AL(hit) AL(queue_a) AL(queue_b) AL(queue_nee) AL(queue_c0) AL(queue_c1) AL(queue_c2) AL(pflags) AL(pclass)
+    AL(ray_o) AL(ray_d) AL(beta) AL(L) AL(sh_o) AL(sh_d) AL(sh_X) AL(mis_o) AL(mis_d) AL(mis_Y) AL(nbeta) AL(meta) AL(hit) AL(queue_a) AL(queue_b) AL(queue_nee) AL(queue_c0) AL(queue_c1) AL(queue_c2) AL(queue_c3) AL(pflags) AL(pclass)
 #undef AL
     if (whitted) {
         const size_t nl = (size_t)std::max(1, n_records), md = (size_t)std::max(1, p.max_depth);
@@ -343,6 +360,8 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
         if ((rc = s->sh_o.alloc(cap * nl)) || (rc = s->sh_d.alloc(cap * nl)) || (rc = s->sh_X.alloc(cap * nl)) || (rc = s->wh_rec.alloc(cap * nl)) ||
             (rc = s->wh_o.alloc(cap * md)) || (rc = s->wh_d.alloc(cap * md)) || (rc = s->wh_L.alloc(cap * md)) || (rc = s->wh_w.alloc(cap * md)) ||
             (rc = s->wh_pdf.alloc(cap * md)) || (rc = s->vol_vs.alloc(cap)))
+            return rc;
+        if (textured_scene && ((rc = s->wh_rxo.alloc(cap * (md + 1))) || (rc = s->wh_rxd.alloc(cap * (md + 1))) || (rc = s->wh_ryo.alloc(cap * (md + 1))) || (rc = s->wh_ryd.alloc(cap * (md + 1)))))
             return rc;
     }
     if (volpath) {
@@ -366,11 +385,12 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     DMediaTables mt = s->media_tables();
     WhittedArrays wa;
     wa.ws = s->vol_vs.p; wa.fr_o = s->wh_o.p; wa.fr_d = s->wh_d.p; wa.fr_L = s->wh_L.p; wa.fr_w = s->wh_w.p; wa.fr_pdf = s->wh_pdf.p;
+    wa.fr_rxo = s->wh_rxo.p; wa.fr_rxd = s->wh_rxd.p; wa.fr_ryo = s->wh_ryo.p; wa.fr_ryd = s->wh_ryd.p;
     wa.cap = (int)cap; wa.n_lights = nL; wa.n_records = n_records;
     // DirectLightingIntegrator::Preprocess requests maxDepth x lights x 2 2D arrays (DirectLightingIntegrator.cpp:19-25)
     wa.start_dim = wmode == WM_DIRECT_ALL ? 5 + 2 * (p.max_depth * nL * 2) : 5;
     if (whitted) {
-        sc.materials = s->materials_single.p;
+        sc.materials = s->materials_single.p + 1;
         pa.sh_o = s->sh_o.p; pa.sh_d = s->sh_d.p; pa.sh_X = s->sh_X.p; pa.mis_o = s->mis_o.p; pa.mis_d = s->mis_d.p; pa.mis_Y = s->mis_Y.p;
     }
 
@@ -385,6 +405,7 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     const bool timing = (g_profiling & 1) != 0, counting = (g_profiling & 2) != 0, spheres = s->cs.n_spheres > 0;
     int class_mask = 0;
     for (const DMaterial &m : s->cs.materials) class_mask |= 1 << m.shade_class;
+    const bool textured = (class_mask & 8) != 0;
     bool area_only = true;
     for (const gnxr_light &l : s->cs.desc_lights) if (l.type != GNXR_LIGHT_AREA_TRI) area_only = false;
     KernelTimer timer;
@@ -431,14 +452,16 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
             ++launches;
         };
         // stream compaction (compact_kernel.hip.h): count -> scan -> scatter, no global atomics
-        auto compact = [&](int mode, const int *qin, int nin, const unsigned char *keys, int nout, int nscatter, unsigned int *totals, int *o0, int *o1, int *o2) {
+        auto compact = [&](int mode, const int *qin, int nin, const unsigned char *keys, int nout, int nscatter, unsigned int *totals, int *o0, int *o1, int *o2, int *o3 = nullptr) {
             int tiles = (nin + kCompactBlock - 1) / kCompactBlock;
             int g = std::min(tiles, g_num_cus * 8);
             if (mode == COMPACT_FLAGS) hipLaunchKernelGGL((k_compact_count<COMPACT_FLAGS, 4>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles);
+            else if (nout == 4) hipLaunchKernelGGL((k_compact_count<COMPACT_CLASS, 4>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles);
             else hipLaunchKernelGGL((k_compact_count<COMPACT_CLASS, 3>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles);
             hipLaunchKernelGGL(k_compact_scan, dim3(nout), dim3(1024), 0, stream, s->tile_counts.p, tiles, totals);
             if (mode == COMPACT_FLAGS && nscatter == 3) hipLaunchKernelGGL((k_compact_scatter<COMPACT_FLAGS, 3>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, (const unsigned int *)s->tile_counts.p, tiles, o0, o1, o2);
             else if (mode == COMPACT_FLAGS) hipLaunchKernelGGL((k_compact_scatter<COMPACT_FLAGS, 2>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, (const unsigned int *)s->tile_counts.p, tiles, o0, o1, o2);
+            else if (nscatter == 4) hipLaunchKernelGGL((k_compact_scatter<COMPACT_CLASS, 4>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, (const unsigned int *)s->tile_counts.p, tiles, o0, o1, o2, o3);
             else hipLaunchKernelGGL((k_compact_scatter<COMPACT_CLASS, 3>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, (const unsigned int *)s->tile_counts.p, tiles, o0, o1, o2);
             launches += 3;
         };
@@ -446,6 +469,7 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
             // depth-first recursion per path (whitted_kernel.hip.h): the path's ray + the previous vertex's shadow rays per round
             hipLaunchKernelGGL(k_whitted_init, dim3(grid_for(n_paths)), dim3(kBlock), 0, stream, pa, wa, n_paths);
             ++launches;
+            if (textured) { hipLaunchKernelGGL(k_whitted_init_diff, dim3(grid_for(n_paths)), dim3(kBlock), 0, stream, sc, r, pa, wa, n_paths); ++launches; }
             int n_cl = n, n_shp = 0;
             const int *q_cl = nullptr;
             unsigned long long *d_shadow = &dctr->whitted_shadow;
@@ -456,7 +480,11 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
                 }
                 launch_trace(TraceWork{q_cl, n_cl, s->wh_rec.p, n_shp * n_records}, 0, 0);
                 if (timing) timer.begin(2, stream);
-#define GX_WH2(MODEV, LTV, SPHV) hipLaunchKernelGGL((k_whitted_step<MODEV, LTV, SPHV>), dim3(grid_for(n)), dim3(kBlock), 0, stream, sc, r, pa, wa, q_in, n, d_shadow)
+#define GX_WH2(MODEV, LTV, SPHV)                                                                                                                     \
+    do {                                                                                                                                             \
+        if (textured) hipLaunchKernelGGL((k_whitted_step<MODEV, LTV, SPHV, true>), dim3(grid_for(n)), dim3(kBlock), 0, stream, sc, r, pa, wa, q_in, n, d_shadow); \
+        else hipLaunchKernelGGL((k_whitted_step<MODEV, LTV, SPHV>), dim3(grid_for(n)), dim3(kBlock), 0, stream, sc, r, pa, wa, q_in, n, d_shadow);   \
+    } while (0)
 #define GX_WH(LTV, SPHV) do { if (wmode == WM_WHITTED) GX_WH2(WM_WHITTED, LTV, SPHV); else if (wmode == WM_DIRECT_ONE) GX_WH2(WM_DIRECT_ONE, LTV, SPHV); else GX_WH2(WM_DIRECT_ALL, LTV, SPHV); } while (0)
                 if (area_only) { if (spheres) GX_WH(LT_AREA, true); else GX_WH(LT_AREA, false); }
                 else { if (spheres) GX_WH(LT_ALL, true); else GX_WH(LT_ALL, false); }
@@ -500,8 +528,13 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
                     int *qc[3] = {s->queue_c0.p, s->queue_c1.p, s->queue_c2.p};
 #define GX_VS1(LMV, LTV, ST) hipLaunchKernelGGL((k_vol_step<LMV, LTV, ST>), dim3(grid_for(n)), dim3(kBlock), 0, stream, sc, mt, r, pa, va, (const int *)qc[ST], (const unsigned int *)&dctr->q_class[ST])
 #define GX_VS(LMV, LTV) do { GX_VS1(LMV, LTV, VS_MAIN); GX_VS1(LMV, LTV, VS_SHADOW); GX_VS1(LMV, LTV, VS_MIS); } while (0)
-                    if (area_only) { if (class_mask <= 1) GX_VS(LM_DIFFUSE, LT_AREA); else if (class_mask <= 3) GX_VS(LM_GLOSSY, LT_AREA); else GX_VS(LM_ALL, LT_AREA); }
+#define GX_VST1(LTV, ST) hipLaunchKernelGGL((k_vol_step<LM_ALL, LTV, ST, true>), dim3(grid_for(n)), dim3(kBlock), 0, stream, sc, mt, r, pa, va, (const int *)qc[ST], (const unsigned int *)&dctr->q_class[ST])
+#define GX_VST(LTV) do { GX_VST1(LTV, VS_MAIN); GX_VST1(LTV, VS_SHADOW); GX_VST1(LTV, VS_MIS); } while (0)
+                    if (textured) { if (area_only) GX_VST(LT_AREA); else GX_VST(LT_ALL); }
+                    else if (area_only) { if (class_mask <= 1) GX_VS(LM_DIFFUSE, LT_AREA); else if (class_mask <= 3) GX_VS(LM_GLOSSY, LT_AREA); else GX_VS(LM_ALL, LT_AREA); }
                     else { if (class_mask <= 1) GX_VS(LM_DIFFUSE, LT_ALL); else if (class_mask <= 3) GX_VS(LM_GLOSSY, LT_ALL); else GX_VS(LM_ALL, LT_ALL); }
+#undef GX_VST
+#undef GX_VST1
 #undef GX_VS
 #undef GX_VS1
                     launches += 2;
@@ -522,26 +555,34 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
         while (n > 0) {
             if (timing) timer.begin(2, stream);
             // bin the paths by the shade specialisation of the material they hit (pclass written by k_trace)
-            compact(COMPACT_CLASS, q_in, n, s->pclass.p, 3, 3, &dctr->q_class[0], s->queue_c0.p, s->queue_c1.p, s->queue_c2.p);
+            const int n_classes = (class_mask & 8) ? 4 : 3;   // image-textured materials have a shade queue of their own
+            compact(COMPACT_CLASS, q_in, n, s->pclass.p, n_classes, n_classes, &dctr->q_class[0], s->queue_c0.p, s->queue_c1.p, s->queue_c2.p, s->queue_c3.p);
             {
-                int *qc[3] = {s->queue_c0.p, s->queue_c1.p, s->queue_c2.p};
+                int *qc[4] = {s->queue_c0.p, s->queue_c1.p, s->queue_c2.p, s->queue_c3.p};
                 dim3 g(grid_for(n)), b(kBlock);
 #define GX_SHADE(LMV, LTV, C)                                                                                                                        \
     do {                                                                                                                                             \
         if (spheres) hipLaunchKernelGGL((k_shade<LMV, LTV, true>), g, b, 0, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C]); \
         else hipLaunchKernelGGL((k_shade<LMV, LTV, false>), g, b, 0, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C]);       \
     } while (0)
+#define GX_SHADE_TEX(LTV)                                                                                                                            \
+    do {                                                                                                                                             \
+        if (spheres) hipLaunchKernelGGL((k_shade<LM_GLOSSY, LTV, true, true>), g, b, 0, stream, sc, r, pa, (const int *)qc[3], (const unsigned int *)&dctr->q_class[3]); \
+        else hipLaunchKernelGGL((k_shade<LM_GLOSSY, LTV, false, true>), g, b, 0, stream, sc, r, pa, (const int *)qc[3], (const unsigned int *)&dctr->q_class[3]);       \
+    } while (0)
                 if (area_only) {
                     GX_SHADE(LM_DIFFUSE, LT_AREA, 0);
                     if (class_mask & 2) GX_SHADE(LM_GLOSSY, LT_AREA, 1);
                     if (class_mask & 4) GX_SHADE(LM_ALL, LT_AREA, 2);
+                    if (class_mask & 8) GX_SHADE_TEX(LT_AREA);
                 } else {
                     GX_SHADE(LM_DIFFUSE, LT_ALL, 0);
                     if (class_mask & 2) GX_SHADE(LM_GLOSSY, LT_ALL, 1);
                     if (class_mask & 4) GX_SHADE(LM_ALL, LT_ALL, 2);
+                    if (class_mask & 8) GX_SHADE_TEX(LT_ALL);
                 }
 #undef GX_SHADE
-                launches += 1 + ((class_mask & 2) ? 1 : 0) + ((class_mask & 4) ? 1 : 0);
+                launches += 1 + ((class_mask & 2) ? 1 : 0) + ((class_mask & 4) ? 1 : 0) + ((class_mask & 8) ? 1 : 0);
             }
             // next-vertex queue + NEE queue from the per-path flags; totals also count shadow and MIS rays
             compact(COMPACT_FLAGS, q_in, n, s->pflags.p, 4, 2, &dctr->q_next, q_cur, s->queue_nee.p, nullptr);

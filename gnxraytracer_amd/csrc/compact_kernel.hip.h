@@ -78,10 +78,10 @@ __global__ void __launch_bounds__(1024) k_compact_scan(unsigned int *tile_counts
 // pass 3: write the survivors of the first NSCATTER predicates at tile_offset + rank-within-tile
 template <int MODE, int NSCATTER>
 __global__ void __launch_bounds__(kCompactBlock) k_compact_scatter(const int *__restrict__ q_in, int n, const unsigned char *__restrict__ keys,
-                                                                   const unsigned int *__restrict__ tile_offsets, int nTiles, int *out0, int *out1, int *out2) {
+                                                                   const unsigned int *__restrict__ tile_offsets, int nTiles, int *out0, int *out1, int *out2, int *out3 = nullptr) {
     __shared__ unsigned int wsum[NSCATTER][kCompactBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int *outs[3] = {out0, out1, out2};
+    int *outs[4] = {out0, out1, out2, out3};
     for (int tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
         int i = tile * kCompactBlock + threadIdx.x;
         unsigned key = 0xffu;

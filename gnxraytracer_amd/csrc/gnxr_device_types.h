@@ -76,11 +76,20 @@ struct DMaterial {
     int32_t has_bump;
     int32_t n_nonspecular;   // NumComponents(BSDF_ALL & ~BSDF_SPECULAR)
     float eta;               // BSDF::eta
-    int32_t shade_class;     // which k_shade specialisation can evaluate every lobe: 0 diffuse, 1 glossy, 2 any
-    int32_t _pad[3];
+    int32_t shade_class;     // which k_shade specialisation can evaluate every lobe: 0 diffuse, 1 glossy, 2 any, 3 image-textured (glossy lobe set)
+    int32_t kd_tex, ks_tex;  // 1 + texture index or 0: lobe 0 = Lambert / Oren (Kd), lobe 1 = microfacet (Ks), see compile_material
+    int32_t _pad;
     DLobe lobes[8];
 };
 
+// ---- image textures: ImageTexture + UVMapping2D + MIPMap (textures/ImageTexture.h, core/Texture.cpp:163-175, core/MIPMap.h) ----
+struct DTexture {
+    int32_t n_levels, w0, h0, wrap;      // level i is max(1, w0 >> i) x max(1, h0 >> i)
+    int32_t trilinear; float max_aniso;
+    float su, sv, du, dv;
+    int32_t level_offset[16];            // first texel (float4 rgb_) of each level in DTexTables::texels
+    int32_t _pad[2];
+};
 // ---- lights ----
 struct DLight {
     int32_t type;       // gnxr_light_type

@@ -51,6 +51,9 @@ struct CompiledScene {
     // shading
     std::vector<DMaterial> materials;
     std::vector<DMaterial> materials_single;   // allowMultipleLobes == false (Whitted)
+    std::vector<DTexture> textures;            // image textures: parameters + level offsets into tex_texels
+    std::vector<float> tex_texels;             // float4 (rgb_) per texel, all levels of all textures
+    std::vector<float> ewa_lut;                // MIPMap::weightLut
     std::vector<DLight> lights;
     std::vector<int32_t> infinite_lights;
     // sampler

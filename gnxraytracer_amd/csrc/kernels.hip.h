@@ -17,6 +17,7 @@
 #pragma once
 #include "device_bsdf.h"
 #include "device_lights.h"
+#include "device_texture.h"
 
 namespace gnxr {
 
@@ -44,7 +45,7 @@ struct PathArrays {
 struct Counters {
     unsigned long long nodes, tris;
     unsigned int q_next, q_nee, q_shadow, q_mis;   // k_compact_scan totals: paths that continue / have NEE / shadow rays / MIS rays
-    unsigned int q_class[3];                        // fill counts of the per-material-class shade queues
+    unsigned int q_class[4];                        // fill counts of the per-material-class shade queues (3: image-textured)
     unsigned int cursor;                            // k_trace work cursor
     unsigned long long whitted_shadow;              // shadow rays queued by k_whitted_step
     unsigned long long whitted_mis;                 // MIS closest-hit rays queued by k_whitted_step (DirectLighting); follows whitted_shadow
@@ -57,7 +58,7 @@ struct DScene {
     const DTri *tris;
     const DSphere *spheres;   // tested before the BVH; hit code -2 - index
     int n_spheres;
-    const DMaterial *materials;
+    const DMaterial *materials;   // materials[-1] holds the DTexTables of the scene (tex_tables(), device_texture.h)
     DLightTables lt;
     DSamplerTables st;
 };
@@ -125,6 +126,57 @@ GX_DEV void camera_ray(const DCamera &cam, const DSamplerTables &st, int px, int
         tm -= dt;
     }
     *o = ow; *d = dw; *tMax = tm; *dimOut = s.dim;
+}
+
+// The offset rays of the same camera sample: PerspectiveCamera::GenerateRayDifferential (camera/Perspective.cpp:86-110),
+// Transform::operator()(RayDifferential) (Transform.h:246-256: plain point / vector transforms) and
+// ray.ScaleDifferentials(1 / sqrt(samplesPerPixel)) (core/Integrator.cpp:283, Geometry.h:874-880).  A pure function of
+// (pixel, Halton index), so a kernel that needs them recomputes them instead of carrying 48 bytes per path.
+GX_DEV RayDiff camera_ray_diff(const DCamera &cam, const DSamplerTables &st, int px, int py, uint32_t index, int spp) {
+    V3 o, d;
+    float tMax;
+    int dim;
+    camera_ray(cam, st, px, py, index, &o, &d, &tMax, &dim);
+    SampleStream s(st, index, 0);
+    float fx, fy, lx, ly;
+    s.get2d(&fx, &fy);
+    (void)s.get1d();
+    s.get2d(&lx, &ly);
+    V3 pCamera = xform_point(cam.r2c, V3((float)px + fx, (float)py + fy, 0));
+    V3 dxCamera = xform_point(cam.r2c, V3(1, 0, 0)) - xform_point(cam.r2c, V3(0, 0, 0));
+    V3 dyCamera = xform_point(cam.r2c, V3(0, 1, 0)) - xform_point(cam.r2c, V3(0, 0, 0));
+    V3 rxO, ryO, rxD, ryD;
+    if (cam.lens_radius > 0) {
+        float ddx, ddy;
+        concentric_sample_disk(lx, ly, &ddx, &ddy);
+        float plx = cam.lens_radius * ddx, ply = cam.lens_radius * ddy;
+        V3 dx = normalize(pCamera + dxCamera);
+        float ft = cam.focal_distance / dx.z;
+        V3 pFocus = V3(0, 0, 0) + (ft * dx);
+        rxO = V3(plx, ply, 0);
+        rxD = normalize(pFocus - rxO);
+        V3 dy = normalize(pCamera + dyCamera);
+        ft = cam.focal_distance / dy.z;
+        pFocus = V3(0, 0, 0) + (ft * dy);
+        ryO = V3(plx, ply, 0);
+        ryD = normalize(pFocus - ryO);
+    } else {
+        rxO = ryO = V3(0, 0, 0);
+        rxD = normalize(pCamera + dxCamera);
+        ryD = normalize(pCamera + dyCamera);
+    }
+    RayDiff rdf;
+    rdf.has = true;
+    rdf.rxo = xform_point(cam.c2w, rxO);
+    rdf.ryo = xform_point(cam.c2w, ryO);
+    rdf.rxd = xform_vector(cam.c2w, rxD);
+    rdf.ryd = xform_vector(cam.c2w, ryD);
+    const float sc = 1 / gx_sqrt((float)(long long)spp);
+    rdf.rxo = o + (rdf.rxo - o) * sc;
+    rdf.ryo = o + (rdf.ryo - o) * sc;
+    rdf.rxd = d + (rdf.rxd - d) * sc;
+    rdf.ryd = d + (rdf.ryd - d) * sc;
+    return rdf;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -241,7 +293,9 @@ GX_DEV Spec nee_record_Ld(const PathArrays &pa, size_t rec, float *xw) {
 #else
 #define GX_SHADE_ATTR
 #endif
-template <uint32_t LM, int LT, bool SPH>
+// TEX: the queue holds hits on image-textured materials (shade class 3): Kd / Ks are looked up per hit, unfiltered -- PathIntegrator
+// slices the camera RayDifferential (`Ray ray(r)`, PathIntegrator.cpp:67), so ComputeDifferentials always takes its zero branch.
+template <uint32_t LM, int LT, bool SPH, bool TEX = false>
 __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRender r, PathArrays pa, const int *__restrict__ queue, const unsigned int *n_dev) {
     const int n = (int)*n_dev;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -297,6 +351,16 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
                     survive = true;
                 } else {
                     const DMaterial *mat = sc.materials + triMat;
+                    DMaterial tm;
+                    if (TEX && leaf >= 0 && (mat->kd_tex | mat->ks_tex)) {
+                        float tu, tv;
+                        V3 dpdu, dpdv;
+                        tri_uv_frame(p0, p1, p2, h, &tu, &tv, &dpdu, &dpdv);
+                        RayDiff none;
+                        none.has = false;
+                        textured_material(tex_tables(sc.materials), *mat, tu, tv, compute_differentials(none, sp.p, sp.n, dpdu, dpdv), &tm);
+                        mat = &tm;
+                    }
                     Bsdf<LM> bsdf;
                     bsdf.mat = mat; bsdf.ns = sp.ns; bsdf.ng = sp.n; bsdf.ss = sp.ss; bsdf.ts = sp.ts;
                     SampleStream ss(sc.st, index, dim);

@@ -195,12 +195,15 @@ static bool compile_material(const gnxr_material &m, DMaterial *out, bool allowM
     out->has_bump = m.has_bump;
     out->eta = 1;
     auto add = [&](const DLobe &l) { if (out->n_lobes < 8) out->lobes[out->n_lobes++] = l; };
+    const bool textured = m.kd_texture > 0 || m.ks_texture > 0;
+    if (textured && m.type != GNXR_MAT_PLASTIC && m.type != GNXR_MAT_MATTE) { set_error("image textures: Kd of MATTE, Kd / Ks of PLASTIC"); return false; }
+    out->kd_tex = m.kd_texture; out->ks_tex = m.type == GNXR_MAT_PLASTIC ? m.ks_texture : 0;
     switch (m.type) {
     case GNXR_MAT_NONE: break;
     case GNXR_MAT_MATTE: {  // MatteMaterial.cpp:14-32
         RGB r = clamp0(m.kd);
         float sig = clampf(m.sigma, 0, 90);
-        if (!black(r)) {
+        if (!black(r) || textured) {   // textured: lobe 0 is the Kd lobe, its R is looked up per hit (and the lobe dropped when black)
             if (sig == 0) { DLobe l = blank_lobe(LOBE_LAMBERT, BSDF_REFLECTION | BSDF_DIFFUSE); set_R(l, r); add(l); }
             else {  // OrenNayar ctor, Reflection.h:236-243
                 DLobe l = blank_lobe(LOBE_OREN, BSDF_REFLECTION | BSDF_DIFFUSE);
@@ -269,8 +272,9 @@ static bool compile_material(const gnxr_material &m, DMaterial *out, bool allowM
     }
     case GNXR_MAT_PLASTIC: {  // PlasticMaterial.cpp:15-41
         RGB kd = clamp0(m.kd), ks = clamp0(m.ks);
-        if (!black(kd)) { DLobe l = blank_lobe(LOBE_LAMBERT, BSDF_REFLECTION | BSDF_DIFFUSE); set_R(l, kd); add(l); }
-        if (!black(ks)) {
+        // textured: lobe 0 = Kd, lobe 1 = Ks always; a constant or looked-up black one is dropped per hit (device: textured_material)
+        if (!black(kd) || textured) { DLobe l = blank_lobe(LOBE_LAMBERT, BSDF_REFLECTION | BSDF_DIFFUSE); set_R(l, kd); add(l); }
+        if (!black(ks) || textured) {
             DLobe l = blank_lobe(LOBE_MICRO_REFL, BSDF_REFLECTION | BSDF_GLOSSY);
             set_R(l, ks); l.fresnel = FRESNEL_DIELECTRIC; l.f_etaI = 1.5f; l.f_etaT = 1.f;
             float rough = m.urough;
@@ -361,6 +365,7 @@ static bool compile_material(const gnxr_material &m, DMaterial *out, bool allowM
                  !out->lobes[i].disney_g) ? 1 : 2;
         out->shade_class = std::max(out->shade_class, c);
     }
+    if (textured) out->shade_class = 3;   // own shade queue: its kernel evaluates the textures and rebuilds the lobe list per hit
     return true;
 }
 
@@ -650,6 +655,102 @@ static void build_env(const gnxr_scene_desc *d, const gnxr_light &l, bool flip_y
     cs->has_env = true;
 }
 
+// ------------------------------------------------------------------ image textures
+// ImageTexture::GetTexture (textures/ImageTexture.cpp:50-106: y flip, convertIn) + the MIPMap constructor (core/MIPMap.h:85-200:
+// Lanczos resample to powers of two with the wrap mode, clamp, box-filtered pyramid through Texel(), EWA weight table).
+static float inverse_gamma_correct(float value) {   // core/GNXRayTracer.h:367-371
+    if (value <= 0.04045f) return value * 1.f / 12.92f;
+    return std::pow((value + 0.055f) * 1.f / 1.055f, (float)2.4f);
+}
+static bool build_textures(const gnxr_scene_desc *d, CompiledScene *cs) {
+    cs->textures.clear(); cs->tex_texels.clear(); cs->ewa_lut.clear();
+    if (d->n_textures <= 0) return true;
+    if (!d->textures || !d->texels) { set_error("textures without texel data"); return false; }
+    cs->ewa_lut.resize(128);
+    for (int i = 0; i < 128; ++i) {   // MIPMap.h:191-198
+        float alpha = 2;
+        float r2 = float(i) / float(128 - 1);
+        cs->ewa_lut[i] = std::exp(-alpha * r2) - std::exp(-alpha);
+    }
+    for (int ti = 0; ti < d->n_textures; ++ti) {
+        const gnxr_texture &t = d->textures[ti];
+        if (t.width <= 0 || t.height <= 0 || t.texel_offset < 0 || t.wrap < GNXR_WRAP_REPEAT || t.wrap > GNXR_WRAP_CLAMP) { set_error("texture %d: bad description", ti); return false; }
+        const float *src = d->texels + t.texel_offset;
+        int rx = t.width, ry = t.height;
+        std::vector<float> tex((size_t)rx * ry * 3);
+        for (int y = 0; y < ry; ++y)
+            for (int x = 0; x < rx; ++x)
+                for (int c = 0; c < 3; ++c) {
+                    float v = src[((size_t)(ry - 1 - y) * rx + x) * 3 + c];   // flipped: (0,0) is the lower left corner
+                    tex[((size_t)y * rx + x) * 3 + c] = t.scale * (t.gamma ? inverse_gamma_correct(v) : v);
+                }
+        auto wrap = [&](int v, int res) { return t.wrap == GNXR_WRAP_REPEAT ? modi(v, res) : (t.wrap == GNXR_WRAP_CLAMP ? std::min(std::max(v, 0), res - 1) : v); };
+        if ((rx & (rx - 1)) || (ry & (ry - 1))) {
+            int px = round_up_pow2(rx), py = round_up_pow2(ry);
+            std::vector<RW> sw = resample_weights(rx, px);
+            std::vector<float> res((size_t)px * py * 3, 0.f);
+            for (int tt = 0; tt < ry; ++tt)
+                for (int s_ = 0; s_ < px; ++s_)
+                    for (int c = 0; c < 3; ++c) {
+                        float acc = 0.f;
+                        for (int j = 0; j < 4; ++j) {
+                            int o = wrap(sw[s_].first + j, rx);
+                            if (o >= 0 && o < rx) acc += sw[s_].w[j] * tex[((size_t)tt * rx + o) * 3 + c];
+                        }
+                        res[((size_t)tt * px + s_) * 3 + c] = acc;
+                    }
+            std::vector<RW> tw = resample_weights(ry, py);
+            std::vector<float> work((size_t)py * 3);
+            for (int s_ = 0; s_ < px; ++s_) {
+                for (int tt = 0; tt < py; ++tt)
+                    for (int c = 0; c < 3; ++c) {
+                        float acc = 0.f;
+                        for (int j = 0; j < 4; ++j) {
+                            int o = wrap(tw[tt].first + j, ry);
+                            if (o >= 0 && o < ry) acc += tw[tt].w[j] * res[((size_t)o * px + s_) * 3 + c];
+                        }
+                        work[(size_t)tt * 3 + c] = acc;
+                    }
+                for (int tt = 0; tt < py; ++tt)
+                    for (int c = 0; c < 3; ++c) res[((size_t)tt * px + s_) * 3 + c] = clampf(work[(size_t)tt * 3 + c], 0.f, INFINITY);
+            }
+            tex.swap(res);
+            rx = px; ry = py;
+        }
+        DTexture dt;
+        memset(&dt, 0, sizeof(dt));
+        dt.w0 = rx; dt.h0 = ry; dt.wrap = t.wrap; dt.trilinear = t.trilinear; dt.max_aniso = t.max_aniso;
+        dt.su = t.su; dt.sv = t.sv; dt.du = t.du; dt.dv = t.dv;
+        int nLevels = 1;
+        for (int m = std::max(rx, ry); m > 1; m >>= 1) ++nLevels;   // 1 + Log2Int(max res)
+        if (nLevels > 16) { set_error("texture %d: more than 16 MIP levels", ti); return false; }
+        dt.n_levels = nLevels;
+        std::vector<float> prev = tex, cur;
+        int pw = rx, ph = ry;
+        auto push_level = [&](const std::vector<float> &lvl, int level, int w, int h) {
+            dt.level_offset[level] = (int32_t)(cs->tex_texels.size() / 4);
+            for (size_t i = 0; i < (size_t)w * h; ++i) { cs->tex_texels.push_back(lvl[3 * i]); cs->tex_texels.push_back(lvl[3 * i + 1]); cs->tex_texels.push_back(lvl[3 * i + 2]); cs->tex_texels.push_back(0.f); }
+        };
+        push_level(prev, 0, pw, ph);
+        for (int i = 1; i < nLevels; ++i) {
+            int sRes = std::max(1, pw / 2), tRes = std::max(1, ph / 2);
+            cur.assign((size_t)sRes * tRes * 3, 0.f);
+            auto tx = [&](int s_, int t_, int c) -> float {   // Texel(i - 1, s, t)
+                if (t.wrap == GNXR_WRAP_BLACK && (s_ < 0 || s_ >= pw || t_ < 0 || t_ >= ph)) return 0.f;
+                return prev[((size_t)wrap(t_, ph) * pw + wrap(s_, pw)) * 3 + c];
+            };
+            for (int tt = 0; tt < tRes; ++tt)
+                for (int s_ = 0; s_ < sRes; ++s_)
+                    for (int c = 0; c < 3; ++c)
+                        cur[((size_t)tt * sRes + s_) * 3 + c] = .25f * (tx(2 * s_, 2 * tt, c) + tx(2 * s_ + 1, 2 * tt, c) + tx(2 * s_, 2 * tt + 1, c) + tx(2 * s_ + 1, 2 * tt + 1, c));
+            push_level(cur, i, sRes, tRes);
+            prev.swap(cur); pw = sRes; ph = tRes;
+        }
+        cs->textures.push_back(dt);
+    }
+    return true;
+}
+
 // ------------------------------------------------------------------ compile
 bool compile_scene(const gnxr_scene_desc *d, CompiledScene *cs) {
     if (!d || d->abi_version != GNXR_ABI_VERSION) { set_error("scene description ABI version mismatch"); return false; }
@@ -662,8 +763,11 @@ bool compile_scene(const gnxr_scene_desc *d, CompiledScene *cs) {
             set_error("material %d: texture reference out of range", i);
             return false;
         }
-    for (int i = 0; i < d->n_materials; ++i)
-        if (d->materials[i].kd_texture || d->materials[i].ks_texture) { set_error("image textures are not on the device yet"); return false; }   // TEXTURE-GUARD
+    if (!build_textures(d, cs)) return false;
+    for (int i = 0; i < d->n_spheres; ++i) {
+        const int m = d->spheres[i].material;
+        if (m >= 0 && m < d->n_materials && (d->materials[m].kd_texture || d->materials[m].ks_texture)) { set_error("sphere %d: image-textured materials are supported on triangles only", i); return false; }
+    }
     for (int i = 0; i < 3 * d->n_triangles; ++i)
         if (d->indices[i] < 0 || d->indices[i] >= d->n_vertices) { set_error("triangle index out of range"); return false; }
     for (int i = 0; i < d->n_triangles; ++i) {

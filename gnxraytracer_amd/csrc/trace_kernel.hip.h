@@ -342,8 +342,8 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
                     if (mat >= 0) cls = sc.materials[mat].shade_class;
                 } else if (sc.lt.n_infinite == 0) {
                     // a ray that escapes a scene without infinite lights adds nothing and ends its path (PathIntegrator.cpp:101-113):
-                    // no shading class (3 is binned nowhere), so it does not take a lane in a k_shade wave
-                    cls = 3;
+                    // no shading class (4 is binned nowhere), so it does not take a lane in a k_shade wave
+                    cls = 4;
                     pa.pflags[path] = 0;
                 }
                 pa.pclass[path] = (unsigned char)cls;

@@ -31,7 +31,7 @@ namespace gnxr {
 enum : int { VS_MAIN = 0, VS_SHADOW = 1, VS_MIS = 2 };
 
 struct VolArrays {
-    int4 *vs;        // x: state, y: Halton dimension, z: hit leaf of the saved vertex, w: (unused)
+    int4 *vs;        // x: state, y: Halton dimension, z: hit leaf of the saved vertex, w: 1 while the main ray is still the camera ray (it has ray differentials)
     float4 *sv_o;    // saved main ray of the vertex: o.xyz, tMax
     float4 *sv_d;    // d.xyz, medium (int bits)
     float4 *p1;      // light sample point p1.xyz, w: light-selection pdf
@@ -51,7 +51,7 @@ struct VolArrays {
 __global__ void __launch_bounds__(kBlock) k_vol_init(PathArrays pa, VolArrays va, int n_paths) {
     for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_paths; slot += gridDim.x * blockDim.x) {
         uint2 m = pa.meta[slot];
-        va.vs[slot] = make_int4(VS_MAIN, (int)m.y, -1, 0);
+        va.vs[slot] = make_int4(VS_MAIN, (int)m.y, -1, 1);
         va.state[slot] = (unsigned char)VS_MAIN;
         pa.meta[slot] = make_uint2(m.x, 0u);   // y: bounces << 16 | specularBounce << 31
     }
@@ -234,7 +234,10 @@ __global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt
 // diffuse-only instantiation, which needs far fewer registers than the Disney-capable one.
 // ST: the state every path of `queue` is in (the host bins the live paths by state before each step, so a wave runs one
 // of the three phases instead of all of them in turn); `n_dev` is the bin's fill count written by the binning.
-template <uint32_t LM, int LT, int ST>
+// TEX: the scene has image-textured materials.  VolPathIntegrator keeps the camera RayDifferential (`RayDifferential ray(r)`,
+// VolPathIntegrator.cpp:30) until the ray is replaced (pass-through, medium or surface scattering all assign a plain SpawnRay), so
+// a surface vertex reached by the camera ray itself filters its textures with the camera differentials (vs.w).
+template <uint32_t LM, int LT, int ST, bool TEX = false>
 __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt, DRender r, PathArrays pa, VolArrays va, const int *__restrict__ queue, const unsigned int *n_dev) {
     const int n = (int)*n_dev;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -387,6 +390,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
                     pa.beta[path] = make_float4(beta.r, beta.g, beta.b, etaScale);
                     pa.L[path] = make_float4(L.r, L.g, L.b, 0.f);
                     vs.y = ss.dim;
+                    vs.w = 0;   // isect.SpawnRay(ray.d): a plain Ray
                     va.vs[path] = vs; va.state[path] = (unsigned char)vs.x;
                     pa.pflags[path] = (unsigned char)(1 | (nm >= 0 ? 2 : 0));
                     continue;
@@ -405,6 +409,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
         SurfacePoint sp;
         sp.valid = true;
         const DMaterial *mat = nullptr;
+        DMaterial tm;
         Bsdf<LM> bsdf;
         V3 itP, itPError, itN;
         int medIn = rayMedium, medOut = rayMedium;
@@ -427,6 +432,20 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
                 (void)tri_test(p0, p1, p2, ro, rd, o4.w, &h);
                 mat = sc.materials + triMat;
                 sp = surface_point(p0, p1, p2, h, mat->has_bump != 0);
+                if (TEX && (mat->kd_tex | mat->ks_tex)) {
+                    float tu, tv;
+                    V3 dpdu, dpdv;
+                    tri_uv_frame(p0, p1, p2, h, &tu, &tv, &dpdu, &dpdv);
+                    RayDiff rdf;
+                    rdf.has = false;
+                    if (vs.w & 1) {
+                        int px, py;
+                        local_pixel(r, path % r.npix, &px, &py);
+                        rdf = camera_ray_diff(r.cam, sc.st, px, py, pa.meta[path].x, r.spp);
+                    }
+                    textured_material(tex_tables(sc.materials), *mat, tu, tv, compute_differentials(rdf, sp.p, sp.n, dpdu, dpdv), &tm);
+                    mat = &tm;
+                }
             }
             bsdf.mat = mat; bsdf.ns = sp.ns; bsdf.ng = sp.n; bsdf.ss = sp.ss; bsdf.ts = sp.ts;
             itP = sp.p; itPError = sp.pError; itN = sp.n;
@@ -583,6 +602,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
                     pa.meta[path] = make_uint2(index, ((uint32_t)(bounces + 1) << 16) | (specularBounce ? 0x80000000u : 0u));
                     vs.x = VS_MAIN;
                     vs.y = ss.dim;
+                    vs.w = 0;   // mi.SpawnRay(wi) / isect.SpawnRay(wi): a plain Ray
                     va.vs[path] = vs; va.state[path] = (unsigned char)vs.x;
                 }
             }

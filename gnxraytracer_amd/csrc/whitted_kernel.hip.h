@@ -39,6 +39,8 @@ struct WhittedArrays {
     float *fr_pdf;   // pdf of the pending child
     int cap;
     int n_lights;
+    // TEX only: offset rays (RayDifferential) of the ray that reaches depth d, [d * cap + path]; rxo.w: hasDifferentials
+    float4 *fr_rxo, *fr_rxd, *fr_ryo, *fr_ryd;
     int n_records;   // NEE records per vertex: lights (Whitted), 1 (DIRECT_ONE), sum of Light::nSamples (DIRECT_ALL)
     int start_dim;   // first regular dimension after the camera sample: 5, or arrayEndDim when arrays were requested
 };
@@ -52,6 +54,32 @@ __global__ void __launch_bounds__(kBlock) k_whitted_init(PathArrays pa, WhittedA
     }
 }
 
+GX_DEV void store_ray_diff(const WhittedArrays &wa, size_t slot, const RayDiff &d) {
+    wa.fr_rxo[slot] = make_float4(d.rxo.x, d.rxo.y, d.rxo.z, d.has ? 1.f : 0.f);
+    if (!d.has) return;
+    wa.fr_rxd[slot] = make_float4(d.rxd.x, d.rxd.y, d.rxd.z, 0.f);
+    wa.fr_ryo[slot] = make_float4(d.ryo.x, d.ryo.y, d.ryo.z, 0.f);
+    wa.fr_ryd[slot] = make_float4(d.ryd.x, d.ryd.y, d.ryd.z, 0.f);
+}
+GX_DEV RayDiff load_ray_diff(const WhittedArrays &wa, size_t slot) {
+    RayDiff d;
+    float4 a = wa.fr_rxo[slot];
+    d.has = a.w != 0.f;
+    if (d.has) {
+        float4 b = wa.fr_rxd[slot], c = wa.fr_ryo[slot], e = wa.fr_ryd[slot];
+        d.rxo = V3(a.x, a.y, a.z); d.rxd = V3(b.x, b.y, b.z); d.ryo = V3(c.x, c.y, c.z); d.ryd = V3(e.x, e.y, e.z);
+    }
+    return d;
+}
+// the camera ray's offset rays (scenes with image textures): differentials of the ray that reaches depth 0
+__global__ void __launch_bounds__(kBlock) k_whitted_init_diff(DScene sc, DRender r, PathArrays pa, WhittedArrays wa, int n_paths) {
+    for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_paths; slot += gridDim.x * blockDim.x) {
+        int px, py;
+        local_pixel(r, slot % r.npix, &px, &py);
+        store_ray_diff(wa, (size_t)slot, camera_ray_diff(r.cam, sc.st, px, py, pa.meta[slot].x, r.spp));
+    }
+}
+
 // record ids of the shadow rays of the paths in `q` (n paths): light * cap + path, light-major inside a path
 __global__ void __launch_bounds__(kBlock) k_whitted_expand(const int *__restrict__ q, int n, int n_lights, int cap, int *__restrict__ out) {
     for (long long i = blockIdx.x * blockDim.x + threadIdx.x; i < (long long)n * n_lights; i += (long long)gridDim.x * blockDim.x) {
@@ -62,7 +90,9 @@ __global__ void __launch_bounds__(kBlock) k_whitted_expand(const int *__restrict
 
 // pflags: bit0 the path is still alive, bit1 it has shadow rays to trace this round, bit2 it has a closest-hit ray to trace.
 // ray_counts[0] += shadow rays, ray_counts[1] += MIS closest-hit rays spawned here
-template <int MODE, int LT, bool SPH>
+// TEX: the scene has image-textured materials -- the frames carry ray differentials (WhittedIntegrator / DirectLightingIntegrator
+// take the camera RayDifferential and SpecularReflect / SpecularTransmit derive the children's), textures are filtered with them.
+template <int MODE, int LT, bool SPH, bool TEX = false>
 __global__ void __launch_bounds__(kBlock) k_whitted_step(DScene sc, DRender r, PathArrays pa, WhittedArrays wa, const int *__restrict__ queue, int n,
                                                          unsigned long long *ray_counts) {
     unsigned long long nShadow = 0, nMis = 0;
@@ -140,10 +170,19 @@ __global__ void __launch_bounds__(kBlock) k_whitted_step(DScene sc, DRender r, P
             } else if (triMat < 0) { // no BSDF: Li(isect.SpawnRay(ray.d), ..., depth)
                 V3 o2 = offset_ray_origin(sp.p, sp.pError, sp.n, rd);
                 pa.ray_o[path] = make_float4(o2.x, o2.y, o2.z, GX_INF);
+                if (TEX) wa.fr_rxo[(size_t)top * cap + path] = make_float4(0.f, 0.f, 0.f, 0.f);   // isect.SpawnRay(ray.d): a plain Ray
                 traceClosest = true;
             } else {
                 // establish the frame of this vertex: L = Le + (lightL, next round)
                 const DMaterial *mat = sc.materials + triMat;
+                DMaterial tm;
+                if (TEX && leaf >= 0 && (mat->kd_tex | mat->ks_tex)) {
+                    float tu, tv;
+                    V3 dpdu, dpdv;
+                    tri_uv_frame(p0, p1, p2, h, &tu, &tv, &dpdu, &dpdv);
+                    textured_material(tex_tables(sc.materials), *mat, tu, tv, compute_differentials(load_ray_diff(wa, (size_t)top * cap + path), sp.p, sp.n, dpdu, dpdv), &tm);
+                    mat = &tm;
+                }
                 Bsdf<LM_ALL> bsdf;
                 bsdf.mat = mat; bsdf.ns = sp.ns; bsdf.ng = sp.n; bsdf.ss = sp.ss; bsdf.ts = sp.ts;
                 const V3 woN = normalize(-rd);
@@ -260,6 +299,8 @@ __global__ void __launch_bounds__(kBlock) k_whitted_step(DScene sc, DRender r, P
                 SurfacePoint sp;
                 int triMat;
                 TriHit h;
+                V3 dpdu(0, 0, 0), dpdv(0, 0, 0);   // TEX: unshaded dpdu / dpdv for ComputeDifferentials (a sphere's only feed the uv
+                                                   // differentials, which multiply dndu = dndv = 0 below)
                 if (SPH && leaf < -1) {
                     const DSphere &sph = sc.spheres[-2 - leaf];
                     triMat = sph.material;
@@ -272,7 +313,9 @@ __global__ void __launch_bounds__(kBlock) k_whitted_step(DScene sc, DRender r, P
                     triMat = __float_as_int(b.w);
                     (void)tri_test(p0, p1, p2, ro, rd, fo.w, &h);
                     sp = surface_point(p0, p1, p2, h, sc.materials[triMat].has_bump != 0);
+                    if (TEX) { float tu, tv; tri_uv_frame(p0, p1, p2, h, &tu, &tv, &dpdu, &dpdv); }
                 }
+                // (image-textured materials have no specular lobe, so the host template's lobe list gives the same answers here)
                 Bsdf<LM_ALL> bsdf;
                 bsdf.mat = sc.materials + triMat; bsdf.ns = sp.ns; bsdf.ng = sp.n; bsdf.ss = sp.ss; bsdf.ts = sp.ts;
                 const V3 woN = normalize(-rd);
@@ -290,6 +333,13 @@ __global__ void __launch_bounds__(kBlock) k_whitted_step(DScene sc, DRender r, P
                         pa.ray_d[path] = make_float4(wi.x, wi.y, wi.z, __int_as_float(-1));
                         wa.fr_w[fi] = make_float4(fs.r, fs.g, fs.b, absdot(wi, sp.ns));
                         wa.fr_pdf[fi] = pdf;
+                        if (TEX) {   // the child's offset rays, Integrator.cpp:335-354 / 376-436
+                            const RayDiff mine = load_ray_diff(wa, fi);
+                            const UVDiff ud = compute_differentials(mine, sp.p, sp.n, dpdu, dpdv);
+                            const RayDiff child = stage == 1 ? reflect_differentials(mine, ud, sp.p, sp.ns, woN, wi)
+                                                             : transmit_differentials(mine, ud, sp.p, sp.ns, bsdf.mat->eta, woN, wi);
+                            store_ray_diff(wa, (size_t)(f + 1) * cap + path, child);
+                        }
                         emitted = true;
                     }
                 }

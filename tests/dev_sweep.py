@@ -15,6 +15,8 @@ SCENES = {
     "sphere_glass": lambda: scenes.cornell_sphere("glass"), "sphere_mirror": lambda: scenes.cornell_sphere("mirror"),
     "vol_synth": lambda: scenes.volume_cornell(sigma_a=(0.5,) * 3, sigma_s=(3.5,) * 3, g_grid=0.3),
     "vol_cfg5_thin": lambda: scenes.volume_cornell_cfg5(0.05), "vol_sphere": lambda: scenes.cornell_sphere("medium"),
+    "textured": lambda: scenes.textured_cornell(os.path.join(GOLDEN, "tex_smile_96x80.hdr")),
+    "vol_textured": lambda: scenes.textured_cornell(os.path.join(GOLDEN, "tex_smile_96x80.hdr")),
     "no_lights": scenes.cornell_no_lights, "vol_fog": scenes.cornell_in_fog, "vol_no_lights": scenes.cornell_no_lights,
 }
 def run_sweep(seed=1, ncase=40, verbose=True):
