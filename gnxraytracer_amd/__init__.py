@@ -139,15 +139,21 @@ class SceneBuilder:
         return _check(lib().gnxr_builder_add_inf_light_data(self._h, rgb.ctypes.data_as(C.POINTER(C.c_float)), w, h, m,
                                                             _f3(power)))
 
-    def add_mesh(self, vertices, indices, material, object_to_world=None, medium_inside=-1, medium_outside=-1):
+    def add_mesh(self, vertices, indices, material, object_to_world=None, medium_inside=-1, medium_outside=-1, uv=None):
+        """TriangleMesh(ObjectToWorld, nTriangles, vertexIndices, nVertices, P, S = nullptr, N = nullptr, UV = uv, ...): uv is the
+        per-vertex (u, v) array of the mesh or None (Triangle::GetUVs defaults, what every mesh of the reference gets)."""
         v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
         i = np.ascontiguousarray(indices, dtype=np.int32).reshape(-1, 3)
         m = None
         if object_to_world is not None:
             m = np.ascontiguousarray(object_to_world, dtype=np.float32).reshape(16).ctypes.data_as(C.POINTER(C.c_float))
-        return _check(lib().gnxr_builder_add_mesh(self._h, v.ctypes.data_as(C.POINTER(C.c_float)), len(v),
-                                                  i.ctypes.data_as(C.POINTER(C.c_int32)), len(i), m, int(material),
-                                                  int(medium_inside), int(medium_outside)))
+        first = _check(lib().gnxr_builder_add_mesh(self._h, v.ctypes.data_as(C.POINTER(C.c_float)), len(v),
+                                                   i.ctypes.data_as(C.POINTER(C.c_int32)), len(i), m, int(material),
+                                                   int(medium_inside), int(medium_outside)))
+        if uv is not None:
+            corner = np.ascontiguousarray(np.asarray(uv, dtype=np.float32).reshape(-1, 2)[i].reshape(-1, 6))
+            _check(lib().gnxr_builder_set_triangle_uv(self._h, first, len(i), corner.ctypes.data_as(C.POINTER(C.c_float))))
+        return first
 
     def add_medium(self, medium, density=None):
         d = None

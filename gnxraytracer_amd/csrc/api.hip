@@ -114,7 +114,7 @@ struct gnxr_scene {
     DevBuf<DSphere> spheres;
     DevBuf<DMaterial> materials, materials_single;
     DevBuf<DTexture> textures;
-    DevBuf<float> tex_texels, ewa_lut;
+    DevBuf<float> tex_texels, ewa_lut, tri_uv;
     DevBuf<DLight> lights;
     DevBuf<int32_t> infinite;
     DevBuf<uint16_t> perms;
@@ -246,12 +246,12 @@ int gnxr_scene_create(const gnxr_scene_desc *desc, gnxr_scene **out) {
     for (const DNode &n : cs.nodes) if ((n.meta & 0xffffu) > 127) s->wide_ok = false;
 #define UP(field) if ((rc = s->field.upload(cs.field)) != GNXR_OK) { delete s; return rc; }
     UP(nodes) UP(nodes4) UP(tris) UP(lights) UP(perms) UP(primes) UP(prime_sums) UP(prime_magic)
-    UP(dmedia) UP(grid_density) UP(tri_media) UP(spheres) UP(textures) UP(tex_texels) UP(ewa_lut)
+    UP(dmedia) UP(grid_density) UP(tri_media) UP(spheres) UP(textures) UP(tex_texels) UP(ewa_lut) UP(tri_uv)
     UP(env_texels) UP(env_cond_func) UP(env_cond_cdf) UP(env_cond_int) UP(env_marg_func) UP(env_marg_cdf)
 #undef UP
     {   // materials, preceded by one record that carries the texture tables (tex_tables(), device_texture.h)
         DTexTables tt;
-        tt.textures = s->textures.p; tt.texels = reinterpret_cast<const float4 *>(s->tex_texels.p); tt.ewa_lut = s->ewa_lut.p;
+        tt.textures = s->textures.p; tt.texels = reinterpret_cast<const float4 *>(s->tex_texels.p); tt.ewa_lut = s->ewa_lut.p; tt.tri_uv = s->tri_uv.p;
         for (int k = 0; k < 2; ++k) {
             const std::vector<DMaterial> &src = k == 0 ? cs.materials : cs.materials_single;
             std::vector<DMaterial> up(src.size() + 1);
@@ -567,8 +567,8 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     } while (0)
 #define GX_SHADE_TEX(LTV)                                                                                                                            \
     do {                                                                                                                                             \
-        if (spheres) hipLaunchKernelGGL((k_shade<LM_GLOSSY, LTV, true, true>), g, b, 0, stream, sc, r, pa, (const int *)qc[3], (const unsigned int *)&dctr->q_class[3]); \
-        else hipLaunchKernelGGL((k_shade<LM_GLOSSY, LTV, false, true>), g, b, 0, stream, sc, r, pa, (const int *)qc[3], (const unsigned int *)&dctr->q_class[3]);       \
+        if (spheres) hipLaunchKernelGGL((k_shade<LM_ALL, LTV, true, true>), g, b, 0, stream, sc, r, pa, (const int *)qc[3], (const unsigned int *)&dctr->q_class[3]); \
+        else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, 0, stream, sc, r, pa, (const int *)qc[3], (const unsigned int *)&dctr->q_class[3]);       \
     } while (0)
                 if (area_only) {
                     GX_SHADE(LM_DIFFUSE, LT_AREA, 0);

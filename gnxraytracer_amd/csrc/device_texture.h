@@ -18,6 +18,7 @@ struct DTexTables {
     const DTexture *textures;
     const float4 *texels;
     const float *ewa_lut;                // MIPMap::weightLut[128]
+    const float *tri_uv;                 // null, or per leaf-order triangle (u,v) x 3 corners + 2 pad floats (TriangleMesh::uv)
 };
 
 // The tables travel in the slot BEFORE the first material (the material array is uploaded with one leading record) instead of in
@@ -149,18 +150,68 @@ GX_DEV void textured_material(const DTexTables &tt, const DMaterial &src, float 
     out->n_nonspecular = n;   // Lambert / OrenNayar / microfacet reflection: none is specular
 }
 
-// uv and the UNSHADED dpdu / dpdv of a triangle hit with the default uvs (0,0),(1,0),(1,1): the arithmetic of surface_point
-// (device_geom.h) before bump mapping, plus `uvHit = b0 * uv[0] + b1 * uv[1] + b2 * uv[2]` (Triangle.cpp:205)
-GX_DEV void tri_uv_frame(V3 p0, V3 p1, V3 p2, const TriHit &h, float *u, float *v, V3 *dpdu, V3 *dpdv) {
-    const float duv02_0 = 0.f - 1.f, duv02_1 = 0.f - 1.f, duv12_0 = 1.f - 1.f, duv12_1 = 0.f - 1.f;
+// Triangle::GetUVs, shape/Triangle.h:60-74
+struct TriUV { float u0, v0, u1, v1, u2, v2; };
+GX_DEV TriUV tri_uvs(const DTexTables &tt, bool has_uv, int leaf) {
+    TriUV t = {0.f, 0.f, 1.f, 0.f, 1.f, 1.f};
+    if (has_uv) {
+        const float4 *q = reinterpret_cast<const float4 *>(tt.tri_uv + (size_t)leaf * 8);
+        float4 a = q[0], b = q[1];
+        t.u0 = a.x; t.v0 = a.y; t.u1 = a.z; t.v1 = a.w; t.u2 = b.x; t.v2 = b.y;
+    }
+    return t;
+}
+// dpdu / dpdv of Triangle::Intersect for arbitrary uvs (shape/Triangle.cpp:170-196): the arithmetic surface_point (device_geom.h)
+// has folded for the default uvs; false when the triangle is degenerate (ng == 0: the reference reports no hit)
+GX_DEV bool tri_dpduv(V3 p0, V3 p1, V3 p2, const TriUV &uv, V3 *dpdu, V3 *dpdv) {
+    const float duv02_0 = uv.u0 - uv.u2, duv02_1 = uv.v0 - uv.v2, duv12_0 = uv.u1 - uv.u2, duv12_1 = uv.v1 - uv.v2;
     V3 dp02 = p0 - p2, dp12 = p1 - p2;
     float determinant = duv02_0 * duv12_1 - duv02_1 * duv12_0;
-    float invdet = 1 / determinant;
-    *dpdu = (duv12_1 * dp02 - duv02_1 * dp12) * invdet;
-    *dpdv = (-duv12_0 * dp02 + duv02_0 * dp12) * invdet;
-    if (length_sq(cross(*dpdu, *dpdv)) == 0) coordinate_system(normalize(cross(p2 - p0, p1 - p0)), dpdu, dpdv);
-    *u = h.b0 * 0.f + h.b1 * 1.f + h.b2 * 1.f;
-    *v = h.b0 * 0.f + h.b1 * 0.f + h.b2 * 1.f;
+    bool degenerateUV = (double)fabsf(determinant) < 1e-8;   // `std::abs(determinant) < 1e-8`: a double comparison
+    if (!degenerateUV) {
+        float invdet = 1 / determinant;
+        *dpdu = (duv12_1 * dp02 - duv02_1 * dp12) * invdet;
+        *dpdv = (-duv12_0 * dp02 + duv02_0 * dp12) * invdet;
+    }
+    if (degenerateUV || length_sq(cross(*dpdu, *dpdv)) == 0) {
+        V3 ng = cross(p2 - p0, p1 - p0);
+        if (length_sq(ng) == 0) return false;
+        coordinate_system(normalize(ng), dpdu, dpdv);
+    }
+    return true;
+}
+// uv of the hit (`uvHit = b0 * uv[0] + b1 * uv[1] + b2 * uv[2]`, Triangle.cpp:205) and the UNSHADED dpdu / dpdv
+GX_DEV void tri_uv_frame(V3 p0, V3 p1, V3 p2, const TriHit &h, const TriUV &uv, float *u, float *v, V3 *dpdu, V3 *dpdv) {
+    (void)tri_dpduv(p0, p1, p2, uv, dpdu, dpdv);
+    *u = h.b0 * uv.u0 + h.b1 * uv.u1 + h.b2 * uv.u2;
+    *v = h.b0 * uv.v0 + h.b1 * uv.v1 + h.b2 * uv.v2;
+}
+// surface_point (device_geom.h) for arbitrary uvs: same operations, dpdu / dpdv from tri_dpduv
+GX_DEV SurfacePoint surface_point_uv(V3 p0, V3 p1, V3 p2, const TriHit &h, bool has_bump, const TriUV &uv) {
+    SurfacePoint s;
+    s.valid = true;
+    V3 dpdu, dpdv;
+    if (!tri_dpduv(p0, p1, p2, uv, &dpdu, &dpdv)) { s.valid = false; return s; }
+    V3 dp02 = p0 - p2, dp12 = p1 - p2;
+    float xAbsSum = (fabsf(h.b0 * p0.x) + fabsf(h.b1 * p1.x) + fabsf(h.b2 * p2.x));
+    float yAbsSum = (fabsf(h.b0 * p0.y) + fabsf(h.b1 * p1.y) + fabsf(h.b2 * p2.y));
+    float zAbsSum = (fabsf(h.b0 * p0.z) + fabsf(h.b1 * p1.z) + fabsf(h.b2 * p2.z));
+    s.pError = GX_GAMMA(7) * V3(xAbsSum, yAbsSum, zAbsSum);
+    s.p = h.b0 * p0 + h.b1 * p1 + h.b2 * p2;
+    s.n = normalize(cross(dp02, dp12));
+    V3 sn = s.n, sdpdu = dpdu, sdpdv = dpdv;
+    if (has_bump) {   // Material::Bump with ConstantTexture(0): see surface_point
+        const float du = .0005f;
+        V3 zero(0, 0, 0);
+        sdpdu = dpdu + (0.f - 0.f) / du * sn + 0.f * zero;
+        sdpdv = dpdv + (0.f - 0.f) / du * sn + 0.f * zero;
+        sn = normalize(cross(sdpdu, sdpdv));
+        sn = faceforward(sn, s.n);
+    }
+    s.ns = sn;
+    s.ss = normalize(sdpdu);
+    s.ts = cross(s.ns, s.ss);
+    return s;
 }
 
 GX_DEV bool solve_2x2(float a00, float a01, float a10, float a11, float b0, float b1, float *x0, float *x1) {

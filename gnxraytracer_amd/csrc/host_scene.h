@@ -24,6 +24,7 @@ struct Builder {
     std::vector<float> grid_density;
     std::vector<gnxr_texture> textures;
     std::vector<float> texels;
+    std::vector<float> tri_uv;     // empty, or 6 floats per triangle (defaults for triangles never given uvs)
     std::vector<float> env_rgb;
     int env_w = 0, env_h = 0;
     gnxr_camera camera;
@@ -54,6 +55,7 @@ struct CompiledScene {
     std::vector<DTexture> textures;            // image textures: parameters + level offsets into tex_texels
     std::vector<float> tex_texels;             // float4 (rgb_) per texel, all levels of all textures
     std::vector<float> ewa_lut;                // MIPMap::weightLut
+    std::vector<float> tri_uv;                 // empty, or 8 floats per leaf-order triangle: (u,v) x 3 corners + pad
     std::vector<DLight> lights;
     std::vector<int32_t> infinite_lights;
     // sampler

@@ -143,6 +143,7 @@ int Builder::add_mesh(const float *verts, int nv, const int32_t *idx, int nt, co
         tri_light.push_back(-1);
         tri_med_in.push_back(med_in);
         tri_med_out.push_back(med_out);
+        if (!tri_uv.empty()) { const float def[6] = {0, 0, 1, 0, 1, 1}; tri_uv.insert(tri_uv.end(), def, def + 6); }
     }
     return first_tri;
 }
@@ -175,6 +176,7 @@ void Builder::fill_desc(gnxr_scene_desc *d) const {
     d->n_textures = (int)textures.size();
     d->textures = textures.empty() ? nullptr : textures.data();
     d->texels = texels.empty() ? nullptr : texels.data();
+    d->tri_uv = tri_uv.empty() ? nullptr : tri_uv.data();
 }
 
 // ---- `.3d` text meshes: shape/plyRead.h:19-48 ----
@@ -567,6 +569,16 @@ int gnxr_builder_set_material_texture(gnxr_builder *b, int32_t material, int32_t
     gnxr_material &m = b->b.materials[material];
     if (m.type != GNXR_MAT_PLASTIC && !(m.type == GNXR_MAT_MATTE && slot == 0)) { set_error("image textures: Kd of MATTE, Kd / Ks of PLASTIC"); return GNXR_ERR_UNSUPPORTED; }
     (slot == 0 ? m.kd_texture : m.ks_texture) = texture + 1;
+    return GNXR_OK;
+}
+
+int gnxr_builder_set_triangle_uv(gnxr_builder *b, int32_t first, int32_t n, const float *tri_uv) {
+    if (!b || !tri_uv || first < 0 || n < 0 || (size_t)first + (size_t)n > b->b.indices.size() / 3) return GNXR_ERR_INVALID;
+    if (b->b.tri_uv.empty()) {   // Triangle::GetUVs defaults for every triangle so far
+        const float def[6] = {0, 0, 1, 0, 1, 1};
+        for (size_t t = 0; t < b->b.indices.size() / 3; ++t) b->b.tri_uv.insert(b->b.tri_uv.end(), def, def + 6);
+    }
+    memcpy(&b->b.tri_uv[(size_t)first * 6], tri_uv, (size_t)n * 6 * sizeof(float));
     return GNXR_OK;
 }
 

@@ -836,6 +836,31 @@ bool compile_scene(const gnxr_scene_desc *d, CompiledScene *cs) {
     for (int i = 0; i < d->n_materials; ++i) if (!compile_material(d->materials[i], &cs->materials[i])) return false;
     cs->materials_single = cs->materials;   // ComputeScatteringFunctions(..., allowMultipleLobes = false): differs for smooth glass only
     for (int i = 0; i < d->n_materials; ++i) if (!compile_material(d->materials[i], &cs->materials_single[i], false)) return false;
+    // ---- per-corner uvs (TriangleMesh::uv).  A triangle whose uvs are not the GetUVs defaults gets a COPY of its material with
+    // shade class 3 (the general shade queue, which loads the uvs and derives dpdu / dpdv from them); everything else stays on
+    // the kernels that have the default uvs folded in.
+    cs->tri_uv.clear();
+    if (d->tri_uv) {
+        cs->tri_uv.assign((size_t)d->n_triangles * 8, 0.f);
+        std::vector<int> uv_copy(d->n_materials, -1);
+        const float def[6] = {0, 0, 1, 0, 1, 1};
+        for (int li = 0; li < d->n_triangles; ++li) {
+            const int prim = cs->tris[li].prim;
+            const float *uv = d->tri_uv + 6 * (size_t)prim;
+            memcpy(&cs->tri_uv[(size_t)li * 8], uv, 24);
+            DTri &t = cs->tris[li];
+            if (t.material < 0 || memcmp(uv, def, 24) == 0) continue;
+            if (uv_copy[t.material] < 0) {
+                uv_copy[t.material] = (int)cs->materials.size();
+                DMaterial m = cs->materials[t.material], ms = cs->materials_single[t.material];
+                m.shade_class = ms.shade_class = 3;
+                m.has_uv = ms.has_uv = 1;
+                cs->materials.push_back(m);
+                cs->materials_single.push_back(ms);
+            }
+            t.material = uv_copy[t.material];
+        }
+    }
     // ---- lights
     cs->lights.resize(std::max(1, d->n_lights));
     memset(cs->lights.data(), 0, sizeof(DLight) * cs->lights.size());

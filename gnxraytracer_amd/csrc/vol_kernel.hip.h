@@ -432,10 +432,11 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
                 (void)tri_test(p0, p1, p2, ro, rd, o4.w, &h);
                 mat = sc.materials + triMat;
                 sp = surface_point(p0, p1, p2, h, mat->has_bump != 0);
+                if (TEX && mat->has_uv) sp = surface_point_uv(p0, p1, p2, h, mat->has_bump != 0, tri_uvs(tex_tables(sc.materials), true, vleaf));
                 if (TEX && (mat->kd_tex | mat->ks_tex)) {
                     float tu, tv;
                     V3 dpdu, dpdv;
-                    tri_uv_frame(p0, p1, p2, h, &tu, &tv, &dpdu, &dpdv);
+                    tri_uv_frame(p0, p1, p2, h, tri_uvs(tex_tables(sc.materials), mat->has_uv != 0, vleaf), &tu, &tv, &dpdu, &dpdv);
                     RayDiff rdf;
                     rdf.has = false;
                     if (vs.w & 1) {

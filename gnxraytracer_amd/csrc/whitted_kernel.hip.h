@@ -162,7 +162,12 @@ __global__ void __launch_bounds__(kBlock) k_whitted_step(DScene sc, DRender r, P
                 p0 = V3(a.x, a.y, a.z); p1 = V3(b.x, b.y, b.z); p2 = V3(c.x, c.y, c.z);
                 triMat = __float_as_int(b.w); triLight = __float_as_int(c.w);
                 found = tri_test(p0, p1, p2, ro, rd, o4.w, &h);
-                if (found) { sp = surface_point(p0, p1, p2, h, triMat >= 0 ? sc.materials[triMat].has_bump != 0 : false); found = sp.valid; }
+                if (found) {
+                    sp = surface_point(p0, p1, p2, h, triMat >= 0 ? sc.materials[triMat].has_bump != 0 : false);
+                    if (TEX && triMat >= 0 && sc.materials[triMat].has_uv)
+                        sp = surface_point_uv(p0, p1, p2, h, sc.materials[triMat].has_bump != 0, tri_uvs(tex_tables(sc.materials), true, leaf));
+                    found = sp.valid;
+                }
             }
             if (!found) {           // `for (light : scene.lights) L += light->Le(ray)`
                 for (int l = 0; l < sc.lt.n_lights; ++l) result = result + light_Le<LT>(sc.lt, l, ro, rd);
@@ -179,7 +184,7 @@ __global__ void __launch_bounds__(kBlock) k_whitted_step(DScene sc, DRender r, P
                 if (TEX && leaf >= 0 && (mat->kd_tex | mat->ks_tex)) {
                     float tu, tv;
                     V3 dpdu, dpdv;
-                    tri_uv_frame(p0, p1, p2, h, &tu, &tv, &dpdu, &dpdv);
+                    tri_uv_frame(p0, p1, p2, h, tri_uvs(tex_tables(sc.materials), mat->has_uv != 0, leaf), &tu, &tv, &dpdu, &dpdv);
                     textured_material(tex_tables(sc.materials), *mat, tu, tv, compute_differentials(load_ray_diff(wa, (size_t)top * cap + path), sp.p, sp.n, dpdu, dpdv), &tm);
                     mat = &tm;
                 }
@@ -313,7 +318,12 @@ __global__ void __launch_bounds__(kBlock) k_whitted_step(DScene sc, DRender r, P
                     triMat = __float_as_int(b.w);
                     (void)tri_test(p0, p1, p2, ro, rd, fo.w, &h);
                     sp = surface_point(p0, p1, p2, h, sc.materials[triMat].has_bump != 0);
-                    if (TEX) { float tu, tv; tri_uv_frame(p0, p1, p2, h, &tu, &tv, &dpdu, &dpdv); }
+                    if (TEX) {
+                        const TriUV tuv = tri_uvs(tex_tables(sc.materials), sc.materials[triMat].has_uv != 0, leaf);
+                        if (sc.materials[triMat].has_uv) sp = surface_point_uv(p0, p1, p2, h, sc.materials[triMat].has_bump != 0, tuv);
+                        float tu, tv;
+                        tri_uv_frame(p0, p1, p2, h, tuv, &tu, &tv, &dpdu, &dpdv);
+                    }
                 }
                 // (image-textured materials have no specular lobe, so the host template's lobe list gives the same answers here)
                 Bsdf<LM_ALL> bsdf;

@@ -200,6 +200,9 @@ typedef struct gnxr_scene_desc {
     int32_t _pad;
     const gnxr_texture *textures;
     const float *texels;
+    const float *tri_uv;        /* n_triangles * 6 or NULL: (u,v) of each triangle's three corners = TriangleMesh::uv looked up through
+                                   the vertex indices (Triangle::GetUVs, shape/Triangle.h:60-74); NULL == the defaults (0,0),(1,0),(1,1)
+                                   every mesh of the reference gets (ui/ModelList.cpp passes uv = nullptr)                     */
 } gnxr_scene_desc;
 
 typedef enum gnxr_integrator {
@@ -362,6 +365,8 @@ int gnxr_builder_add_medium(gnxr_builder *b, const gnxr_medium *m, const float *
 int gnxr_builder_add_texture_data(gnxr_builder *b, const gnxr_texture *t, const float *rgb, int32_t w, int32_t h);
 int gnxr_builder_add_texture_file(gnxr_builder *b, const gnxr_texture *t, const char *hdr_path);
 int gnxr_builder_set_material_texture(gnxr_builder *b, int32_t material, int32_t slot /* 0 Kd, 1 Ks */, int32_t texture);
+/* per-corner (u,v) of triangles [first_triangle, first_triangle + n_triangles): tri_uv holds n_triangles * 6 floats */
+int gnxr_builder_set_triangle_uv(gnxr_builder *b, int32_t first_triangle, int32_t n_triangles, const float *tri_uv);
 int gnxr_builder_add_sphere(gnxr_builder *b, const float center[3], float radius, int32_t material, int32_t medium_inside,
                             int32_t medium_outside);                                      /* returns the sphere index */
 int gnxr_builder_set_camera(gnxr_builder *b, const gnxr_camera *cam);

@@ -298,6 +298,21 @@ def texture_goldens():
         assert maxdim < 1000 and same.all()
     out["cfg"] = np.array([W, H, spp, depth], np.int32)
     save("render_textured.npz", **out)
+    # per-vertex uv (TriangleMesh::uv): a separate fixture so that render_textured.npz stays the default-uv case
+    b = scenes.textured_cornell(tex_path, uv_quads=True)
+    path = scene_file(b, "textured_uv")
+    out = {}
+    for name, integ, args in [("path", gx.PathIntegrator(depth, 1.0, "spatial"), [0, 0, 0]), ("whitted", gx.WhittedIntegrator(depth), [0, 0, 2]),
+                              ("direct_one", gx.DirectLightingIntegrator("one", depth), [0, 0, 3, 1]), ("volpath", gx.VolPathIntegrator(depth, 1.0, "spatial"), [0, 0, 1])]:
+        raw = ol.run_ref(path, "render", None, [W, H, spp, depth, 1.0] + args)
+        out[name] = np.frombuffer(raw[:W * H * 16], np.float32).reshape(H, W, 4).copy()
+        out[name + "_rays"] = np.frombuffer(raw[W * H * 16:W * H * 16 + 16], np.uint64).copy()
+        oimg, st = ol.OracleScene(b).render(integ, W, H, spp)
+        same = oimg.view(np.uint32) == out[name].view(np.uint32)
+        print("textured_uv", name, "rays", out[name + "_rays"], (st["rays_closest"], st["rays_any"]), "identical %.3f%%" % (100 * same.mean()), "maxabs", float(np.abs(oimg - out[name]).max()))
+        assert same.all()
+    out["cfg"] = np.array([W, H, spp, depth], np.int32)
+    save("render_textured_uv.npz", **out)
 
 
 if __name__ == "__main__":

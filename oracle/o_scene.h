@@ -131,6 +131,7 @@ struct Scene {
     int cameraMedium = -1;
     std::vector<gnxr_sphere> spheres;   // prim index = nTriangles() + sphere index; tested before the triangle BVH
     std::vector<ImageTexture> textures; // gnxr_material::kd_texture / ks_texture - 1
+    std::vector<float> triUV;           // empty (Triangle::GetUVs defaults) or 6 floats per triangle, authoring order
     // BVH
     std::vector<LinearBVHNode> nodes;
     std::vector<int> orderedPrims;  // BVH leaf order -> authoring index (primitives.swap(orderedPrims), BVHAccel.cpp:171)
@@ -170,6 +171,7 @@ struct Scene {
         if (envW && envH) envRgb.assign(d->env_rgb, d->env_rgb + (size_t)envW * envH * 3);
         camera = d->camera;
         cameraMedium = d->camera_medium;
+        if (d->tri_uv) triUV.assign(d->tri_uv, d->tri_uv + 6 * (size_t)d->n_triangles);
         textures.resize(d->n_textures);
         for (int i = 0; i < d->n_textures; ++i) textures[i].Build(d->textures[i], d->texels + d->textures[i].texel_offset);
         if (d->n_spheres > 0) {
@@ -352,9 +354,10 @@ struct Scene {
         if (t <= deltaT) return false;
         if (!isect) { return true; }  // IntersectP stops here (Triangle.cpp:305-453 has no alpha mask on this path)
 
-        // partial derivatives with the default UVs (0,0),(1,0),(1,1), Triangle.h:60-74
+        // partial derivatives; GetUVs: mesh->uv through the indices, else (0,0),(1,0),(1,1), Triangle.h:60-74
         V3 dpdu, dpdv;
         P2 uv[3] = {P2(0, 0), P2(1, 0), P2(1, 1)};
+        if (!triUV.empty()) for (int k = 0; k < 3; ++k) uv[k] = P2(triUV[6 * (size_t)tri + 2 * k], triUV[6 * (size_t)tri + 2 * k + 1]);
         Float duv02[2] = {uv[0].x - uv[2].x, uv[0].y - uv[2].y}, duv12[2] = {uv[1].x - uv[2].x, uv[1].y - uv[2].y};
         V3 dp02 = p0 - p2, dp12 = p1 - p2;
         Float determinant = duv02[0] * duv12[1] - duv02[1] * duv12[0];

@@ -89,6 +89,7 @@ struct SceneFile {
     std::string hdrPath;
     std::vector<gnxr_texture> textures;        // file version 2
     std::vector<std::string> texturePaths;     // the image file each ImageTexture loads (the texels themselves stay behind)
+    std::vector<float> triUV;                  // file version 3: empty or 6 floats per triangle
 };
 
 bool readScene(const char *path, SceneFile *s) {
@@ -117,6 +118,10 @@ bool readScene(const char *path, SceneFile *s) {
             if (ok && plen > 0) { tp.resize(plen); ok = fread(&tp[0], 1, plen, f) == (size_t)plen; }
             s->texturePaths.push_back(tp);
         }
+    }
+    if (ok && ver >= 3) {
+        int32_t hasUV = 0;
+        ok = fread(&hasUV, 4, 1, f) == 1 && (!hasUV || rd(s->triUV, 6 * (size_t)s->nt));
     }
     fclose(f);
     return ok;
@@ -189,7 +194,9 @@ struct RefScene {
                 int v = sf.idx[3 * t + k];
                 P[k] = Point3f(sf.verts[3 * v], sf.verts[3 * v + 1], sf.verts[3 * v + 2]);
             }
-            auto mesh = std::make_shared<TriangleMesh>(identity, 1, vi, 3, P, nullptr, nullptr, nullptr, nullptr);
+            Point2f UV[3];
+            if (!sf.triUV.empty()) for (int k = 0; k < 3; ++k) UV[k] = Point2f(sf.triUV[6 * (size_t)t + 2 * k], sf.triUV[6 * (size_t)t + 2 * k + 1]);
+            auto mesh = std::make_shared<TriangleMesh>(identity, 1, vi, 3, P, nullptr, nullptr, sf.triUV.empty() ? nullptr : UV, nullptr);
             meshes.push_back(mesh);
             auto tri = std::make_shared<Triangle>(&identity, &identityInv, false, mesh, 0);
             shapes.push_back(tri);

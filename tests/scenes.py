@@ -245,7 +245,7 @@ def cornell_in_fog():
     return b
 
 
-def textured_cornell(tex_path, glass_sheet=True):
+def textured_cornell(tex_path, glass_sheet=True, uv_quads=False):
     """image-textured materials.  Back wall = the reference's getSmileFacePlasticMaterial (ui/MaterialList.cpp:31-46:
     Kd = Ks = one ImageTexture, EWA, Repeat) on `tex_path`; floor = Matte whose Kd is the same image tiled 3 x 3 through the
     trilinear filter with Clamp wrap, gamma and scale; left wall = mirror and a free-standing smooth-glass sheet so that Whitted /
@@ -270,5 +270,16 @@ def textured_cornell(tex_path, glass_sheet=True):
         sglass = b.add_material(type=gx._abi.MAT_GLASS, kr=(0.98,) * 3, kt=(0.98,) * 3, eta=(1.5, 0, 0), urough=0.0, vrough=0.0)
         v = np.array([[0.3, -2.5, 0.4], [1.9, -2.5, -0.6], [1.9, 0.4, -0.6], [0.3, 0.4, 0.4]], np.float32)
         b.add_mesh(v, np.array([[0, 1, 2], [0, 2, 3]], np.int32), sglass)
+    if uv_quads:
+        # meshes WITH per-vertex uv (TriangleMesh::uv): a poster showing the whole image once, a Disney-coated panel whose uvs
+        # run to 2.5 (Repeat) -- uv also sets dpdu / dpdv and with them the shading frame of every lobe --, and a panel whose
+        # three uvs coincide (degenerate: Triangle::Intersect falls back to CoordinateSystem(ng))
+        quad = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+        poster = np.array([[-2.0, -1.0, -2.2], [-0.2, -1.0, -2.3], [-0.2, 0.9, -2.3], [-2.0, 0.9, -2.2]], np.float32)
+        b.add_mesh(poster, quad, smile, uv=[[0, 0], [1, 0], [1, 1], [0, 1]])
+        panel = np.array([[0.9, -2.45, 1.2], [2.3, -2.45, 0.2], [2.3, -1.2, 0.0], [0.9, -1.2, 1.0]], np.float32)
+        b.add_mesh(panel, quad, disney_preset(b), uv=[[0.25, 0.5], [2.5, 0.5], [2.5, 1.75], [0.25, 1.75]])
+        flat = np.array([[-2.4, -2.4, 0.5], [-1.2, -2.4, 1.2], [-1.2, -1.5, 1.2], [-2.4, -1.5, 0.5]], np.float32)
+        b.add_mesh(flat, quad, floor, uv=[[0.4, 0.6]] * 4)
     b.AddAreaLight(white)
     return b

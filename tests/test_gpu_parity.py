@@ -348,6 +348,26 @@ def test_textured_materials_match_reference(gpu, name):
     assert (st["rays_closest"], st["rays_any"]) == (ost["rays_closest"], ost["rays_any"])
     assert biteq(img[..., :3], oimg[..., :3])
 
+@pytest.mark.parametrize("name", ["path", "whitted", "direct_one", "volpath", "direct_all"])
+def test_per_vertex_uvs_match_reference(gpu, name):
+    """TriangleMesh::uv on the device: triangles with uvs of their own go through the general shade queue, which derives dpdu /
+    dpdv (and with them every shading frame) and the texture coordinates from the stored corner uvs, degenerate uvs included.
+    Golden images of the reference's classes; direct_all compares with the oracle."""
+    g = golden("render_textured_uv.npz")
+    W, H, spp, depth = (int(v) for v in g["cfg"])
+    b = scenes.textured_cornell(os.path.join(GOLDEN, "tex_smile_96x80.hdr"), uv_quads=True)
+    integ = {"path": lambda: gpu.PathIntegrator(depth, 1.0, "spatial"), "whitted": lambda: gpu.WhittedIntegrator(depth),
+             "direct_all": lambda: gpu.DirectLightingIntegrator("all", depth), "direct_one": lambda: gpu.DirectLightingIntegrator("one", depth),
+             "volpath": lambda: gpu.VolPathIntegrator(depth, 1.0, "spatial")}[name]()
+    img, st = integ.Render(gpu.Scene(b), W, H, spp)
+    if name in g.files:
+        assert (st["rays_closest"], st["rays_any"]) == tuple(int(v) for v in g[name + "_rays"])
+        assert biteq(img[..., :3], g[name][..., :3])
+    else:
+        oimg, ost = ol.OracleScene(b).render(integ, W, H, spp)
+        assert (st["rays_closest"], st["rays_any"]) == (ost["rays_closest"], ost["rays_any"])
+        assert biteq(img[..., :3], oimg[..., :3])
+
 
 @pytest.mark.parametrize("kind", ["matte", "mirror", "glass", "medium"])
 def test_sphere_matches_oracle(gpu, kind):

@@ -200,6 +200,19 @@ def test_textured_images(name, gx):
     assert (st["rays_closest"], st["rays_any"]) == tuple(int(v) for v in g[name + "_rays"])
     assert biteq(img, g[name])
 
+@pytest.mark.parametrize("name", ["path", "whitted", "direct_one", "volpath"])
+def test_textured_uv_images(name, gx):
+    """TriangleMesh::uv (per-vertex uvs, Triangle::GetUVs / the dpdu-dpdv block of Triangle::Intersect): a poster mapped with the
+    whole image, a Disney panel whose uvs run past 1 and a panel with coinciding uvs (the degenerate-uv fallback to
+    CoordinateSystem(ng)); the uvs also set the shading frame of every lobe.  Images and ray counts of the reference's classes."""
+    g = golden("render_textured_uv.npz")
+    W, H, spp, depth = (int(v) for v in g["cfg"])
+    b = scenes.textured_cornell(os.path.join(GOLDEN, "tex_smile_96x80.hdr"), uv_quads=True)
+    integ = gx.DirectLightingIntegrator("one", depth) if name == "direct_one" else _textured_integrator(gx, name, depth)
+    img, st = ol.OracleScene(b).render(integ, W, H, spp)
+    assert (st["rays_closest"], st["rays_any"]) == tuple(int(v) for v in g[name + "_rays"])
+    assert biteq(img, g[name])
+
 
 def test_cfg2_reproduces_the_recorded_reference_run(gx):
     """the complete reference traced 16 058 662 closest-hit and 12 329 468 any-hit rays
