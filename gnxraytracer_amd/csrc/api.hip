@@ -11,10 +11,17 @@
 
 #include "host_scene.h"
 #include "kernels.hip.h"
-#include "vol_kernel.hip.h"
-#include "whitted_kernel.hip.h"
+#include "kernel_instances.h"
 
 using namespace gnxr;
+
+// compiled in inst_whitted.hip / inst_whitted_tex.hip / inst_vol.hip
+#define X(M, L, S, T) extern template GX_WHITTED_SIGNATURE(M, L, S, T)
+GX_WHITTED_INSTANCES(X)
+#undef X
+#define X(M, L, ST, T) extern template GX_VOL_SIGNATURE(M, L, ST, T)
+GX_VOL_INSTANCES(X)
+#undef X
 
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \

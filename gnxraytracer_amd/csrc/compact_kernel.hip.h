@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(kCompactBlock) k_compact_count(const int *__re
 }
 
 // pass 2: exclusive scan of each predicate's tile counts (one 1024-thread block per predicate), totals[o] = sum
-__global__ void __launch_bounds__(1024) k_compact_scan(unsigned int *tile_counts, int nTiles, unsigned int *totals) {
+static __global__ void __launch_bounds__(1024) k_compact_scan(unsigned int *tile_counts, int nTiles, unsigned int *totals) {
     __shared__ unsigned int wtot[16];
     __shared__ unsigned int carry_s;
     unsigned int *c = tile_counts + (size_t)blockIdx.x * nTiles;

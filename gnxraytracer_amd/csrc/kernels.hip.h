@@ -180,7 +180,7 @@ GX_DEV RayDiff camera_ray_diff(const DCamera &cam, const DSamplerTables &st, int
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) k_raygen(DScene sc, DRender r, PathArrays pa, int n_paths, int s0) {
+static __global__ void __launch_bounds__(kBlock) k_raygen(DScene sc, DRender r, PathArrays pa, int n_paths, int s0) {
     for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_paths; slot += gridDim.x * blockDim.x) {
         int j = slot / r.npix;
         int lp = slot - j * r.npix;
@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
 
 // ------------------------------------------------------------------------------------------------
 // colObj += Li(...) in sample order (core/Integrator.cpp:286), one lane per pixel, no atomics.
-__global__ void __launch_bounds__(kBlock) k_resolve(PathArrays pa, float4 *accum, int npix, int k) {
+static __global__ void __launch_bounds__(kBlock) k_resolve(PathArrays pa, float4 *accum, int npix, int k) {
     for (int lp = blockIdx.x * blockDim.x + threadIdx.x; lp < npix; lp += gridDim.x * blockDim.x) {
         float4 a = accum[lp];
         for (int j = 0; j < k; ++j) {
@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(kBlock) k_resolve(PathArrays pa, float4 *accum
     }
 }
 // colObj / samplesPerPixel and the FrameBuffer layout (x + y*W)*4 + c (core/Integrator.cpp:293-310)
-__global__ void __launch_bounds__(kBlock) k_finish(DRender r, const float4 *accum, float4 *out) {
+static __global__ void __launch_bounds__(kBlock) k_finish(DRender r, const float4 *accum, float4 *out) {
     for (int lp = blockIdx.x * blockDim.x + threadIdx.x; lp < r.npix; lp += gridDim.x * blockDim.x) {
         int x, y;
         local_pixel(r, lp, &x, &y);
@@ -551,13 +551,13 @@ __global__ void __launch_bounds__(kBlock) k_trace_any_api(DScene sc, const gnxr_
 }
 
 // probes
-__global__ void k_halton_probe(DSamplerTables st, const int *px, const int *py, const long long *s, const int *dim, long long n, float *out) {
+static __global__ void k_halton_probe(DSamplerTables st, const int *px, const int *py, const long long *s, const int *dim, long long n, float *out) {
     for (long long i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         uint32_t index = halton_pixel_offset(st.h, px[i], py[i]) + (uint32_t)s[i] * (uint32_t)st.h.stride;
         out[i] = halton_sample(st, index, dim[i]);
     }
 }
-__global__ void k_camera_probe(DSamplerTables st, DCamera cam, const int *px, const int *py, const long long *s, long long n, float *o_out, float *d_out) {
+static __global__ void k_camera_probe(DSamplerTables st, DCamera cam, const int *px, const int *py, const long long *s, long long n, float *o_out, float *d_out) {
     for (long long i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         uint32_t index = halton_pixel_offset(st.h, px[i], py[i]) + (uint32_t)s[i] * (uint32_t)st.h.stride;
         V3 o, d;
@@ -627,7 +627,7 @@ __global__ void __launch_bounds__(kBlock) k_light_grid(DLightTables lt, DLightGr
 }
 
 // test hook: the device's float libm (device_math.h) on caller-supplied arguments
-__global__ void k_libm_probe(int fn, const float *x, const float *x2, long long n, float *out) {
+static __global__ void k_libm_probe(int fn, const float *x, const float *x2, long long n, float *out) {
     for (long long i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float v = x[i];
         if (fn == 8) out[i] = gx_pow(v, x2 ? x2[i] : 1.0f);
@@ -639,7 +639,7 @@ __global__ void k_libm_probe(int fn, const float *x, const float *x2, long long 
 }
 
 // FrameBuffer::update_f_u_c, ui/FrameBuffer.h:127-149
-__global__ void k_framebuffer_update(float *mean, const float *frame, long long nvals, int frame_count, unsigned char *rgba8) {
+static __global__ void k_framebuffer_update(float *mean, const float *frame, long long nvals, int frame_count, unsigned char *rgba8) {
     for (long long i = blockIdx.x * blockDim.x + threadIdx.x; i < nvals; i += (long long)gridDim.x * blockDim.x) {
         if ((i & 3) == 3) { rgba8[i] = 255; continue; }  // set_uc(i, j, 3, 255)
         float weight = (1.0f / (float)frame_count);

@@ -129,7 +129,7 @@ GX_DEV int bvh4_step(const float4 *__restrict__ n4, int node, V3 ro, V3 invDir, 
 }
 
 #ifdef GX_TRACE_STATS
-__device__ unsigned long long g_trace_stats[16];
+static __device__ unsigned long long g_trace_stats[16];
 #define GX_STAT(i, v) do { if (lane == 0) st_[i] += (unsigned long long)(v); } while (0)
 #else
 #define GX_STAT(i, v) do {} while (0)
@@ -367,7 +367,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
 
 // L += beta * (EstimateDirect(...) / lightPdf), core/Integrator.cpp:78 + PathIntegrator.cpp:135-141, once the
 // two visibility results of the vertex are known.  Pure streaming.
-__global__ void __launch_bounds__(kBlock) k_nee_combine(PathArrays pa, const int *__restrict__ queue, int n) {
+static __global__ void __launch_bounds__(kBlock) k_nee_combine(PathArrays pa, const int *__restrict__ queue, int n) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         int path = queue[i];
         float4 sd4 = pa.sh_d[path], X4 = pa.sh_X[path];

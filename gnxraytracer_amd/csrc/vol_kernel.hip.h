@@ -48,7 +48,7 @@ struct VolArrays {
     float4 *mres;    // k_vol_media result for the ray in flight: Medium::Sample weight / Medium::Tr (rgb), w: t of the sampled interaction or -1
 };
 
-__global__ void __launch_bounds__(kBlock) k_vol_init(PathArrays pa, VolArrays va, int n_paths) {
+static __global__ void __launch_bounds__(kBlock) k_vol_init(PathArrays pa, VolArrays va, int n_paths) {
     for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_paths; slot += gridDim.x * blockDim.x) {
         uint2 m = pa.meta[slot];
         va.vs[slot] = make_int4(VS_MAIN, (int)m.y, -1, 1);
@@ -81,7 +81,7 @@ GX_DEV int hit_medium(const DScene &sc, const DMediaTables &mt, int leaf, int ra
 // loop and refills from the wave's pool when it ends.  Results: va.mres[path], and the path's stream position va.vs[path].y.
 constexpr int kMediaChunk = 256;   // most paths a wave takes per global atomic (smaller for thin launches, chosen by the host)
 
-__global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt, PathArrays pa, VolArrays va, const int *__restrict__ queue, int n, unsigned int *cursor, int chunk) {
+static __global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt, PathArrays pa, VolArrays va, const int *__restrict__ queue, int n, unsigned int *cursor, int chunk) {
     const int lane = __lane_id();
     const unsigned total = (unsigned)n;
     unsigned poolBase = 0, poolCount = 0;

@@ -45,7 +45,7 @@ struct WhittedArrays {
     int start_dim;   // first regular dimension after the camera sample: 5, or arrayEndDim when arrays were requested
 };
 
-__global__ void __launch_bounds__(kBlock) k_whitted_init(PathArrays pa, WhittedArrays wa, int n_paths) {
+static __global__ void __launch_bounds__(kBlock) k_whitted_init(PathArrays pa, WhittedArrays wa, int n_paths) {
     for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_paths; slot += gridDim.x * blockDim.x) {
         uint2 m = pa.meta[slot];
         // GlobalSampler::Get1D / Get2D jump over [arrayStartDim, arrayEndDim) (core/Sampler.cpp:165-166, 173-174); the camera
@@ -72,7 +72,7 @@ GX_DEV RayDiff load_ray_diff(const WhittedArrays &wa, size_t slot) {
     return d;
 }
 // the camera ray's offset rays (scenes with image textures): differentials of the ray that reaches depth 0
-__global__ void __launch_bounds__(kBlock) k_whitted_init_diff(DScene sc, DRender r, PathArrays pa, WhittedArrays wa, int n_paths) {
+static __global__ void __launch_bounds__(kBlock) k_whitted_init_diff(DScene sc, DRender r, PathArrays pa, WhittedArrays wa, int n_paths) {
     for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_paths; slot += gridDim.x * blockDim.x) {
         int px, py;
         local_pixel(r, slot % r.npix, &px, &py);
@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(kBlock) k_whitted_init_diff(DScene sc, DRender
 }
 
 // record ids of the shadow rays of the paths in `q` (n paths): light * cap + path, light-major inside a path
-__global__ void __launch_bounds__(kBlock) k_whitted_expand(const int *__restrict__ q, int n, int n_lights, int cap, int *__restrict__ out) {
+static __global__ void __launch_bounds__(kBlock) k_whitted_expand(const int *__restrict__ q, int n, int n_lights, int cap, int *__restrict__ out) {
     for (long long i = blockIdx.x * blockDim.x + threadIdx.x; i < (long long)n * n_lights; i += (long long)gridDim.x * blockDim.x) {
         int p = (int)(i / n_lights), l = (int)(i - (long long)p * n_lights);
         out[i] = l * cap + (q ? q[p] : p);
