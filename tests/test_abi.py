@@ -52,3 +52,19 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".h", ".cpp", ".hip")):
                 for line in open(os.path.join(dp, f), errors="replace"):
                     assert not bad.search(line), (f, line)
+
+
+def test_c_caller_builds_and_fails_loudly_without_a_device(gx):
+    """tools/gnxr_cli.c (RenderThread::run against the C ABI) compiles as C11 against include/gnxr.h and links libgnxr.so; without a
+    HIP device it reports GNXR_ERR_NO_DEVICE and exits with status 3 instead of rendering on the CPU."""
+    import subprocess, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import __graft_entry__ as ge
+    cli = ge.build_cli()
+    assert subprocess.run([cli, "--help"], capture_output=True).returncode == 0
+    assert subprocess.run([cli], capture_output=True).returncode == 2          # --out is required
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the failure path cannot be observed")
+    r = subprocess.run([cli, "--out", "/tmp/gnxr_cli_should_not_exist.png"], capture_output=True, text=True)
+    assert r.returncode == 3 and "no HIP device" in r.stderr and not os.path.exists("/tmp/gnxr_cli_should_not_exist.png")

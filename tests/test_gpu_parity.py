@@ -449,3 +449,33 @@ def test_framebuffer_update_matches_ui_framebuffer(gpu):
     assert biteq(mean[..., :3], expect[..., :3])
     tm = (1.0 - np.exp(-expect.astype(np.float64) / 0.25)) * 255
     assert np.abs(u2[..., :3].astype(np.float64) - np.floor(tm[..., :3])).max() <= 1 and (u2[..., 3] == 255).all()
+
+
+def test_c_caller_renders_the_default_scene(gpu, tmp_path):
+    """tools/gnxr_cli.c -- RenderThread::run in plain C against the C ABI: scene authoring through gnxr_builder_*, two Render()
+    iterations folded by gnxr_framebuffer_update (FrameBuffer::update_f_u_c) and written as PNG.  The file must decode to the RGBA8
+    plane the same pipeline produces through the Python mirror."""
+    import struct, subprocess, sys, zlib
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import __graft_entry__ as ge
+    cli = ge.build_cli()
+    W, H, spp = 64, 48, 8
+    for integ_name, integ in [("whitted", gpu.WhittedIntegrator(5)), ("path", gpu.PathIntegrator(5, 1.0, "spatial"))]:
+        out = tmp_path / f"cli_{integ_name}.png"
+        r = subprocess.run([cli, "--width", str(W), "--height", str(H), "--spp", str(spp), "--frames", "2", "--integrator", integ_name, "--sky", "--out", str(out)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        b = scenes.cornell(light_material="dragon", sky=True)
+        scene = gpu.Scene(b)
+        mean = np.zeros((H, W, 4), np.float32)
+        for f in (1, 2):
+            img, _ = integ.Render(scene, W, H, spp)
+            rgba8 = gpu.framebuffer_update(mean, img, f)
+        data = out.read_bytes()
+        pos, idat = 8, b""
+        while pos < len(data):
+            n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+            if typ == b"IDAT": idat += data[pos + 8:pos + 8 + n]
+            pos += 12 + n
+        raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(H, W * 4 + 1)
+        assert (raw[:, 1:].reshape(H, W, 4) == rgba8).all() and rgba8[..., :3].max() > 100
