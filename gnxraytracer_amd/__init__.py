@@ -139,9 +139,10 @@ class SceneBuilder:
         return _check(lib().gnxr_builder_add_inf_light_data(self._h, rgb.ctypes.data_as(C.POINTER(C.c_float)), w, h, m,
                                                             _f3(power)))
 
-    def add_mesh(self, vertices, indices, material, object_to_world=None, medium_inside=-1, medium_outside=-1, uv=None):
-        """TriangleMesh(ObjectToWorld, nTriangles, vertexIndices, nVertices, P, S = nullptr, N = nullptr, UV = uv, ...): uv is the
-        per-vertex (u, v) array of the mesh or None (Triangle::GetUVs defaults, what every mesh of the reference gets)."""
+    def add_mesh(self, vertices, indices, material, object_to_world=None, medium_inside=-1, medium_outside=-1, uv=None, normals=None):
+        """TriangleMesh(ObjectToWorld, nTriangles, vertexIndices, nVertices, P, S = nullptr, N = normals, UV = uv, ...): uv is the
+        per-vertex (u, v) array of the mesh or None (Triangle::GetUVs defaults, what every mesh of the reference gets); normals the
+        per-vertex object-space shading normals or None (flat shading)."""
         v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
         i = np.ascontiguousarray(indices, dtype=np.int32).reshape(-1, 3)
         m = None
@@ -153,6 +154,15 @@ class SceneBuilder:
         if uv is not None:
             corner = np.ascontiguousarray(np.asarray(uv, dtype=np.float32).reshape(-1, 2)[i].reshape(-1, 6))
             _check(lib().gnxr_builder_set_triangle_uv(self._h, first, len(i), corner.ctypes.data_as(C.POINTER(C.c_float))))
+        if normals is not None:
+            n = np.asarray(normals, dtype=np.float32).reshape(-1, 3)
+            if object_to_world is not None:   # Transform::operator()(Normal3f): n' = (M^-1)^T n, evaluated in float like Transform.h:308-315
+                minv = np.linalg.inv(np.asarray(object_to_world, dtype=np.float64).reshape(4, 4)).astype(np.float32)
+                x, y, z = n[:, 0].copy(), n[:, 1].copy(), n[:, 2].copy()
+                n = np.stack([minv[0, 0] * x + minv[1, 0] * y + minv[2, 0] * z, minv[0, 1] * x + minv[1, 1] * y + minv[2, 1] * z,
+                              minv[0, 2] * x + minv[1, 2] * y + minv[2, 2] * z], 1).astype(np.float32)
+            corner = np.ascontiguousarray(n[i].reshape(-1, 9))
+            _check(lib().gnxr_builder_set_triangle_normals(self._h, first, len(i), corner.ctypes.data_as(C.POINTER(C.c_float))))
         return first
 
     def add_medium(self, medium, density=None):

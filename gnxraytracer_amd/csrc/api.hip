@@ -121,7 +121,7 @@ struct gnxr_scene {
     DevBuf<DSphere> spheres;
     DevBuf<DMaterial> materials, materials_single;
     DevBuf<DTexture> textures;
-    DevBuf<float> tex_texels, ewa_lut, tri_uv;
+    DevBuf<float> tex_texels, ewa_lut, tri_uv, tri_n;
     DevBuf<DLight> lights;
     DevBuf<int32_t> infinite;
     DevBuf<uint16_t> perms;
@@ -253,12 +253,12 @@ int gnxr_scene_create(const gnxr_scene_desc *desc, gnxr_scene **out) {
     for (const DNode &n : cs.nodes) if ((n.meta & 0xffffu) > 127) s->wide_ok = false;
 #define UP(field) if ((rc = s->field.upload(cs.field)) != GNXR_OK) { delete s; return rc; }
     UP(nodes) UP(nodes4) UP(tris) UP(lights) UP(perms) UP(primes) UP(prime_sums) UP(prime_magic)
-    UP(dmedia) UP(grid_density) UP(tri_media) UP(spheres) UP(textures) UP(tex_texels) UP(ewa_lut) UP(tri_uv)
+    UP(dmedia) UP(grid_density) UP(tri_media) UP(spheres) UP(textures) UP(tex_texels) UP(ewa_lut) UP(tri_uv) UP(tri_n)
     UP(env_texels) UP(env_cond_func) UP(env_cond_cdf) UP(env_cond_int) UP(env_marg_func) UP(env_marg_cdf)
 #undef UP
     {   // materials, preceded by one record that carries the texture tables (tex_tables(), device_texture.h)
         DTexTables tt;
-        tt.textures = s->textures.p; tt.texels = reinterpret_cast<const float4 *>(s->tex_texels.p); tt.ewa_lut = s->ewa_lut.p; tt.tri_uv = s->tri_uv.p;
+        tt.textures = s->textures.p; tt.texels = reinterpret_cast<const float4 *>(s->tex_texels.p); tt.ewa_lut = s->ewa_lut.p; tt.tri_uv = cs.tri_uv.empty() ? nullptr : s->tri_uv.p; tt.tri_n = cs.tri_n.empty() ? nullptr : s->tri_n.p;   // (an empty upload still allocates)
         for (int k = 0; k < 2; ++k) {
             const std::vector<DMaterial> &src = k == 0 ? cs.materials : cs.materials_single;
             std::vector<DMaterial> up(src.size() + 1);
@@ -327,8 +327,10 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
         for (const gnxr_light &l : s->cs.desc_lights) { n_records += std::max(1, l.n_samples); max_light_samples = std::max(max_light_samples, l.n_samples); }
         n_records = std::max(1, n_records);
     }
-    if (whitted && (n_records > 64 || p.max_depth > 32 || !s->cs.media.empty())) {
-        set_error("Whitted / DirectLighting on the device: at most 64 light samples per vertex (every light is sampled at every vertex), depth 32, no media");
+    // (media in the scene are fine: these integrators never look at them -- a medium boundary without material is passed
+    // through by the main ray, WhittedIntegrator.cpp:34-35, and blocks shadow rays like any other surface, Light.cpp:28-31)
+    if (whitted && (n_records > 64 || p.max_depth > 32)) {
+        set_error("Whitted / DirectLighting on the device: at most 64 light samples per vertex (every light is sampled at every vertex), depth 32");
         return GNXR_ERR_UNSUPPORTED;
     }
     bool textured_scene = false;

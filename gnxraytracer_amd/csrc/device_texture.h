@@ -19,6 +19,7 @@ struct DTexTables {
     const float4 *texels;
     const float *ewa_lut;                // MIPMap::weightLut[128]
     const float *tri_uv;                 // null, or per leaf-order triangle (u,v) x 3 corners + 2 pad floats (TriangleMesh::uv)
+    const float *tri_n;                  // null, or per leaf-order triangle 3 shading normals (12 floats; zeros == none) (TriangleMesh::n)
 };
 
 // The tables travel in the slot BEFORE the first material (the material array is uploaded with one leading record) instead of in
@@ -152,9 +153,9 @@ GX_DEV void textured_material(const DTexTables &tt, const DMaterial &src, float 
 
 // Triangle::GetUVs, shape/Triangle.h:60-74
 struct TriUV { float u0, v0, u1, v1, u2, v2; };
-GX_DEV TriUV tri_uvs(const DTexTables &tt, bool has_uv, int leaf) {
+GX_DEV TriUV tri_uvs(const DTexTables &tt, int leaf) {
     TriUV t = {0.f, 0.f, 1.f, 0.f, 1.f, 1.f};
-    if (has_uv) {
+    if (tt.tri_uv && leaf >= 0) {   // the table holds the defaults for triangles that were never given uvs
         const float4 *q = reinterpret_cast<const float4 *>(tt.tri_uv + (size_t)leaf * 8);
         float4 a = q[0], b = q[1];
         t.u0 = a.x; t.v0 = a.y; t.u1 = a.z; t.v1 = a.w; t.u2 = b.x; t.v2 = b.y;
@@ -180,16 +181,56 @@ GX_DEV bool tri_dpduv(V3 p0, V3 p1, V3 p2, const TriUV &uv, V3 *dpdu, V3 *dpdv) 
     }
     return true;
 }
-// uv of the hit (`uvHit = b0 * uv[0] + b1 * uv[1] + b2 * uv[2]`, Triangle.cpp:205) and the UNSHADED dpdu / dpdv
-GX_DEV void tri_uv_frame(V3 p0, V3 p1, V3 p2, const TriHit &h, const TriUV &uv, float *u, float *v, V3 *dpdu, V3 *dpdv) {
-    (void)tri_dpduv(p0, p1, p2, uv, dpdu, dpdv);
-    *u = h.b0 * uv.u0 + h.b1 * uv.u1 + h.b2 * uv.u2;
-    *v = h.b0 * uv.v0 + h.b1 * uv.v1 + h.b2 * uv.v2;
+// TriangleMesh::n of a triangle; false when it has none
+struct TriN { V3 n0, n1, n2; };
+GX_DEV bool tri_normals(const DTexTables &tt, int leaf, TriN *out) {
+    if (!tt.tri_n || leaf < 0) return false;
+    const float4 *q = reinterpret_cast<const float4 *>(tt.tri_n + (size_t)leaf * 12);
+    float4 a = q[0], b = q[1], c = q[2];
+    out->n0 = V3(a.x, a.y, a.z); out->n1 = V3(a.w, b.x, b.y); out->n2 = V3(b.z, b.w, c.x);
+    return a.x != 0 || a.y != 0 || a.z != 0 || a.w != 0 || b.x != 0 || b.y != 0 || b.z != 0 || b.w != 0 || c.x != 0;
 }
-// surface_point (device_geom.h) for arbitrary uvs: same operations, dpdu / dpdv from tri_dpduv
-GX_DEV SurfacePoint surface_point_uv(V3 p0, V3 p1, V3 p2, const TriHit &h, bool has_bump, const TriUV &uv) {
+// The shading-geometry block of Triangle::Intersect for a triangle with per-vertex normals (shape/Triangle.cpp:228-297, mesh->s ==
+// nullptr): interpolated shading normal, the (ss, ts) frame, dndu / dndv, and SetShadingGeometry(ss, ts, dndu, dndv, true), which
+// flips the GEOMETRIC normal onto the shading normal's side.  In: the flat SurfacePoint's n and the unshaded dpdu.  Out: n (flipped),
+// shading.n, shading.dpdu (= ss), shading.dpdv (= ts), dndu, dndv.
+struct ShadingGeom { V3 n, sn, sdpdu, sdpdv, dndu, dndv; };
+GX_DEV ShadingGeom tri_shading_geometry(const TriN &tn, const TriHit &h, const TriUV &uv, V3 n, V3 dpdu) {
+    ShadingGeom g;
+    V3 ns = (h.b0 * tn.n0 + h.b1 * tn.n1 + h.b2 * tn.n2);
+    if (length_sq(ns) > 0) ns = normalize(ns);
+    else ns = n;
+    V3 ss = normalize(dpdu);
+    V3 ts = cross(ss, ns);
+    if (length_sq(ts) > 0.f) {
+        ts = normalize(ts);
+        ss = cross(ts, ns);
+    } else coordinate_system(ns, &ss, &ts);
+    const float duv02_0 = uv.u0 - uv.u2, duv02_1 = uv.v0 - uv.v2, duv12_0 = uv.u1 - uv.u2, duv12_1 = uv.v1 - uv.v2;
+    V3 dn1 = tn.n0 - tn.n2, dn2 = tn.n1 - tn.n2;
+    float determinant = duv02_0 * duv12_1 - duv02_1 * duv12_0;
+    if ((double)fabsf(determinant) < 1e-8) {
+        V3 dn = cross(tn.n2 - tn.n0, tn.n1 - tn.n0);
+        if (length_sq(dn) == 0) g.dndu = g.dndv = V3(0, 0, 0);
+        else coordinate_system(dn, &g.dndu, &g.dndv);
+    } else {
+        float invDet = 1 / determinant;
+        g.dndu = (duv12_1 * dn1 - duv02_1 * dn2) * invDet;
+        g.dndv = (-duv12_0 * dn1 + duv02_0 * dn2) * invDet;
+    }
+    // SetShadingGeometry(ss, ts, dndu, dndv, true), Interaction.cpp:36-54
+    g.sn = normalize(cross(ss, ts));
+    g.n = faceforward(n, g.sn);
+    g.sdpdu = ss; g.sdpdv = ts;
+    return g;
+}
+// SurfacePoint of a triangle hit with its attributes: per-corner uvs (`uv`, defaults when it has none) and, when `tn` is given,
+// per-vertex normals.  Material::Bump then runs on the shading geometry (core/Material.cpp:16-52 with the constant-0 displacement).
+// *dndu / *dndv receive shading.dndu / dndv (zero without normals).
+GX_DEV SurfacePoint surface_point_attr(V3 p0, V3 p1, V3 p2, const TriHit &h, bool has_bump, const TriUV &uv, const TriN *tn, V3 *dndu, V3 *dndv) {
     SurfacePoint s;
     s.valid = true;
+    *dndu = *dndv = V3(0, 0, 0);
     V3 dpdu, dpdv;
     if (!tri_dpduv(p0, p1, p2, uv, &dpdu, &dpdv)) { s.valid = false; return s; }
     V3 dp02 = p0 - p2, dp12 = p1 - p2;
@@ -200,11 +241,15 @@ GX_DEV SurfacePoint surface_point_uv(V3 p0, V3 p1, V3 p2, const TriHit &h, bool 
     s.p = h.b0 * p0 + h.b1 * p1 + h.b2 * p2;
     s.n = normalize(cross(dp02, dp12));
     V3 sn = s.n, sdpdu = dpdu, sdpdv = dpdv;
-    if (has_bump) {   // Material::Bump with ConstantTexture(0): see surface_point
+    if (tn) {
+        ShadingGeom g = tri_shading_geometry(*tn, h, uv, s.n, dpdu);
+        s.n = g.n; sn = g.sn; sdpdu = g.sdpdu; sdpdv = g.sdpdv;
+        *dndu = g.dndu; *dndv = g.dndv;
+    }
+    if (has_bump) {
         const float du = .0005f;
-        V3 zero(0, 0, 0);
-        sdpdu = dpdu + (0.f - 0.f) / du * sn + 0.f * zero;
-        sdpdv = dpdv + (0.f - 0.f) / du * sn + 0.f * zero;
+        sdpdu = sdpdu + (0.f - 0.f) / du * sn + 0.f * *dndu;
+        sdpdv = sdpdv + (0.f - 0.f) / du * sn + 0.f * *dndv;
         sn = normalize(cross(sdpdu, sdpdv));
         sn = faceforward(sn, s.n);
     }
@@ -212,6 +257,20 @@ GX_DEV SurfacePoint surface_point_uv(V3 p0, V3 p1, V3 p2, const TriHit &h, bool 
     s.ss = normalize(sdpdu);
     s.ts = cross(s.ns, s.ss);
     return s;
+}
+
+// the general-queue kernels shade every triangle hit through this: attributes from the scene tables (defaults when absent)
+GX_DEV SurfacePoint surface_point_tables(const DTexTables &tt, int leaf, V3 p0, V3 p1, V3 p2, const TriHit &h, bool has_bump, V3 *dndu, V3 *dndv) {
+    TriN tn;
+    const bool hasN = tri_normals(tt, leaf, &tn);
+    return surface_point_attr(p0, p1, p2, h, has_bump, tri_uvs(tt, leaf), hasN ? &tn : nullptr, dndu, dndv);
+}
+
+// uv of the hit (`uvHit = b0 * uv[0] + b1 * uv[1] + b2 * uv[2]`, Triangle.cpp:205) and the UNSHADED dpdu / dpdv
+GX_DEV void tri_uv_frame(V3 p0, V3 p1, V3 p2, const TriHit &h, const TriUV &uv, float *u, float *v, V3 *dpdu, V3 *dpdv) {
+    (void)tri_dpduv(p0, p1, p2, uv, dpdu, dpdv);
+    *u = h.b0 * uv.u0 + h.b1 * uv.u1 + h.b2 * uv.u2;
+    *v = h.b0 * uv.v0 + h.b1 * uv.v1 + h.b2 * uv.v2;
 }
 
 GX_DEV bool solve_2x2(float a00, float a01, float a10, float a11, float b0, float b1, float *x0, float *x1) {
@@ -251,13 +310,12 @@ GX_DEV UVDiff compute_differentials(const RayDiff &rd, V3 p, V3 n, V3 dpdu, V3 d
 }
 
 // Offset rays of the specular children, SamplerIntegrator::SpecularReflect / SpecularTransmit (core/Integrator.cpp:335-354,
-// 376-436).  shading.dndu / dndv are zero here (no per-vertex normals) but their products with the uv differentials are kept:
-// an infinite differential turns them into NaN as in the reference.  p / ns: the vertex; wo = isect.wo; wi the sampled direction.
-GX_DEV RayDiff reflect_differentials(const RayDiff &ray, const UVDiff &ud, V3 p, V3 ns, V3 wo, V3 wi) {
+// 376-436).  dndu / dndv = shading.dndu / dndv (zero without per-vertex normals; the products with the uv differentials are kept
+// either way).  p / ns: the vertex; wo = isect.wo; wi the sampled direction.
+GX_DEV RayDiff reflect_differentials(const RayDiff &ray, const UVDiff &ud, V3 p, V3 ns, V3 dndu, V3 dndv, V3 wo, V3 wi) {
     RayDiff rd;
     rd.has = ray.has;
     if (!ray.has) return rd;
-    const V3 dndu(0, 0, 0), dndv(0, 0, 0);
     rd.rxo = p + ud.dpdx;
     rd.ryo = p + ud.dpdy;
     V3 dndx = dndu * ud.dudx + dndv * ud.dvdx;
@@ -269,11 +327,10 @@ GX_DEV RayDiff reflect_differentials(const RayDiff &ray, const UVDiff &ud, V3 p,
     rd.ryd = wi - dwody + 2.f * V3(dot(wo, ns) * dndy + dDNdy * ns);
     return rd;
 }
-GX_DEV RayDiff transmit_differentials(const RayDiff &ray, const UVDiff &ud, V3 p, V3 ns, float bsdfEta, V3 wo, V3 wi) {
+GX_DEV RayDiff transmit_differentials(const RayDiff &ray, const UVDiff &ud, V3 p, V3 ns, V3 dndu, V3 dndv, float bsdfEta, V3 wo, V3 wi) {
     RayDiff rd;
     rd.has = ray.has;
     if (!ray.has) return rd;
-    const V3 dndu(0, 0, 0), dndv(0, 0, 0);
     rd.rxo = p + ud.dpdx;
     rd.ryo = p + ud.dpdy;
     V3 dndx = dndu * ud.dudx + dndv * ud.dvdx;

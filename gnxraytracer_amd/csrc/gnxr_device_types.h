@@ -78,7 +78,7 @@ struct DMaterial {
     float eta;               // BSDF::eta
     int32_t shade_class;     // which k_shade specialisation can evaluate every lobe: 0 diffuse, 1 glossy, 2 any, 3 general queue (image textures, per-corner uvs)
     int32_t kd_tex, ks_tex;  // 1 + texture index or 0: lobe 0 = Lambert / Oren (Kd), lobe 1 = microfacet (Ks), see compile_material
-    int32_t has_uv;          // copy of a material for triangles with their own uvs (DTexTables::tri_uv); shade class 3
+    int32_t has_attr;        // copy of a material for triangles with uvs / shading normals of their own (DTexTables::tri_uv, tri_n); shade class 3
     DLobe lobes[8];
 };
 

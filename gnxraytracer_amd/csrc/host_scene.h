@@ -25,6 +25,7 @@ struct Builder {
     std::vector<gnxr_texture> textures;
     std::vector<float> texels;
     std::vector<float> tri_uv;     // empty, or 6 floats per triangle (defaults for triangles never given uvs)
+    std::vector<float> tri_n;      // empty, or 9 floats per triangle (zeros for triangles without normals)
     std::vector<float> env_rgb;
     int env_w = 0, env_h = 0;
     gnxr_camera camera;
@@ -56,6 +57,7 @@ struct CompiledScene {
     std::vector<float> tex_texels;             // float4 (rgb_) per texel, all levels of all textures
     std::vector<float> ewa_lut;                // MIPMap::weightLut
     std::vector<float> tri_uv;                 // empty, or 8 floats per leaf-order triangle: (u,v) x 3 corners + pad
+    std::vector<float> tri_n;                  // empty, or 12 floats per leaf-order triangle: 3 shading normals + pad (zeros == none)
     std::vector<DLight> lights;
     std::vector<int32_t> infinite_lights;
     // sampler

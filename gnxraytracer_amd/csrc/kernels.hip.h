@@ -332,8 +332,10 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
                 found = tri_test(p0, p1, p2, ro, rd, o4.w, &h);  // same arithmetic as the traversal: always true here
                 if (found) {
                     sp = surface_point(p0, p1, p2, h, triMat >= 0 ? sc.materials[triMat].has_bump != 0 : false);
-                    if (TEX && triMat >= 0 && sc.materials[triMat].has_uv)   // the triangle has uvs of its own: dpdu / dpdv follow them
-                        sp = surface_point_uv(p0, p1, p2, h, sc.materials[triMat].has_bump != 0, tri_uvs(tex_tables(sc.materials), true, leaf));
+                    if (TEX) {   // per-corner uvs / shading normals (defaults when the triangle has none: same arithmetic as above)
+                        V3 dndu, dndv;
+                        sp = surface_point_tables(tex_tables(sc.materials), leaf, p0, p1, p2, h, triMat >= 0 ? sc.materials[triMat].has_bump != 0 : false, &dndu, &dndv);
+                    }
                     found = sp.valid;
                 }
             }
@@ -357,7 +359,7 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
                     if (TEX && leaf >= 0 && (mat->kd_tex | mat->ks_tex)) {
                         float tu, tv;
                         V3 dpdu, dpdv;
-                        tri_uv_frame(p0, p1, p2, h, tri_uvs(tex_tables(sc.materials), mat->has_uv != 0, leaf), &tu, &tv, &dpdu, &dpdv);
+                        tri_uv_frame(p0, p1, p2, h, tri_uvs(tex_tables(sc.materials), leaf), &tu, &tv, &dpdu, &dpdv);
                         RayDiff none;
                         none.has = false;
                         textured_material(tex_tables(sc.materials), *mat, tu, tv, compute_differentials(none, sp.p, sp.n, dpdu, dpdv), &tm);

@@ -144,6 +144,7 @@ int Builder::add_mesh(const float *verts, int nv, const int32_t *idx, int nt, co
         tri_med_in.push_back(med_in);
         tri_med_out.push_back(med_out);
         if (!tri_uv.empty()) { const float def[6] = {0, 0, 1, 0, 1, 1}; tri_uv.insert(tri_uv.end(), def, def + 6); }
+        if (!tri_n.empty()) tri_n.insert(tri_n.end(), 9, 0.f);
     }
     return first_tri;
 }
@@ -177,6 +178,7 @@ void Builder::fill_desc(gnxr_scene_desc *d) const {
     d->textures = textures.empty() ? nullptr : textures.data();
     d->texels = texels.empty() ? nullptr : texels.data();
     d->tri_uv = tri_uv.empty() ? nullptr : tri_uv.data();
+    d->tri_n = tri_n.empty() ? nullptr : tri_n.data();
 }
 
 // ---- `.3d` text meshes: shape/plyRead.h:19-48 ----
@@ -579,6 +581,13 @@ int gnxr_builder_set_triangle_uv(gnxr_builder *b, int32_t first, int32_t n, cons
         for (size_t t = 0; t < b->b.indices.size() / 3; ++t) b->b.tri_uv.insert(b->b.tri_uv.end(), def, def + 6);
     }
     memcpy(&b->b.tri_uv[(size_t)first * 6], tri_uv, (size_t)n * 6 * sizeof(float));
+    return GNXR_OK;
+}
+
+int gnxr_builder_set_triangle_normals(gnxr_builder *b, int32_t first, int32_t n, const float *tri_n) {
+    if (!b || !tri_n || first < 0 || n < 0 || (size_t)first + (size_t)n > b->b.indices.size() / 3) return GNXR_ERR_INVALID;
+    if (b->b.tri_n.empty()) b->b.tri_n.assign(b->b.indices.size() / 3 * 9, 0.f);
+    memcpy(&b->b.tri_n[(size_t)first * 9], tri_n, (size_t)n * 9 * sizeof(float));
     return GNXR_OK;
 }
 

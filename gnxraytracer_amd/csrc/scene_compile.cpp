@@ -836,29 +836,42 @@ bool compile_scene(const gnxr_scene_desc *d, CompiledScene *cs) {
     for (int i = 0; i < d->n_materials; ++i) if (!compile_material(d->materials[i], &cs->materials[i])) return false;
     cs->materials_single = cs->materials;   // ComputeScatteringFunctions(..., allowMultipleLobes = false): differs for smooth glass only
     for (int i = 0; i < d->n_materials; ++i) if (!compile_material(d->materials[i], &cs->materials_single[i], false)) return false;
-    // ---- per-corner uvs (TriangleMesh::uv).  A triangle whose uvs are not the GetUVs defaults gets a COPY of its material with
-    // shade class 3 (the general shade queue, which loads the uvs and derives dpdu / dpdv from them); everything else stays on
-    // the kernels that have the default uvs folded in.
+    // ---- per-corner uvs and shading normals (TriangleMesh::uv / ::n).  A triangle whose uvs are not the GetUVs defaults or that has
+    // normals gets a COPY of its material with shade class 3 (the general shade queue, which reads the attribute tables and derives
+    // dpdu / dpdv, the shading frame and dndu / dndv from them); everything else stays on the kernels with the defaults folded in.
     cs->tri_uv.clear();
-    if (d->tri_uv) {
-        cs->tri_uv.assign((size_t)d->n_triangles * 8, 0.f);
-        std::vector<int> uv_copy(d->n_materials, -1);
-        const float def[6] = {0, 0, 1, 0, 1, 1};
+    cs->tri_n.clear();
+    if (d->tri_uv || d->tri_n) {
+        if (d->tri_uv) cs->tri_uv.assign((size_t)d->n_triangles * 8, 0.f);
+        if (d->tri_n) cs->tri_n.assign((size_t)d->n_triangles * 12, 0.f);
+        std::vector<int> attr_copy(d->n_materials, -1);
+        const float def[6] = {0, 0, 1, 0, 1, 1}, zero9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int li = 0; li < d->n_triangles; ++li) {
             const int prim = cs->tris[li].prim;
-            const float *uv = d->tri_uv + 6 * (size_t)prim;
-            memcpy(&cs->tri_uv[(size_t)li * 8], uv, 24);
+            bool custom = false;
+            if (d->tri_uv) {
+                const float *uv = d->tri_uv + 6 * (size_t)prim;
+                memcpy(&cs->tri_uv[(size_t)li * 8], uv, 24);
+                custom = custom || memcmp(uv, def, 24) != 0;
+            }
+            if (d->tri_n) {
+                const float *nn = d->tri_n + 9 * (size_t)prim;
+                memcpy(&cs->tri_n[(size_t)li * 12], nn, 36);
+                const bool hasN = memcmp(nn, zero9, 36) != 0;
+                if (hasN && d->tri_light[prim] >= 0) { set_error("triangle %d: per-vertex normals on an emissive triangle are not supported", prim); return false; }
+                custom = custom || hasN;
+            }
             DTri &t = cs->tris[li];
-            if (t.material < 0 || memcmp(uv, def, 24) == 0) continue;
-            if (uv_copy[t.material] < 0) {
-                uv_copy[t.material] = (int)cs->materials.size();
+            if (t.material < 0 || !custom) continue;
+            if (attr_copy[t.material] < 0) {
+                attr_copy[t.material] = (int)cs->materials.size();
                 DMaterial m = cs->materials[t.material], ms = cs->materials_single[t.material];
                 m.shade_class = ms.shade_class = 3;
-                m.has_uv = ms.has_uv = 1;
+                m.has_attr = ms.has_attr = 1;
                 cs->materials.push_back(m);
                 cs->materials_single.push_back(ms);
             }
-            t.material = uv_copy[t.material];
+            t.material = attr_copy[t.material];
         }
     }
     // ---- lights

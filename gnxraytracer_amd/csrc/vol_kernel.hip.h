@@ -277,7 +277,11 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
             found = tri_test(p0, p1, p2, ro, rd, o4.w, &h);   // same arithmetic as the traversal
         }
         // hit point / error bound / normal of the traced ray's hit (no Bump: only p, pError, n are used)
-        auto hit_geometry = [&]() { return leaf < -1 ? sphere_surface_point(sc.spheres[-2 - leaf], ro, rd, h.t, false) : surface_point(p0, p1, p2, h, false); };
+        auto hit_geometry = [&]() {
+            if (leaf < -1) return sphere_surface_point(sc.spheres[-2 - leaf], ro, rd, h.t, false);
+            if (TEX) { V3 dndu, dndv; return surface_point_tables(tex_tables(sc.materials), leaf, p0, p1, p2, h, false, &dndu, &dndv); }   // n follows the shading normals
+            return surface_point(p0, p1, p2, h, false);
+        };
 
         if (ST != VS_MAIN) {
             // ---------------- phase 1: one segment of the light-sample ray or of the scattering ray ----------------
@@ -432,11 +436,11 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
                 (void)tri_test(p0, p1, p2, ro, rd, o4.w, &h);
                 mat = sc.materials + triMat;
                 sp = surface_point(p0, p1, p2, h, mat->has_bump != 0);
-                if (TEX && mat->has_uv) sp = surface_point_uv(p0, p1, p2, h, mat->has_bump != 0, tri_uvs(tex_tables(sc.materials), true, vleaf));
+                if (TEX) { V3 dndu, dndv; sp = surface_point_tables(tex_tables(sc.materials), vleaf, p0, p1, p2, h, mat->has_bump != 0, &dndu, &dndv); }
                 if (TEX && (mat->kd_tex | mat->ks_tex)) {
                     float tu, tv;
                     V3 dpdu, dpdv;
-                    tri_uv_frame(p0, p1, p2, h, tri_uvs(tex_tables(sc.materials), mat->has_uv != 0, vleaf), &tu, &tv, &dpdu, &dpdv);
+                    tri_uv_frame(p0, p1, p2, h, tri_uvs(tex_tables(sc.materials), vleaf), &tu, &tv, &dpdu, &dpdv);
                     RayDiff rdf;
                     rdf.has = false;
                     if (vs.w & 1) {

@@ -164,8 +164,7 @@ __global__ void __launch_bounds__(kBlock) k_whitted_step(DScene sc, DRender r, P
                 found = tri_test(p0, p1, p2, ro, rd, o4.w, &h);
                 if (found) {
                     sp = surface_point(p0, p1, p2, h, triMat >= 0 ? sc.materials[triMat].has_bump != 0 : false);
-                    if (TEX && triMat >= 0 && sc.materials[triMat].has_uv)
-                        sp = surface_point_uv(p0, p1, p2, h, sc.materials[triMat].has_bump != 0, tri_uvs(tex_tables(sc.materials), true, leaf));
+                    if (TEX) { V3 dndu, dndv; sp = surface_point_tables(tex_tables(sc.materials), leaf, p0, p1, p2, h, triMat >= 0 ? sc.materials[triMat].has_bump != 0 : false, &dndu, &dndv); }
                     found = sp.valid;
                 }
             }
@@ -184,7 +183,7 @@ __global__ void __launch_bounds__(kBlock) k_whitted_step(DScene sc, DRender r, P
                 if (TEX && leaf >= 0 && (mat->kd_tex | mat->ks_tex)) {
                     float tu, tv;
                     V3 dpdu, dpdv;
-                    tri_uv_frame(p0, p1, p2, h, tri_uvs(tex_tables(sc.materials), mat->has_uv != 0, leaf), &tu, &tv, &dpdu, &dpdv);
+                    tri_uv_frame(p0, p1, p2, h, tri_uvs(tex_tables(sc.materials), leaf), &tu, &tv, &dpdu, &dpdv);
                     textured_material(tex_tables(sc.materials), *mat, tu, tv, compute_differentials(load_ray_diff(wa, (size_t)top * cap + path), sp.p, sp.n, dpdu, dpdv), &tm);
                     mat = &tm;
                 }
@@ -306,6 +305,7 @@ __global__ void __launch_bounds__(kBlock) k_whitted_step(DScene sc, DRender r, P
                 TriHit h;
                 V3 dpdu(0, 0, 0), dpdv(0, 0, 0);   // TEX: unshaded dpdu / dpdv for ComputeDifferentials (a sphere's only feed the uv
                                                    // differentials, which multiply dndu = dndv = 0 below)
+                V3 dndu(0, 0, 0), dndv(0, 0, 0);   // shading.dndu / dndv: non-zero for triangles with per-vertex normals
                 if (SPH && leaf < -1) {
                     const DSphere &sph = sc.spheres[-2 - leaf];
                     triMat = sph.material;
@@ -319,10 +319,9 @@ __global__ void __launch_bounds__(kBlock) k_whitted_step(DScene sc, DRender r, P
                     (void)tri_test(p0, p1, p2, ro, rd, fo.w, &h);
                     sp = surface_point(p0, p1, p2, h, sc.materials[triMat].has_bump != 0);
                     if (TEX) {
-                        const TriUV tuv = tri_uvs(tex_tables(sc.materials), sc.materials[triMat].has_uv != 0, leaf);
-                        if (sc.materials[triMat].has_uv) sp = surface_point_uv(p0, p1, p2, h, sc.materials[triMat].has_bump != 0, tuv);
+                        sp = surface_point_tables(tex_tables(sc.materials), leaf, p0, p1, p2, h, sc.materials[triMat].has_bump != 0, &dndu, &dndv);
                         float tu, tv;
-                        tri_uv_frame(p0, p1, p2, h, tuv, &tu, &tv, &dpdu, &dpdv);
+                        tri_uv_frame(p0, p1, p2, h, tri_uvs(tex_tables(sc.materials), leaf), &tu, &tv, &dpdu, &dpdv);
                     }
                 }
                 // (image-textured materials have no specular lobe, so the host template's lobe list gives the same answers here)
@@ -346,8 +345,8 @@ __global__ void __launch_bounds__(kBlock) k_whitted_step(DScene sc, DRender r, P
                         if (TEX) {   // the child's offset rays, Integrator.cpp:335-354 / 376-436
                             const RayDiff mine = load_ray_diff(wa, fi);
                             const UVDiff ud = compute_differentials(mine, sp.p, sp.n, dpdu, dpdv);
-                            const RayDiff child = stage == 1 ? reflect_differentials(mine, ud, sp.p, sp.ns, woN, wi)
-                                                             : transmit_differentials(mine, ud, sp.p, sp.ns, bsdf.mat->eta, woN, wi);
+                            const RayDiff child = stage == 1 ? reflect_differentials(mine, ud, sp.p, sp.ns, dndu, dndv, woN, wi)
+                                                             : transmit_differentials(mine, ud, sp.p, sp.ns, dndu, dndv, bsdf.mat->eta, woN, wi);
                             store_ray_diff(wa, (size_t)(f + 1) * cap + path, child);
                         }
                         emitted = true;

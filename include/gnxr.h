@@ -203,6 +203,11 @@ typedef struct gnxr_scene_desc {
     const float *tri_uv;        /* n_triangles * 6 or NULL: (u,v) of each triangle's three corners = TriangleMesh::uv looked up through
                                    the vertex indices (Triangle::GetUVs, shape/Triangle.h:60-74); NULL == the defaults (0,0),(1,0),(1,1)
                                    every mesh of the reference gets (ui/ModelList.cpp passes uv = nullptr)                     */
+    const float *tri_n;         /* n_triangles * 9 or NULL: WORLD-space shading normals of each triangle's three corners = TriangleMesh::n
+                                   looked up through the vertex indices (shape/Triangle.cpp:228-297: interpolated shading normal,
+                                   shading frame, dndu / dndv, geometric normal flipped onto its side); three zero vectors == the
+                                   triangle has no normals.  Not allowed on emissive triangles.  Per-vertex tangents (TriangleMesh::s)
+                                   are not supported.                                                                        */
 } gnxr_scene_desc;
 
 typedef enum gnxr_integrator {
@@ -367,6 +372,9 @@ int gnxr_builder_add_texture_file(gnxr_builder *b, const gnxr_texture *t, const 
 int gnxr_builder_set_material_texture(gnxr_builder *b, int32_t material, int32_t slot /* 0 Kd, 1 Ks */, int32_t texture);
 /* per-corner (u,v) of triangles [first_triangle, first_triangle + n_triangles): tri_uv holds n_triangles * 6 floats */
 int gnxr_builder_set_triangle_uv(gnxr_builder *b, int32_t first_triangle, int32_t n_triangles, const float *tri_uv);
+/* per-corner WORLD-space shading normals (n_triangles * 9 floats); a caller with object-space normals applies the mesh's
+ * ObjectToWorld as TriangleMesh's constructor does (Transform::operator()(Normal3f): the inverse transpose) */
+int gnxr_builder_set_triangle_normals(gnxr_builder *b, int32_t first_triangle, int32_t n_triangles, const float *tri_n);
 int gnxr_builder_add_sphere(gnxr_builder *b, const float center[3], float radius, int32_t material, int32_t medium_inside,
                             int32_t medium_outside);                                      /* returns the sphere index */
 int gnxr_builder_set_camera(gnxr_builder *b, const gnxr_camera *cam);

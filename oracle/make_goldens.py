@@ -313,6 +313,24 @@ def texture_goldens():
         assert same.all()
     out["cfg"] = np.array([W, H, spp, depth], np.int32)
     save("render_textured_uv.npz", **out)
+    # per-vertex shading normals (TriangleMesh::n): smooth-shaded mirror / glass / textured / Disney balls, a medium container
+    b = scenes.smooth_cornell(tex_path)
+    path = scene_file(b, "smooth")
+    out = {}
+    for name, integ, args in [("path", gx.PathIntegrator(depth, 1.0, "spatial"), [0, 0, 0]), ("whitted", gx.WhittedIntegrator(depth), [0, 0, 2]),
+                              ("direct_all", gx.DirectLightingIntegrator("all", depth), [0, 0, 3, 0]), ("volpath", gx.VolPathIntegrator(depth, 1.0, "spatial"), [0, 0, 1])]:
+        raw = ol.run_ref(path, "render", None, [W, H, spp, depth, 1.0] + args)
+        out[name] = np.frombuffer(raw[:W * H * 16], np.float32).reshape(H, W, 4).copy()
+        out[name + "_rays"] = np.frombuffer(raw[W * H * 16:W * H * 16 + 16], np.uint64).copy()
+        ol.olib().gnxo_max_dimension(1)
+        oimg, st = ol.OracleScene(b).render(integ, W, H, spp)
+        maxdim = ol.olib().gnxo_max_dimension(1)
+        same = oimg.view(np.uint32) == out[name].view(np.uint32)
+        print("smooth", name, "rays", out[name + "_rays"], (st["rays_closest"], st["rays_any"]), "max dimension", maxdim, "identical %.3f%%" % (100 * same.mean()),
+              "maxabs", float(np.abs(oimg - out[name]).max()))
+        assert maxdim < 1000 and same.all()
+    out["cfg"] = np.array([W, H, spp, depth], np.int32)
+    save("render_smooth.npz", **out)
 
 
 if __name__ == "__main__":

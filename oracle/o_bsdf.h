@@ -491,10 +491,9 @@ inline Spec S3(const float *p) { return Spec(p[0], p[1], p[2]); }
 inline void Bump(SurfaceInteraction *si) {
     Float du = .0005f, dv = .0005f;
     Float uDisplace = 0, vDisplace = 0, displace = 0;
-    V3 zero(0, 0, 0);
-    V3 dpdu = si->sdpdu + (uDisplace - displace) / du * si->sn + displace * zero;
-    V3 dpdv = si->sdpdv + (vDisplace - displace) / dv * si->sn + displace * zero;
-    si->SetShadingGeometry(dpdu, dpdv, false);
+    V3 dpdu = si->sdpdu + (uDisplace - displace) / du * si->sn + displace * si->dndu;
+    V3 dpdv = si->sdpdv + (vDisplace - displace) / dv * si->sn + displace * si->dndv;
+    si->SetShadingGeometry(dpdu, dpdv, false);   // (dndu / dndv pass through unchanged)
 }
 
 // <Material>::ComputeScatteringFunctions(si, arena, TransportMode::Radiance, allowMultipleLobes)

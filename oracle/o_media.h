@@ -337,11 +337,10 @@ inline Spec VolPathLi(const RenderContext &rc, const PathParams &pp, const Ray &
 }
 
 // Ray differentials of the specular children, SamplerIntegrator::SpecularReflect / SpecularTransmit (core/Integrator.cpp:335-354,
-// 376-436).  shading.dndu / dndv are zero (no per-vertex normals on this path) but the products are kept: an infinite uv
-// differential turns them into NaN exactly as in the reference.
+// 376-436).  shading.dndu / dndv are zero unless the triangle has per-vertex normals.
 inline void ReflectDifferentials(const Ray &ray, const SurfaceInteraction &isect, const V3 &wo, const V3 &wi, Ray *rd) {
     if (!ray.hasDifferentials) return;
-    const V3 ns = isect.sn, dndu(0, 0, 0), dndv(0, 0, 0);
+    const V3 ns = isect.sn, dndu = isect.dndu, dndv = isect.dndv;
     rd->hasDifferentials = true;
     rd->rxOrigin = isect.p + isect.dpdx;
     rd->ryOrigin = isect.p + isect.dpdy;
@@ -356,7 +355,7 @@ inline void ReflectDifferentials(const Ray &ray, const SurfaceInteraction &isect
 inline void TransmitDifferentials(const Ray &ray, const SurfaceInteraction &isect, Float bsdfEta, const V3 &wo, const V3 &wi, Ray *rd) {
     if (!ray.hasDifferentials) return;
     V3 ns = isect.sn;
-    const V3 dndu(0, 0, 0), dndv(0, 0, 0);
+    const V3 dndu = isect.dndu, dndv = isect.dndv;
     rd->hasDifferentials = true;
     rd->rxOrigin = isect.p + isect.dpdx;
     rd->ryOrigin = isect.p + isect.dpdy;

@@ -48,6 +48,7 @@ struct SurfaceInteraction : Interaction {
     P2 uv;
     V3 dpdu, dpdv;
     V3 sn, sdpdu, sdpdv;  // shading.n / dpdu / dpdv
+    V3 dndu, dndv;        // shading.dndu / dndv: zero unless the triangle has per-vertex normals (Triangle.cpp:262-292)
     int prim = -1;         // triangle index in AUTHORING order (desc order)
     Float b0 = 0, b1 = 0, b2 = 0, t = 0;
     // SurfaceInteraction::ComputeDifferentials, Interaction.cpp:65-112 (mutable members there)
@@ -132,6 +133,7 @@ struct Scene {
     std::vector<gnxr_sphere> spheres;   // prim index = nTriangles() + sphere index; tested before the triangle BVH
     std::vector<ImageTexture> textures; // gnxr_material::kd_texture / ks_texture - 1
     std::vector<float> triUV;           // empty (Triangle::GetUVs defaults) or 6 floats per triangle, authoring order
+    std::vector<float> triN;            // empty or 9 floats per triangle (TriangleMesh::n through the indices; zeros == none)
     // BVH
     std::vector<LinearBVHNode> nodes;
     std::vector<int> orderedPrims;  // BVH leaf order -> authoring index (primitives.swap(orderedPrims), BVHAccel.cpp:171)
@@ -172,6 +174,7 @@ struct Scene {
         camera = d->camera;
         cameraMedium = d->camera_medium;
         if (d->tri_uv) triUV.assign(d->tri_uv, d->tri_uv + 6 * (size_t)d->n_triangles);
+        if (d->tri_n) triN.assign(d->tri_n, d->tri_n + 9 * (size_t)d->n_triangles);
         textures.resize(d->n_textures);
         for (int i = 0; i < d->n_textures; ++i) textures[i].Build(d->textures[i], d->texels + d->textures[i].texel_offset);
         if (d->n_spheres > 0) {
@@ -386,6 +389,37 @@ struct Scene {
         // Triangle.cpp:223-226 (no reverseOrientation / handedness swap on this path)
         si.n = si.sn = Normalize(Cross(dp02, dp12));
         si.p = b0 * p0 + b1 * p1 + b2 * p2;
+        // shading geometry of a triangle with per-vertex normals, Triangle.cpp:228-297 (mesh->s == nullptr, no reverseOrientation)
+        if (!triN.empty()) {
+            const float *q = &triN[9 * (size_t)tri];
+            V3 n0(q[0], q[1], q[2]), n1(q[3], q[4], q[5]), n2(q[6], q[7], q[8]);
+            if (n0 != V3() || n1 != V3() || n2 != V3()) {
+                V3 ns = (b0 * n0 + b1 * n1 + b2 * n2);
+                if (ns.LengthSquared() > 0) ns = Normalize(ns);
+                else ns = si.n;
+                V3 ss = Normalize(si.dpdu);
+                V3 ts = Cross(ss, ns);
+                if (ts.LengthSquared() > 0.f) {
+                    ts = Normalize(ts);
+                    ss = Cross(ts, ns);
+                } else CoordinateSystem(ns, &ss, &ts);
+                V3 dndu, dndv;
+                V3 dn1 = n0 - n2, dn2 = n1 - n2;
+                Float determinantN = duv02[0] * duv12[1] - duv02[1] * duv12[0];
+                bool degenerateUVN = std::abs(determinantN) < 1e-8;
+                if (degenerateUVN) {
+                    V3 dn = Cross(n2 - n0, n1 - n0);
+                    if (dn.LengthSquared() == 0) dndu = dndv = V3(0, 0, 0);
+                    else CoordinateSystem(dn, &dndu, &dndv);
+                } else {
+                    Float invDet = 1 / determinantN;
+                    dndu = (duv12[1] * dn1 - duv02[1] * dn2) * invDet;
+                    dndv = (-duv12[0] * dn1 + duv02[0] * dn2) * invDet;
+                }
+                si.dndu = dndu; si.dndv = dndv;
+                si.SetShadingGeometry(ss, ts, true);   // shading.n = Normalize(Cross(ss, ts)); n = Faceforward(n, shading.n)
+            }
+        }
         si.prim = tri; si.b0 = b0; si.b1 = b1; si.b2 = b2; si.t = t;
         // GeometricPrimitive::Intersect, Primitive.cpp:32-46
         ray.tMax = t;

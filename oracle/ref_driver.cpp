@@ -90,6 +90,7 @@ struct SceneFile {
     std::vector<gnxr_texture> textures;        // file version 2
     std::vector<std::string> texturePaths;     // the image file each ImageTexture loads (the texels themselves stay behind)
     std::vector<float> triUV;                  // file version 3: empty or 6 floats per triangle
+    std::vector<float> triN;                   // file version 4: empty or 9 floats per triangle (zeros == no normals)
 };
 
 bool readScene(const char *path, SceneFile *s) {
@@ -122,6 +123,10 @@ bool readScene(const char *path, SceneFile *s) {
     if (ok && ver >= 3) {
         int32_t hasUV = 0;
         ok = fread(&hasUV, 4, 1, f) == 1 && (!hasUV || rd(s->triUV, 6 * (size_t)s->nt));
+    }
+    if (ok && ver >= 4) {
+        int32_t hasN = 0;
+        ok = fread(&hasN, 4, 1, f) == 1 && (!hasN || rd(s->triN, 9 * (size_t)s->nt));
     }
     fclose(f);
     return ok;
@@ -196,7 +201,13 @@ struct RefScene {
             }
             Point2f UV[3];
             if (!sf.triUV.empty()) for (int k = 0; k < 3; ++k) UV[k] = Point2f(sf.triUV[6 * (size_t)t + 2 * k], sf.triUV[6 * (size_t)t + 2 * k + 1]);
-            auto mesh = std::make_shared<TriangleMesh>(identity, 1, vi, 3, P, nullptr, nullptr, sf.triUV.empty() ? nullptr : UV, nullptr);
+            Normal3f N[3];
+            bool hasN = false;
+            if (!sf.triN.empty()) for (int k = 0; k < 3; ++k) {
+                N[k] = Normal3f(sf.triN[9 * (size_t)t + 3 * k], sf.triN[9 * (size_t)t + 3 * k + 1], sf.triN[9 * (size_t)t + 3 * k + 2]);
+                hasN = hasN || N[k].x != 0 || N[k].y != 0 || N[k].z != 0;
+            }
+            auto mesh = std::make_shared<TriangleMesh>(identity, 1, vi, 3, P, nullptr, hasN ? N : nullptr, sf.triUV.empty() ? nullptr : UV, nullptr);
             meshes.push_back(mesh);
             auto tri = std::make_shared<Triangle>(&identity, &identityInv, false, mesh, 0);
             shapes.push_back(tri);

@@ -17,6 +17,8 @@ SCENES = {
     "vol_cfg5_thin": lambda: scenes.volume_cornell_cfg5(0.05), "vol_sphere": lambda: scenes.cornell_sphere("medium"),
     "textured": lambda: scenes.textured_cornell(os.path.join(GOLDEN, "tex_smile_96x80.hdr")),
     "vol_textured": lambda: scenes.textured_cornell(os.path.join(GOLDEN, "tex_smile_96x80.hdr")),
+    "smooth": lambda: scenes.smooth_cornell(os.path.join(GOLDEN, "tex_smile_96x80.hdr")),
+    "vol_smooth": lambda: scenes.smooth_cornell(os.path.join(GOLDEN, "tex_smile_96x80.hdr")),
     "textured_uv": lambda: scenes.textured_cornell(os.path.join(GOLDEN, "tex_smile_96x80.hdr"), uv_quads=True),
     "no_lights": scenes.cornell_no_lights, "vol_fog": scenes.cornell_in_fog, "vol_no_lights": scenes.cornell_no_lights,
 }

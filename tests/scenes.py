@@ -283,3 +283,58 @@ def textured_cornell(tex_path, glass_sheet=True, uv_quads=False):
         b.add_mesh(flat, quad, floor, uv=[[0.4, 0.6]] * 4)
     b.AddAreaLight(white)
     return b
+
+
+def uv_sphere_mesh(center, radius, n_lat=8, n_lon=12):
+    """Lat-long tessellated sphere with per-vertex uvs (phi / 2pi, theta / pi) and object-space normals (p - center) / r."""
+    c = np.asarray(center, np.float64)
+    verts, uvs, normals = [], [], []
+    for i in range(n_lat + 1):
+        th = np.pi * i / n_lat
+        for j in range(n_lon + 1):
+            ph = 2 * np.pi * j / n_lon
+            n = np.array([np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph)])
+            verts.append(c + radius * n); normals.append(n); uvs.append([j / n_lon, i / n_lat])
+    tris = []
+    for i in range(n_lat):
+        for j in range(n_lon):
+            a, b = i * (n_lon + 1) + j, (i + 1) * (n_lon + 1) + j
+            if i > 0: tris.append([a, b, a + 1])
+            if i < n_lat - 1: tris.append([a + 1, b, b + 1])
+    return np.array(verts, np.float32), np.array(tris, np.int32), np.array(uvs, np.float32), np.array(normals, np.float32)
+
+
+def smooth_cornell(tex_path, medium_ball=True):
+    """Per-vertex shading normals (TriangleMesh::n): coarse lat-long spheres that are smooth-shaded -- a mirror ball and a glass ball
+    (the interpolated normal drives the specular directions, dndu / dndv the ray differentials of Whitted / DirectLighting, and the
+    geometric normal is flipped onto the shading side, which the glass's etaScale and the medium interface read), a ball with normals
+    AND uvs carrying the image-textured plastic, a scaled (non-uniform object-to-world) Disney ellipsoid, and -- for VolPath -- a
+    null-material ball with normals around a HomogeneousMedium."""
+    b = gx.SceneBuilder()
+    white = b.MatteMaterial(WHITE, 60.0)
+    red = b.MatteMaterial(RED, 60.0)
+    blue = b.MatteMaterial(BLUE, 60.0)
+    mirror = b.MirrorMaterial((0.9, 0.9, 0.9))
+    sglass = b.add_material(type=gx._abi.MAT_GLASS, kr=(0.98,) * 3, kt=(0.98,) * 3, eta=(1.5, 0, 0), urough=0.0, vrough=0.0)
+    smile = b.getSmileFacePlasticMaterial(tex_path)
+    b.AddCornell(red, blue, white)
+    v, t, uv, n = uv_sphere_mesh((-1.3, -1.6, -0.6), 0.85)
+    b.add_mesh(v, t, mirror, normals=n)
+    v, t, uv, n = uv_sphere_mesh((1.2, -1.5, 0.6), 0.9, 6, 9)
+    b.add_mesh(v, t, sglass, normals=n)
+    v, t, uv, n = uv_sphere_mesh((0.0, 0.3, -1.3), 0.8, 7, 10)
+    b.add_mesh(v, t, smile, uv=uv, normals=n)
+    v, t, uv, n = uv_sphere_mesh((0.0, 0.0, 0.0), 1.0, 6, 8)
+    m = np.array([[0.7, 0, 0, 1.4], [0, 0.35, 0, 0.9], [0, 0, 0.5, -0.8], [0, 0, 0, 1]], np.float32)
+    b.add_mesh(v, t, disney_preset(b), object_to_world=m, uv=uv, normals=n)
+    if medium_ball:
+        hom = gx.Medium()
+        hom.type = gx._abi.MEDIUM_HOMOGENEOUS
+        hom.sigma_a[:] = (0.4, 0.5, 0.9)
+        hom.sigma_s[:] = (1.6, 1.4, 0.8)
+        hom.g = 0.3
+        med = b.add_medium(hom)
+        v, t, uv, n = uv_sphere_mesh((-0.3, -1.9, 1.4), 0.55, 6, 8)
+        b.add_mesh(v, t, -1, medium_inside=med, medium_outside=-1, normals=n)
+    b.AddAreaLight(white)
+    return b

@@ -368,6 +368,26 @@ def test_per_vertex_uvs_match_reference(gpu, name):
         assert (st["rays_closest"], st["rays_any"]) == (ost["rays_closest"], ost["rays_any"])
         assert biteq(img[..., :3], oimg[..., :3])
 
+@pytest.mark.parametrize("name", ["path", "whitted", "direct_all", "volpath", "direct_one"])
+def test_per_vertex_normals_match_reference(gpu, name):
+    """TriangleMesh::n on the device: the general shade queue reads the per-corner normals, builds the interpolated shading frame,
+    dndu / dndv (ray differentials of the specular children) and the flipped geometric normal (etaScale, medium interfaces).
+    Golden images of the reference's classes; direct_one compares with the oracle."""
+    g = golden("render_smooth.npz")
+    W, H, spp, depth = (int(v) for v in g["cfg"])
+    b = scenes.smooth_cornell(os.path.join(GOLDEN, "tex_smile_96x80.hdr"))
+    integ = {"path": lambda: gpu.PathIntegrator(depth, 1.0, "spatial"), "whitted": lambda: gpu.WhittedIntegrator(depth),
+             "direct_all": lambda: gpu.DirectLightingIntegrator("all", depth), "direct_one": lambda: gpu.DirectLightingIntegrator("one", depth),
+             "volpath": lambda: gpu.VolPathIntegrator(depth, 1.0, "spatial")}[name]()
+    img, st = integ.Render(gpu.Scene(b), W, H, spp)
+    if name in g.files:
+        assert (st["rays_closest"], st["rays_any"]) == tuple(int(v) for v in g[name + "_rays"])
+        assert biteq(img[..., :3], g[name][..., :3])
+    else:
+        oimg, ost = ol.OracleScene(b).render(integ, W, H, spp)
+        assert (st["rays_closest"], st["rays_any"]) == (ost["rays_closest"], ost["rays_any"])
+        assert biteq(img[..., :3], oimg[..., :3])
+
 
 @pytest.mark.parametrize("kind", ["matte", "mirror", "glass", "medium"])
 def test_sphere_matches_oracle(gpu, kind):

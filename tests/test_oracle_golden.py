@@ -213,6 +213,18 @@ def test_textured_uv_images(name, gx):
     assert (st["rays_closest"], st["rays_any"]) == tuple(int(v) for v in g[name + "_rays"])
     assert biteq(img, g[name])
 
+@pytest.mark.parametrize("name", ["path", "whitted", "direct_all", "volpath"])
+def test_smooth_normal_images(name, gx):
+    """TriangleMesh::n (per-vertex shading normals, the shading-geometry block of Triangle::Intersect, shape/Triangle.cpp:228-297):
+    interpolated normal, (ss, ts) frame, dndu / dndv, geometric normal flipped onto the shading side -- on a mirror ball, a glass
+    ball, a textured ball with uvs, a non-uniformly scaled Disney ellipsoid and a medium container.  The reference's classes."""
+    g = golden("render_smooth.npz")
+    W, H, spp, depth = (int(v) for v in g["cfg"])
+    b = scenes.smooth_cornell(os.path.join(GOLDEN, "tex_smile_96x80.hdr"))
+    img, st = ol.OracleScene(b).render(_textured_integrator(gx, name, depth), W, H, spp)
+    assert (st["rays_closest"], st["rays_any"]) == tuple(int(v) for v in g[name + "_rays"])
+    assert biteq(img, g[name])
+
 
 def test_cfg2_reproduces_the_recorded_reference_run(gx):
     """the complete reference traced 16 058 662 closest-hit and 12 329 468 any-hit rays
