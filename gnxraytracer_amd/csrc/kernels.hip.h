@@ -531,6 +531,12 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest_api(DScene sc, const g
             V3 p0, p1, p2;
             load_tri(sc.tris, leaf, &p0, &p1, &p2);
             V3 nn = normalize(cross(p0 - p2, p1 - p2));
+            const DTexTables &tt = tex_tables(sc.materials);
+            if (tt.tri_n) {   // per-vertex normals flip isect->n onto the shading side (SetShadingGeometry(..., true), Triangle.cpp:296)
+                V3 dndu, dndv;
+                SurfacePoint sp = surface_point_tables(tt, leaf, p0, p1, p2, h, false, &dndu, &dndv);
+                if (sp.valid) nn = sp.n;
+            }
             out.prim = sc.tris[leaf].prim; out.t = h.t; out.b0 = h.b0; out.b1 = h.b1; out.b2 = h.b2;
             out.n[0] = nn.x; out.n[1] = nn.y; out.n[2] = nn.z;
         }

@@ -758,6 +758,12 @@ bool compile_scene(const gnxr_scene_desc *d, CompiledScene *cs) {
         set_error("scene description has no geometry");
         return false;
     }
+    // counts and the arrays they describe must agree (the caller's pointers are read below without further checks)
+    if (d->n_materials < 0 || d->n_lights < 0 || d->n_media < 0 || d->n_spheres < 0 || d->n_textures < 0 || (d->n_materials > 0 && !d->materials) ||
+        (d->n_lights > 0 && !d->lights) || (d->n_media > 0 && !d->media) || (d->n_spheres > 0 && !d->spheres) || (d->n_textures > 0 && (!d->textures || !d->texels))) {
+        set_error("scene description: a table has a count but no data");
+        return false;
+    }
     for (int i = 0; i < d->n_materials; ++i)
         if (d->materials[i].kd_texture > d->n_textures || d->materials[i].ks_texture > d->n_textures || d->materials[i].kd_texture < 0 || d->materials[i].ks_texture < 0) {
             set_error("material %d: texture reference out of range", i);

@@ -379,7 +379,8 @@ def test_per_vertex_normals_match_reference(gpu, name):
     integ = {"path": lambda: gpu.PathIntegrator(depth, 1.0, "spatial"), "whitted": lambda: gpu.WhittedIntegrator(depth),
              "direct_all": lambda: gpu.DirectLightingIntegrator("all", depth), "direct_one": lambda: gpu.DirectLightingIntegrator("one", depth),
              "volpath": lambda: gpu.VolPathIntegrator(depth, 1.0, "spatial")}[name]()
-    img, st = integ.Render(gpu.Scene(b), W, H, spp)
+    scene = gpu.Scene(b)
+    img, st = integ.Render(scene, W, H, spp)
     if name in g.files:
         assert (st["rays_closest"], st["rays_any"]) == tuple(int(v) for v in g[name + "_rays"])
         assert biteq(img[..., :3], g[name][..., :3])
@@ -387,6 +388,10 @@ def test_per_vertex_normals_match_reference(gpu, name):
         oimg, ost = ol.OracleScene(b).render(integ, W, H, spp)
         assert (st["rays_closest"], st["rays_any"]) == (ost["rays_closest"], ost["rays_any"])
         assert biteq(img[..., :3], oimg[..., :3])
+        # Aggregate seam: isect->n of a smooth-shaded triangle is the geometric normal flipped onto the shading side
+        rays = scenes.random_rays(20000, seed=4)
+        gh, oh = scene.Intersect(rays), ol.OracleScene(b).Intersect(rays)
+        assert (gh["prim"] == oh["prim"]).all() and biteq(gh["t"], oh["t"]) and biteq(gh["n"], oh["n"])
 
 
 @pytest.mark.parametrize("kind", ["matte", "mirror", "glass", "medium"])
