@@ -6,10 +6,11 @@ maxDepth 8, rrThreshold 1, "spatial" light sampling, HaltonSampler(1024), 1920x1
 seeded SYNTHETIC stand-in for the reference's dragon.3d, which is absent from the snapshot
 (.MISSING_LARGE_BLOBS) -- numbers are not comparable with anyone else's "dragon".
 
-A step = one pass of the hot path over one batch: `--spp-per-step` (default 32) consecutive Halton samples
-of every pixel (66 M camera samples at 1080p; bigger batches keep the late, thin bounces of a pass from
-under-filling the GPU: 8 -> 2262, 16 -> 2554, 32 -> 2727, 64 -> 2810 Mrays/s).  The default --steps 32
-therefore renders the full 1024 spp image and `wall_to_1024spp_s` is measured, not extrapolated.
+A step = one pass of the hot path over one batch: `--spp-per-step` (default 128) consecutive Halton samples
+of every pixel (265 M camera samples at 1080p, 47 GB of path state in the 288 GB of HBM; bigger batches keep
+the late, thin bounces of a pass from under-filling the GPU: 8 -> 2262, 16 -> 2554 Mrays/s on an earlier
+build, 32 -> 2997, 64 -> 3065, 128 -> 3107 on the final one).  The default --steps 8 therefore renders the
+full 1024 spp image and `wall_to_1024spp_s` is measured, not extrapolated.
 
 With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) image rows are interleaved over
 the ranks, no collective runs during rendering, and the final FrameBuffer is gathered to rank 0 with one
@@ -38,9 +39,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, MI355X_MICROARCH.md
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp-per-step", type=int, default=32)
+    ap.add_argument("--spp-per-step", type=int, default=128,
+                    help="samples of every pixel rendered by one step = one pass; 128 at 1080p keeps 265 M paths (47 GB of the 288 GB) in flight")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=1024, help="HaltonSampler samplesPerPixel")
@@ -274,8 +276,11 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(name, {}).get("hbm_bytes_per_launch")
+            try:   # PMC bytes per launch belong to the launch size they were measured on (profiles/README.md)
+                tj = json.load(open(tpath))
+                on = tj.get("_measured_on", {})
+                if (on.get("workload"), on.get("spp_per_step"), on.get("width"), on.get("height")) == (args.workload, sps, W, H) and world == 1:
+                    traffic = tj.get(name, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -283,7 +288,8 @@ def main():
                               "rays_per_launch": krays / launches, "bytes_per_ray": b_ray, "nodes_per_ray": n_nodes, "tris_per_ray": n_tris,
                               "kernel_seconds": {"k_trace": tot["seconds_closest"], "k_nee_combine": tot["seconds_nee"], "k_shade": tot["seconds_shade"]},
                               "note": "algorithmic bytes (SURVEY 8d) / HIP-event kernel time; the 11 MB BVH lives in L2/Infinity Cache, "
-                                      "so measured HBM traffic is far below the algorithmic figure"}
+                                      "so measured HBM traffic is far below the algorithmic figure and frac can pass 1: the kernel is "
+                                      "bound by VALU issue, not by HBM (DESIGN.md section 4)"}
     if args.save_image and rank == 0:
         np.save(args.save_image, acc.cpu().numpy())
     if world == 1 and not args.no_cpu_baseline:
