@@ -353,8 +353,15 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     if (r.npix == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return GNXR_OK; }
     int nsamples = p.spp_end - p.spp_begin;
     int k = p.samples_per_pass;
-    if (k <= 0) {  // auto: about 32M paths in flight (big passes keep the thin late bounces from under-filling the GPU)
-        long long target = whitted ? (4ll << 20) / std::max(1, n_records / 4) : (32ll << 20);   // Whitted keeps max_depth frames and n_records NEE records per path
+    if (k <= 0) {
+        // auto: big passes keep the thin late bounces from under-filling the GPU (bench.py: 32 -> 128 spp per pass at 1080p is
+        // +4 %), so take up to a quarter of the free HBM for path state (~230 B per path), at most 256 M paths; Whitted /
+        // DirectLighting keep max_depth frames and n_records NEE records per path and stay small
+        long long target = 32ll << 20;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) target = std::max<long long>(target, std::min<long long>(256ll << 20, (long long)(free_b / 4 / 230)));
+        if (volpath) target = std::min<long long>(target, 64ll << 20);   // + 8 float4 of VolPath state per path
+        if (whitted) target = (4ll << 20) / std::max(1, n_records / 4);
         k = (int)std::max<long long>(1, std::min<long long>(nsamples, target / r.npix));
     }
     k = std::min(k, nsamples);
