@@ -126,6 +126,26 @@ class SceneBuilder:
     def AddSkyLight(self):                            # ui/ModelList.cpp:163-170
         return _check(lib().gnxr_builder_add_sky_light(self._h))
 
+    def AddSpotLight(self):                           # ui/ModelList.cpp:149-154 (the call is commented out in RenderThread.cpp:138)
+        return _check(lib().gnxr_builder_add_spot_light(self._h))
+
+    def AddDistLight(self):                           # ui/ModelList.cpp:156-161
+        return _check(lib().gnxr_builder_add_dist_light(self._h))
+
+    def add_delta_light(self, kind, I, light_to_world=None, total_width=45.0, falloff_start=30.0, w_light=(0, 0, 1)):
+        """PointLight(LightToWorld, I) / SpotLight(LightToWorld, I, totalWidth, falloffStart) / DistantLight(LightToWorld, L, wLight)."""
+        l = Light()
+        l.type = {"point": _abi.LIGHT_POINT, "spot": _abi.LIGHT_SPOT, "distant": _abi.LIGHT_DISTANT}[kind]
+        l.tri = -1
+        l.n_samples = 1
+        l.le[:] = [float(v) for v in I]
+        l.radius = float(total_width)
+        l.falloff_start = float(falloff_start)
+        l.center[:] = [float(v) for v in w_light]
+        m = np.eye(4, dtype=np.float32) if light_to_world is None else np.asarray(light_to_world, dtype=np.float32).reshape(4, 4)
+        l.light_to_world[:] = [float(v) for v in m.reshape(16)]
+        return _check(lib().gnxr_builder_add_light(self._h, C.byref(l)))
+
     def AddInfLight(self, hdr_path):                  # ui/ModelList.cpp:172-179
         self.hdr_path = str(hdr_path)
         return _check(lib().gnxr_builder_add_inf_light(self._h, os.fsencode(hdr_path)))

@@ -12,7 +12,7 @@ OK, ERR_INVALID, ERR_NO_DEVICE, ERR_OOM, ERR_UNSUPPORTED, ERR_IO = 0, -1, -2, -3
 # gnxr_material_type
 MAT_NONE, MAT_MATTE, MAT_MIRROR, MAT_GLASS, MAT_METAL, MAT_PLASTIC, MAT_DISNEY = range(7)
 # gnxr_light_type
-LIGHT_AREA_TRI, LIGHT_INFINITE, LIGHT_SKYBOX = 1, 2, 3
+LIGHT_AREA_TRI, LIGHT_INFINITE, LIGHT_SKYBOX, LIGHT_POINT, LIGHT_SPOT, LIGHT_DISTANT = 1, 2, 3, 4, 5, 6
 # gnxr_integrator / gnxr_light_strategy
 INTEGRATOR_PATH, INTEGRATOR_VOLPATH, INTEGRATOR_WHITTED, INTEGRATOR_DIRECT = 0, 1, 2, 3
 DIRECT_SAMPLE_ALL, DIRECT_SAMPLE_ONE = 0, 1
@@ -37,7 +37,7 @@ class Material(C.Structure):
 class Light(C.Structure):
     _fields_ = [
         ("type", i32), ("tri", i32), ("two_sided", i32), ("n_samples", i32),
-        ("le", f32 * 3), ("radius", f32), ("center", f32 * 3), ("_pad2", f32), ("light_to_world", f32 * 16),
+        ("le", f32 * 3), ("radius", f32), ("center", f32 * 3), ("falloff_start", f32), ("light_to_world", f32 * 16),
     ]
 
 
@@ -146,6 +146,9 @@ PROTOTYPES = {
     "gnxr_builder_add_inf_light": (C.c_int, [VP, C.c_char_p]),
     "gnxr_builder_add_inf_light_data": (C.c_int, [VP, P(f32), i32, i32, P(f32), P(f32)]),
     "gnxr_builder_add_medium": (C.c_int, [VP, P(Medium), P(f32)]),
+    "gnxr_builder_add_spot_light": (C.c_int, [VP]),
+    "gnxr_builder_add_dist_light": (C.c_int, [VP]),
+    "gnxr_builder_add_light": (C.c_int, [VP, P(Light)]),
     "gnxr_builder_add_texture_data": (C.c_int, [VP, P(Texture), P(f32), i32, i32]),
     "gnxr_builder_add_texture_file": (C.c_int, [VP, P(Texture), C.c_char_p]),
     "gnxr_builder_set_material_texture": (C.c_int, [VP, i32, i32, i32]),

@@ -95,8 +95,11 @@ GX_DEV Spec skybox_Le(const DLight &l, V3 ro, V3 rd) {  // SkyBoxLight.cpp:55-85
     return Spec((q.x + R) / (2.f * R), (q.y + R) / (2.f * R), (q.z + R) / (2.f * R));
 }
 // LT: compile-time mask of the light types a scene holds (bit 0 area triangles, bit 1 InfiniteAreaLight,
-// bit 2 SkyBoxLight); unused types are compiled out of the shade kernels.
-constexpr int LT_AREA = 1, LT_ENV = 2, LT_SKY = 4, LT_ALL = 7;
+// bit 2 SkyBoxLight, bit 3 the delta lights Point / Spot / Distant); unused types are compiled out of the shade kernels.
+constexpr int LT_AREA = 1, LT_ENV = 2, LT_SKY = 4, LT_DELTA = 8, LT_ALL = 15;
+// IsDeltaLight(light.flags), core/Light.h:28-32
+template <int LT>
+GX_DEV bool light_is_delta(const DLight &l) { return (LT & LT_DELTA) && l.type >= GNXR_LIGHT_POINT; }
 
 // Light::Le(ray) for an escaped ray
 template <int LT>
@@ -157,7 +160,37 @@ GX_DEV LightSample light_sample(const DLightTables &t, int li, V3 refP, float u0
         s.p1Error = V3(); s.n1 = V3();
         s.Li = env_lookup(t, d0, d1);
         return s;
-    } else if (LT & LT_SKY) {  // SkyBoxLight::Sample_Li, SkyBoxLight.cpp:43-53: black, pdf 1/4pi
+    } else if ((LT & LT_DELTA) && l.type >= GNXR_LIGHT_POINT) {
+        // PointLight.cpp:13-22, SpotLight.cpp:19-40, DistantLight.cpp:15-25.  DLight reuse: p0 = pLight, n = wLight (world),
+        // radius = worldRadius, area / inv_area = cosTotalWidth / cosFalloffStart, p1 / p2 / center = rows of WorldToLight's 3x3
+        const Spec I(l.le[0], l.le[1], l.le[2]);
+        s.pdf = 1.f;
+        s.p1Error = V3(); s.n1 = V3();
+        if (l.type == GNXR_LIGHT_DISTANT) {
+            V3 w(l.n[0], l.n[1], l.n[2]);
+            s.wi = w;
+            s.p1 = refP + w * (2 * l.radius);
+            s.Li = I;
+        } else {
+            V3 pL(l.p0[0], l.p0[1], l.p0[2]);
+            s.wi = normalize(pL - refP);
+            s.p1 = pL;
+            if (l.type == GNXR_LIGHT_SPOT) {
+                V3 w = -s.wi;
+                V3 wl = normalize(V3(l.p1[0] * w.x + l.p1[1] * w.y + l.p1[2] * w.z, l.p2[0] * w.x + l.p2[1] * w.y + l.p2[2] * w.z,
+                                     l.center[0] * w.x + l.center[1] * w.y + l.center[2] * w.z));
+                float cosTheta = wl.z, falloff;
+                if (cosTheta < l.area) falloff = 0;
+                else if (cosTheta >= l.inv_area) falloff = 1;
+                else {
+                    float delta = (cosTheta - l.area) / (l.inv_area - l.area);
+                    falloff = (delta * delta) * (delta * delta);
+                }
+                s.Li = I * falloff / length_sq(pL - refP);
+            } else s.Li = I / length_sq(pL - refP);
+        }
+        return s;
+    } else if ((LT & LT_SKY) && l.type == GNXR_LIGHT_SKYBOX) {  // SkyBoxLight::Sample_Li, SkyBoxLight.cpp:43-53: black, pdf 1/4pi
         float theta = u1 * GX_PI, phi = u0 * 2 * GX_PI;
         float cosTheta, sinTheta, sinPhi, cosPhi;
         gx_sincos(theta, &sinTheta, &cosTheta);

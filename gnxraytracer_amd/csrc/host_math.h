@@ -60,6 +60,7 @@ inline Xf xinverse(const Xf &a) { return {a.inv, a.m}; }
 Xf translate(Vec3 d);
 Xf scale(float x, float y, float z);
 Xf rotate_x(float deg);
+Xf rotate_axis(float deg, Vec3 axis);
 Xf rotate_y(float deg);
 Xf look_at(Vec3 pos, Vec3 look, Vec3 up);
 Xf perspective(float fov, float n, float f);

@@ -219,12 +219,13 @@ GX_DEV int estimate_direct_record(const DScene &sc, const Bsdf<LM> &bsdf, const 
         if (!f.is_black()) {
             // visibility.Unoccluded(scene): shadow ray p0.SpawnRayTo(p1), Light.cpp:28-31
             spawn_ray_to(sp.p, sp.pError, sp.n, ls.p1, ls.p1Error, ls.n1, &so, &sd);
-            float weight = power_heuristic(ls.pdf, scatteringPdf);
+            // IsDeltaLight: `Ld += f * Li / lightPdf` (:157-158) == the weighted form with weight 1, and no BSDF-sampling half (:168)
+            float weight = light_is_delta<LT>(sc.lt.lights[lightNum]) ? 1.f : power_heuristic(ls.pdf, scatteringPdf);
             X = f * ls.Li * weight / ls.pdf;
             nflags |= 1;
         }
     }
-    {
+    if (!light_is_delta<LT>(sc.lt.lights[lightNum])) {
         int sampledType;
         Spec f = bsdf.sample_f(woN, &wi2, us0, us1, &scatteringPdf, bsdfFlags, &sampledType);
         f = f * absdot(wi2, sp.ns);
@@ -392,12 +393,12 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
                                 if (!f.is_black()) {
                                     // visibility.Unoccluded(scene): shadow ray p0.SpawnRayTo(p1), Light.cpp:28-31
                                     spawn_ray_to(sp.p, sp.pError, sp.n, ls.p1, ls.p1Error, ls.n1, &so, &sd);
-                                    float weight = power_heuristic(ls.pdf, scatteringPdf);
+                                    float weight = light_is_delta<LT>(sc.lt.lights[lightNum]) ? 1.f : power_heuristic(ls.pdf, scatteringPdf);
                                     X = f * ls.Li * weight / ls.pdf;
                                     nflags |= 1;
                                 }
                             }
-                            {
+                            if (!light_is_delta<LT>(sc.lt.lights[lightNum])) {
                                 int sampledType;
                                 Spec f = bsdf.sample_f(woN, &wi2, us0, us1, &scatteringPdf, bsdfFlags, &sampledType);
                                 f = f * absdot(wi2, sp.ns);

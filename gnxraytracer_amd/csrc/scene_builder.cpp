@@ -84,6 +84,26 @@ Xf rotate_y(float theta) {  // Transform.cpp:139-145
     t.inv = transpose(t.m);
     return t;
 }
+Xf rotate_axis(float theta, Vec3 axis) {  // Rotate(theta, axis), Transform.cpp:156-179
+    Vec3 a = normalize(axis);
+    float sinTheta = std::sin(radians(theta)), cosTheta = std::cos(radians(theta));
+    Xf t;
+    Mat4 &m = t.m;
+    m.m[0][0] = a.x * a.x + (1 - a.x * a.x) * cosTheta;
+    m.m[0][1] = a.x * a.y * (1 - cosTheta) - a.z * sinTheta;
+    m.m[0][2] = a.x * a.z * (1 - cosTheta) + a.y * sinTheta;
+    m.m[0][3] = 0;
+    m.m[1][0] = a.x * a.y * (1 - cosTheta) + a.z * sinTheta;
+    m.m[1][1] = a.y * a.y + (1 - a.y * a.y) * cosTheta;
+    m.m[1][2] = a.y * a.z * (1 - cosTheta) - a.x * sinTheta;
+    m.m[1][3] = 0;
+    m.m[2][0] = a.x * a.z * (1 - cosTheta) - a.y * sinTheta;
+    m.m[2][1] = a.y * a.z * (1 - cosTheta) + a.x * sinTheta;
+    m.m[2][2] = a.z * a.z + (1 - a.z * a.z) * cosTheta;
+    m.m[2][3] = 0;
+    t.inv = transpose(t.m);
+    return t;
+}
 Xf look_at(Vec3 pos, Vec3 look, Vec3 up) {  // Transform.cpp:181-215
     Mat4 c2w;
     c2w.m[0][3] = pos.x; c2w.m[1][3] = pos.y; c2w.m[2][3] = pos.z; c2w.m[3][3] = 1;
@@ -506,6 +526,38 @@ int gnxr_builder_add_sky_light(gnxr_builder *b) {
     for (int i = 0; i < 4; ++i) l.light_to_world[5 * i] = 1.f;
     b->b.lights.push_back(l);
     return (int)b->b.lights.size() - 1;
+}
+
+int gnxr_builder_add_light(gnxr_builder *b, const gnxr_light *l) {
+    if (!b || !l) return GNXR_ERR_INVALID;
+    if (l->type != GNXR_LIGHT_POINT && l->type != GNXR_LIGHT_SPOT && l->type != GNXR_LIGHT_DISTANT) { set_error("gnxr_builder_add_light: POINT, SPOT or DISTANT"); return GNXR_ERR_INVALID; }
+    gnxr_light ll = *l;
+    ll.tri = -1;
+    b->b.lights.push_back(ll);
+    return (int)b->b.lights.size() - 1;
+}
+// AddSpotLight, ui/ModelList.cpp:149-154: Translate(0, 2.43, 0) * Rotate(90, (1,0,0)), I = 25, totalWidth 45, falloffStart 30
+int gnxr_builder_add_spot_light(gnxr_builder *b) {
+    if (!b) return GNXR_ERR_INVALID;
+    gnxr_light l;
+    memset(&l, 0, sizeof(l));
+    l.type = GNXR_LIGHT_SPOT; l.tri = -1; l.n_samples = 1;
+    l.le[0] = l.le[1] = l.le[2] = 25.0f;
+    l.radius = 45.f; l.falloff_start = 30.f;
+    Xf t = xmul(translate(Vec3(0.0f, 2.43f, 0.0f)), rotate_axis(90.f, Vec3(1.0f, 0.0f, 0.0f)));
+    memcpy(l.light_to_world, &t.m.m[0][0], 64);
+    return gnxr_builder_add_light(b, &l);
+}
+// AddDistLight, ui/ModelList.cpp:156-161: identity, L = 25, wLight = (0, 0, 1)
+int gnxr_builder_add_dist_light(gnxr_builder *b) {
+    if (!b) return GNXR_ERR_INVALID;
+    gnxr_light l;
+    memset(&l, 0, sizeof(l));
+    l.type = GNXR_LIGHT_DISTANT; l.tri = -1; l.n_samples = 1;
+    l.le[0] = l.le[1] = l.le[2] = 25.0f;
+    l.center[2] = 1.f;
+    for (int i = 0; i < 4; ++i) l.light_to_world[5 * i] = 1.f;
+    return gnxr_builder_add_light(b, &l);
 }
 
 int gnxr_builder_add_inf_light_data(gnxr_builder *b, const float *rgb, int32_t w, int32_t h, const float *l2w16, const float power[3]) {

@@ -914,6 +914,23 @@ bool compile_scene(const gnxr_scene_desc *d, CompiledScene *cs) {
             memcpy(dl.center, l.center, 12);
             dl.radius = l.radius;
             cs->infinite_lights.push_back(i);
+        } else if (l.type == GNXR_LIGHT_POINT || l.type == GNXR_LIGHT_SPOT || l.type == GNXR_LIGHT_DISTANT) {
+            // lights/PointLight.cpp, SpotLight.cpp, DistantLight.cpp (field reuse: device_lights.h light_sample)
+            Mat4 l2w, w2l;
+            memcpy(&l2w.m[0][0], l.light_to_world, 64);
+            w2l = inverse(l2w);                                             // Transform(const Matrix4x4 &): mInv = Inverse(m)
+            Vec3 pL = xform_point(l2w, Vec3(0, 0, 0));
+            memcpy(dl.p0, &pL, 12);
+            for (int c = 0; c < 3; ++c) { dl.p1[c] = w2l.m[0][c]; dl.p2[c] = w2l.m[1][c]; dl.center[c] = w2l.m[2][c]; }
+            dl.area = std::cos((kPi / 180) * l.radius);                     // cosTotalWidth
+            dl.inv_area = std::cos((kPi / 180) * l.falloff_start);          // cosFalloffStart
+            Vec3 w = normalize(xform_vector(l2w, Vec3(l.center[0], l.center[1], l.center[2])));
+            memcpy(dl.n, &w, 12);
+            // DistantLight::Preprocess: scene.WorldBound().BoundingSphere (Geometry.h:770-773)
+            Vec3 c = (cs->world_bound.lo + cs->world_bound.hi) / 2;
+            const Box3 &wb = cs->world_bound;
+            bool inside = c.x >= wb.lo.x && c.x <= wb.hi.x && c.y >= wb.lo.y && c.y <= wb.hi.y && c.z >= wb.lo.z && c.z <= wb.hi.z;
+            dl.radius = inside ? length(c - wb.hi) : 0.f;
         } else { set_error("light %d: unknown type %d", i, l.type); return false; }
     }
     // ---- media
@@ -1037,6 +1054,26 @@ static float light_contrib(const CompiledScene &cs, int j, Vec3 ref, float u0, f
                      ds * dt * texel(s0 + 1, t0 + 1, c);
         float y = 0.212671f * rgb[0] + 0.715160f * rgb[1] + 0.072169f * rgb[2];
         return pdf > 0 ? y / pdf : 0;
+    } else if (l.type == GNXR_LIGHT_POINT || l.type == GNXR_LIGHT_SPOT || l.type == GNXR_LIGHT_DISTANT) {   // pdf = 1
+        float rgb[3] = {l.le[0], l.le[1], l.le[2]};
+        if (l.type != GNXR_LIGHT_DISTANT) {
+            Vec3 pL(l.p0[0], l.p0[1], l.p0[2]);
+            Vec3 wi = normalize(pL - ref);
+            Vec3 dd = pL - ref;
+            float d2 = dot(dd, dd), falloff = 1;
+            if (l.type == GNXR_LIGHT_SPOT) {   // SpotLight::Falloff(-wi)
+                Vec3 w(-wi.x, -wi.y, -wi.z);
+                Vec3 wl = normalize(Vec3(l.p1[0] * w.x + l.p1[1] * w.y + l.p1[2] * w.z, l.p2[0] * w.x + l.p2[1] * w.y + l.p2[2] * w.z,
+                                         l.center[0] * w.x + l.center[1] * w.y + l.center[2] * w.z));
+                float cosTheta = wl.z;
+                if (cosTheta < l.area) falloff = 0;
+                else if (cosTheta >= l.inv_area) falloff = 1;
+                else { float delta = (cosTheta - l.area) / (l.inv_area - l.area); falloff = (delta * delta) * (delta * delta); }
+                for (int c = 0; c < 3; ++c) rgb[c] = rgb[c] * falloff / d2;
+            } else for (int c = 0; c < 3; ++c) rgb[c] = rgb[c] / d2;
+        }
+        float y = 0.212671f * rgb[0] + 0.715160f * rgb[1] + 0.072169f * rgb[2];
+        return y / 1.f;
     } else {  // SKYBOX: Li = 0, pdf = 1/4pi
         return 0.f / (1.f / (4 * kPi));
     }
@@ -1079,6 +1116,13 @@ void build_light_grid(const CompiledScene &cs, int strategy, DLightGrid *grid, s
             } else if (l.type == GNXR_LIGHT_INFINITE && cs.has_env) {   // InfiniteAreaLight::Power, InfiniteAreaLight.cpp:84-89
                 float k = kPi * cs.env.world_radius * cs.env.world_radius;
                 float rgb[3] = {k * cs.env_power_lookup[0], k * cs.env_power_lookup[1], k * cs.env_power_lookup[2]};
+                power[i] = 0.212671f * rgb[0] + 0.715160f * rgb[1] + 0.072169f * rgb[2];
+            } else if (l.type == GNXR_LIGHT_POINT || l.type == GNXR_LIGHT_SPOT || l.type == GNXR_LIGHT_DISTANT) {
+                float rgb[3];
+                for (int c = 0; c < 3; ++c)
+                    rgb[c] = l.type == GNXR_LIGHT_POINT ? 4 * kPi * l.le[c]                                         // PointLight.cpp:24
+                           : l.type == GNXR_LIGHT_SPOT ? l.le[c] * 2 * kPi * (1 - .5f * (l.inv_area + l.area))      // SpotLight.cpp:42-45
+                                                       : l.le[c] * kPi * l.radius * l.radius;                       // DistantLight.cpp:27-30
                 power[i] = 0.212671f * rgb[0] + 0.715160f * rgb[1] + 0.072169f * rgb[2];
             } else power[i] = 0;  // SkyBoxLight::Power() = 0
         }

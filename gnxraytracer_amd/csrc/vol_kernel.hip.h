@@ -486,11 +486,11 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
                     if (!fX.is_black()) {
                         spawn_ray_to(itP, itPError, itN, ls.p1, ls.p1Error, ls.n1, &so, &sd);
                         shMedium = dot(sd, itN) > 0 ? medOut : medIn;
-                        weightX = power_heuristic(ls.pdf, scatteringPdf);
+                        weightX = light_is_delta<LT>(sc.lt.lights[lightNum]) ? 1.f : power_heuristic(ls.pdf, scatteringPdf);   // IsDeltaLight: no MIS weight
                         nflags |= 1;
                     }
                 }
-                {
+                if (!light_is_delta<LT>(sc.lt.lights[lightNum])) {   // ... and no scattering-sample half (Integrator.cpp:168)
                     Spec f2;
                     bool sampledSpecular = false;
                     if (isMedium) {

@@ -119,7 +119,13 @@ typedef struct gnxr_texture {
 typedef enum gnxr_light_type {
     GNXR_LIGHT_AREA_TRI = 1, /* one DiffuseAreaLight per emissive triangle, ModelList.cpp:140-146 */
     GNXR_LIGHT_INFINITE = 2, /* InfiniteAreaLight.cpp:12-132, uses desc.env_*                    */
-    GNXR_LIGHT_SKYBOX = 3    /* SkyBoxLight.cpp:43-85 with a failed image load (gradient)        */
+    GNXR_LIGHT_SKYBOX = 3,   /* SkyBoxLight.cpp:43-85 with a failed image load (gradient)        */
+    /* delta lights (LightFlags::DeltaPosition / DeltaDirection): EstimateDirect takes its IsDeltaLight branch, core/Integrator.cpp:
+     * 157-158, 168.  The reference authors a spot and a distant light (AddSpotLight / AddDistLight, ui/ModelList.cpp:149-161) but
+     * leaves the calls commented out (ui/RenderThread.cpp:138-141).                                                            */
+    GNXR_LIGHT_POINT = 4,    /* lights/PointLight.cpp: le = I, position = light_to_world * (0,0,0)                              */
+    GNXR_LIGHT_SPOT = 5,     /* lights/SpotLight.cpp: le = I, radius = totalWidth (degrees), falloff_start (degrees), axis +z   */
+    GNXR_LIGHT_DISTANT = 6   /* lights/DistantLight.cpp: le = L, center = wLight in light space (Normalize(LightToWorld(w)))    */
 } gnxr_light_type;
 
 typedef struct gnxr_light {
@@ -129,8 +135,8 @@ typedef struct gnxr_light {
     int32_t n_samples;  /* Light::nSamples (core/Light.cpp:19: max(1, n)); used by UniformSampleAllLights only */
     float le[3];        /* AREA_TRI: Lemit ; INFINITE: power scale L                      */
     float radius;       /* SKYBOX: sphere radius                                          */
-    float center[3];    /* SKYBOX: sphere centre                                          */
-    float _pad2;
+    float center[3];    /* SKYBOX: sphere centre ; DISTANT: wLight                        */
+    float falloff_start;/* SPOT: falloffStart in degrees (radius carries totalWidth)      */
     float light_to_world[16]; /* INFINITE: row-major 4x4 (LightToWorld, ModelList.cpp:174) */
 } gnxr_light;
 
@@ -360,6 +366,9 @@ int gnxr_builder_add_cornell(gnxr_builder *b, int32_t material1, int32_t materia
 int gnxr_builder_add_floor(gnxr_builder *b, int32_t material);                        /* ModelList.cpp:20-45  */
 int gnxr_builder_add_area_light(gnxr_builder *b, int32_t material);                   /* ModelList.cpp:120-147 */
 int gnxr_builder_add_sky_light(gnxr_builder *b);                                      /* ModelList.cpp:163-170 */
+int gnxr_builder_add_spot_light(gnxr_builder *b);                                     /* AddSpotLight, ModelList.cpp:149-154 */
+int gnxr_builder_add_dist_light(gnxr_builder *b);                                     /* AddDistLight, ModelList.cpp:156-161 */
+int gnxr_builder_add_light(gnxr_builder *b, const gnxr_light *l);                     /* POINT / SPOT / DISTANT with caller-chosen parameters */
 int gnxr_builder_add_inf_light(gnxr_builder *b, const char *hdr_path);                /* ModelList.cpp:172-179 */
 int gnxr_builder_add_inf_light_data(gnxr_builder *b, const float *rgb, int32_t w, int32_t h,
                                     const float *light_to_world16, const float power[3]);

@@ -230,6 +230,7 @@ def main():
     save("render_whitted.npz", **wh)
     direct_goldens(cornell_path, zoo_path)
     texture_goldens()
+    delta_goldens()
     # cfg 2 at full size: the counts the survey recorded from the COMPLETE reference
     img, cnt = render(cornell_path, 256, 256, 64)
     checksum = float(img[..., :3].astype(np.float64).sum())
@@ -333,10 +334,36 @@ def texture_goldens():
     save("render_smooth.npz", **out)
 
 
+def delta_goldens():
+    # ---- 15: delta lights (Point / Spot / Distant) through every integrator and every light-selection strategy
+    b = scenes.delta_cornell()
+    path = scene_file(b, "delta")
+    out = {}
+    W, H, spp, depth = 64, 56, 8, 5
+    for name, integ, args in [("path_spatial", gx.PathIntegrator(depth, 1.0, "spatial"), [0, 0, 0]), ("path_power", gx.PathIntegrator(depth, 1.0, "power"), [2, 0, 0]),
+                              ("path_uniform", gx.PathIntegrator(depth, 1.0, "uniform"), [1, 0, 0]), ("whitted", gx.WhittedIntegrator(depth), [0, 0, 2]),
+                              ("direct_all", gx.DirectLightingIntegrator("all", depth), [0, 0, 3, 0]), ("direct_one", gx.DirectLightingIntegrator("one", depth), [0, 0, 3, 1]),
+                              ("volpath", gx.VolPathIntegrator(depth, 1.0, "spatial"), [0, 0, 1])]:
+        raw = ol.run_ref(path, "render", None, [W, H, spp, depth, 1.0] + args)
+        out[name] = np.frombuffer(raw[:W * H * 16], np.float32).reshape(H, W, 4).copy()
+        out[name + "_rays"] = np.frombuffer(raw[W * H * 16:W * H * 16 + 16], np.uint64).copy()
+        ol.olib().gnxo_max_dimension(1)
+        oimg, st = ol.OracleScene(b).render(integ, W, H, spp)
+        maxdim = ol.olib().gnxo_max_dimension(1)
+        same = oimg.view(np.uint32) == out[name].view(np.uint32)
+        print("delta", name, "rays", out[name + "_rays"], (st["rays_closest"], st["rays_any"]), "max dimension", maxdim, "identical %.3f%%" % (100 * same.mean()),
+              "maxabs", float(np.abs(oimg - out[name]).max()))
+        assert maxdim < 1000 and same.all()
+    out["cfg"] = np.array([W, H, spp, depth], np.int32)
+    save("render_delta.npz", **out)
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["direct"]:   # only section 13
         direct_goldens(scene_file(scenes.cornell(), "cornell"), scene_file(scenes.material_zoo(), "zoo"))
     elif sys.argv[1:] == ["textured"]:   # only section 14
         texture_goldens()
+    elif sys.argv[1:] == ["delta"]:      # only section 15
+        delta_goldens()
     else:
         main()

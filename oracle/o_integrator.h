@@ -35,7 +35,27 @@ struct RenderContext {
     mutable std::vector<std::atomic<int>> voxelState;                    // 0 empty, 1 building, 2 ready
     Bounds3 worldBound;
 
-    bool IsDeltaLight(int) const { return false; }  // only Area / Infinite lights on this path
+    // delta lights: lights/PointLight.cpp, lights/SpotLight.cpp, lights/DistantLight.cpp
+    struct DeltaLight {
+        V3 pLight;                    // Point / Spot: LightToWorld(Point3f(0, 0, 0))
+        M44 worldToLight;             // Spot::Falloff
+        Float cosTotalWidth = 0, cosFalloffStart = 0;
+        V3 wLight;                    // Distant: Normalize(LightToWorld(wLight))
+        Float worldRadius = 0;        // Distant::Preprocess
+    };
+    std::vector<DeltaLight> deltaLights;   // per light index (unused entries for the other types)
+    static bool IsDeltaType(int type) { return type == GNXR_LIGHT_POINT || type == GNXR_LIGHT_SPOT || type == GNXR_LIGHT_DISTANT; }
+    // IsDeltaLight(flags), core/Light.h:28-32
+    bool IsDeltaLight(int light) const { return IsDeltaType(scene->lights[light].type); }
+    // SpotLight::Falloff, SpotLight.cpp:30-40
+    Float SpotFalloff(const DeltaLight &d, const V3 &w) const {
+        V3 wl = Normalize(XVector(d.worldToLight, w));
+        Float cosTheta = wl.z;
+        if (cosTheta < d.cosTotalWidth) return 0;
+        if (cosTheta >= d.cosFalloffStart) return 1;
+        Float delta = (cosTheta - d.cosTotalWidth) / (d.cosFalloffStart - d.cosTotalWidth);
+        return (delta * delta) * (delta * delta);
+    }
 
     // DiffuseAreaLight::L, DiffuseAreaLight.h:22-27.  `bool dotNW = Dot(intr.n, w)` truncates the dot
     // product to bool, so the light emits from both faces whenever the dot product is non-zero.
@@ -69,6 +89,22 @@ struct RenderContext {
             return s;
         } else if (l.type == GNXR_LIGHT_INFINITE) {
             return envLights[light]->Sample_Li(ref, u);
+        } else if (IsDeltaType(l.type)) {
+            const DeltaLight &d = deltaLights[light];
+            const Spec I(l.le[0], l.le[1], l.le[2]);
+            s.pdf = 1.f;
+            s.p1 = Interaction();   // Interaction(p, time, mediumInterface): n = pError = 0
+            if (l.type == GNXR_LIGHT_DISTANT) {          // DistantLight.cpp:15-25
+                s.wi = d.wLight;
+                s.p1.p = ref.p + d.wLight * (2 * d.worldRadius);
+                s.Li = I;
+            } else {                                     // PointLight.cpp:13-22, SpotLight.cpp:19-28
+                s.wi = Normalize(d.pLight - ref.p);
+                s.p1.p = d.pLight;
+                if (l.type == GNXR_LIGHT_SPOT) s.Li = I * SpotFalloff(d, -s.wi) / DistanceSquared(d.pLight, ref.p);
+                else s.Li = I / DistanceSquared(d.pLight, ref.p);
+            }
+            return s;
         } else {  // SkyBoxLight::Sample_Li, SkyBoxLight.cpp:43-53
             return SkyBoxSample_Li(l, ref, u);
         }
@@ -87,6 +123,11 @@ struct RenderContext {
             return P.y();
         }
         if (l.type == GNXR_LIGHT_INFINITE) return envLights[light]->Power().y();
+        const Spec I(l.le[0], l.le[1], l.le[2]);
+        if (l.type == GNXR_LIGHT_POINT) return (4 * Pi * I).y();                                       // PointLight.cpp:24
+        if (l.type == GNXR_LIGHT_SPOT)                                                                  // SpotLight.cpp:42-45
+            return (I * 2 * Pi * (1 - .5f * (deltaLights[light].cosFalloffStart + deltaLights[light].cosTotalWidth))).y();
+        if (l.type == GNXR_LIGHT_DISTANT) return (I * Pi * deltaLights[light].worldRadius * deltaLights[light].worldRadius).y();   // DistantLight.cpp:27-30
         return 0;
     }
 
@@ -97,11 +138,24 @@ struct RenderContext {
         lightTri.assign(nl, -1);
         lightArea.assign(nl, 0);
         envLights.resize(nl);
+        deltaLights.assign(nl, DeltaLight());
         worldBound = s->WorldBound();
         for (int i = 0; i < nl; ++i) {
             const gnxr_light &l = s->lights[i];
             if (l.type == GNXR_LIGHT_AREA_TRI) { lightTri[i] = l.tri; lightArea[i] = s->TriArea(l.tri); }
-            else {
+            else if (IsDeltaType(l.type)) {
+                DeltaLight &d = deltaLights[i];
+                M44 l2w = M44::FromRowMajor(l.light_to_world);
+                d.worldToLight = Inverse(l2w);
+                d.pLight = XPoint(l2w, V3(0, 0, 0));
+                d.cosTotalWidth = std::cos(Radians(l.radius));
+                d.cosFalloffStart = std::cos(Radians(l.falloff_start));
+                d.wLight = Normalize(XVector(l2w, V3(l.center[0], l.center[1], l.center[2])));
+                V3 c = (worldBound.pMin + worldBound.pMax) / 2;   // Preprocess: scene.WorldBound().BoundingSphere, Geometry.h:770-773
+                bool inside = c.x >= worldBound.pMin.x && c.x <= worldBound.pMax.x && c.y >= worldBound.pMin.y && c.y <= worldBound.pMax.y &&
+                              c.z >= worldBound.pMin.z && c.z <= worldBound.pMax.z;
+                d.worldRadius = inside ? (c - worldBound.pMax).Length() : 0;
+            } else {
                 infiniteLights.push_back(i);
                 if (l.type == GNXR_LIGHT_INFINITE) {
                     bool flipY = false;  // a SkyBoxLight built earlier switched stb_image to flipped loading

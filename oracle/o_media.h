@@ -223,12 +223,15 @@ inline Spec EstimateDirectMedia(const VolContext &vc, const Interaction &it, con
         if (!f.IsBlack()) {
             Li *= VisibilityTr(vc, it, ls.p1, sampler);
             if (!Li.IsBlack()) {
-                Float weight = PowerHeuristic(1, lightPdf, 1, scatteringPdf);
-                Ld += f * Li * weight / lightPdf;
+                if (rc.IsDeltaLight(light)) Ld += f * Li / lightPdf;
+                else {
+                    Float weight = PowerHeuristic(1, lightPdf, 1, scatteringPdf);
+                    Ld += f * Li * weight / lightPdf;
+                }
             }
         }
     }
-    {
+    if (!rc.IsDeltaLight(light)) {
         Spec f;
         bool sampledSpecular = false;
         if (isect) {

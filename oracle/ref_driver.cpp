@@ -48,6 +48,9 @@
 #include "shape/Triangle.h"
 #include "textures/ConstantTexture.h"
 #include "textures/ImageTexture.h"
+#include "lights/PointLight.h"
+#include "lights/SpotLight.h"
+#include "lights/DistantLight.h"
 
 #include "include/gnxr.h"
 
@@ -232,6 +235,13 @@ struct RefScene {
                 lights[i] = std::make_shared<InfiniteAreaLight>(Transform(m), S3(l.le), l.n_samples, sf.hdrPath);
             } else if (l.type == GNXR_LIGHT_SKYBOX) {
                 lights[i] = std::make_shared<SkyBoxLight>(Transform(), Point3f(l.center[0], l.center[1], l.center[2]), l.radius, "1", l.n_samples);
+            } else if (l.type == GNXR_LIGHT_POINT || l.type == GNXR_LIGHT_SPOT || l.type == GNXR_LIGHT_DISTANT) {
+                Matrix4x4 m;
+                memcpy(m.m, l.light_to_world, 64);
+                Transform l2w(m);   // Transform(const Matrix4x4 &) computes the inverse itself
+                if (l.type == GNXR_LIGHT_POINT) lights[i] = std::make_shared<PointLight>(l2w, MediumInterface(), S3(l.le));
+                else if (l.type == GNXR_LIGHT_SPOT) lights[i] = std::make_shared<SpotLight>(l2w, MediumInterface(), S3(l.le), l.radius, l.falloff_start);
+                else lights[i] = std::make_shared<DistantLight>(l2w, S3(l.le), Vector3f(l.center[0], l.center[1], l.center[2]));
             }
         }
         bvh = std::make_shared<BVHAccel>(prims, 1);
@@ -459,8 +469,11 @@ Spectrum refEstimateDirectMedia(const Interaction &it, const Point2f &uScatterin
         if (!f.IsBlack()) {
             Li *= visibility.Tr(scene, sampler);
             if (!Li.IsBlack()) {
-                Float weight = PowerHeuristic(1, lightPdf, 1, scatteringPdf);
-                Ld += f * Li * weight / lightPdf;
+                if (IsDeltaLight(light.flags)) Ld += f * Li / lightPdf;
+                else {
+                    Float weight = PowerHeuristic(1, lightPdf, 1, scatteringPdf);
+                    Ld += f * Li * weight / lightPdf;
+                }
             }
         }
     }
@@ -678,7 +691,8 @@ Spectrum refDirectLi(const RayDifferential &ray, const Scene &scene, Sampler &sa
     Vector3f wo = isect.wo;
     L += isect.Le(wo);
     if (scene.lights.size() > 0) {
-        if (strategy == 0) {   // UniformSampleAllLights
+        if (strategy == 0) {   // L += UniformSampleAllLights(...): the lights are summed in the callee's own L first (core/Integrator.cpp:31-54)
+            Spectrum Lall(0.f);
             for (size_t j = 0; j < scene.lights.size(); ++j) {
                 const std::shared_ptr<Light> &light = scene.lights[j];
                 int nSamples = nLightSamples[j];
@@ -687,13 +701,14 @@ Spectrum refDirectLi(const RayDifferential &ray, const Scene &scene, Sampler &sa
                 if (!uLightArray || !uScatteringArray) {
                     Point2f uLight = sampler.Get2D();
                     Point2f uScattering = sampler.Get2D();
-                    L += refEstimateDirect(isect, uScattering, *light, uLight, scene);
+                    Lall += refEstimateDirect(isect, uScattering, *light, uLight, scene);
                 } else {
                     Spectrum Ld(0.f);
                     for (int k = 0; k < nSamples; ++k) Ld += refEstimateDirect(isect, uScatteringArray[k], *light, uLightArray[k], scene);
-                    L += Ld / nSamples;
+                    Lall += Ld / nSamples;
                 }
             }
+            L += Lall;
         } else {               // UniformSampleOneLight, lightDistrib == nullptr
             int nLights = int(scene.lights.size());
             int lightNum = std::min((int)(sampler.Get1D() * nLights), nLights - 1);

@@ -19,6 +19,7 @@ SCENES = {
     "vol_textured": lambda: scenes.textured_cornell(os.path.join(GOLDEN, "tex_smile_96x80.hdr")),
     "smooth": lambda: scenes.smooth_cornell(os.path.join(GOLDEN, "tex_smile_96x80.hdr")),
     "vol_smooth": lambda: scenes.smooth_cornell(os.path.join(GOLDEN, "tex_smile_96x80.hdr")),
+    "delta": scenes.delta_cornell, "vol_delta": scenes.delta_cornell,
     "textured_uv": lambda: scenes.textured_cornell(os.path.join(GOLDEN, "tex_smile_96x80.hdr"), uv_quads=True),
     "no_lights": scenes.cornell_no_lights, "vol_fog": scenes.cornell_in_fog, "vol_no_lights": scenes.cornell_no_lights,
 }

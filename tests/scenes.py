@@ -338,3 +338,25 @@ def smooth_cornell(tex_path, medium_ball=True):
         b.add_mesh(v, t, -1, medium_inside=med, medium_outside=-1, normals=n)
     b.AddAreaLight(white)
     return b
+
+
+def delta_cornell(medium_ball=True):
+    """Delta lights (EstimateDirect's IsDeltaLight branch, core/Integrator.cpp:157-158, 168): the reference's AddSpotLight and
+    AddDistLight (ui/ModelList.cpp:149-161; their calls are commented out in RenderThread.cpp:138-141) plus a PointLight, next to the
+    area light, in the material zoo -- and a HomogeneousMedium ball so that VolPath's handleMedia = true variant takes the branch too."""
+    b = material_zoo()
+    b.AddSpotLight()
+    b.AddDistLight()
+    b.add_delta_light("point", (6.0, 4.0, 2.5), light_to_world=[[1, 0, 0, -1.2], [0, 1, 0, -0.4], [0, 0, 1, 1.1], [0, 0, 0, 1]])
+    b.add_delta_light("spot", (30.0, 30.0, 40.0), total_width=35.0, falloff_start=10.0,
+                      light_to_world=[[0.8, 0, 0.6, 1.9], [0, 1, 0, 1.7], [-0.6, 0, 0.8, 2.0], [0, 0, 0, 1]])
+    if medium_ball:
+        hom = gx.Medium()
+        hom.type = gx._abi.MEDIUM_HOMOGENEOUS
+        hom.sigma_a[:] = (0.3, 0.4, 0.6)
+        hom.sigma_s[:] = (1.2, 1.0, 0.7)
+        hom.g = 0.2
+        med = b.add_medium(hom)
+        v, t, uv, n = uv_sphere_mesh((0.2, -1.4, 0.9), 0.7, 6, 8)
+        b.add_mesh(v, t, -1, medium_inside=med, medium_outside=-1)
+    return b

@@ -393,6 +393,24 @@ def test_per_vertex_normals_match_reference(gpu, name):
         gh, oh = scene.Intersect(rays), ol.OracleScene(b).Intersect(rays)
         assert (gh["prim"] == oh["prim"]).all() and biteq(gh["t"], oh["t"]) and biteq(gh["n"], oh["n"])
 
+@pytest.mark.parametrize("name", ["path_spatial", "path_power", "path_uniform", "whitted", "direct_all", "direct_one", "volpath"])
+def test_delta_lights_match_reference(gpu, name):
+    """Point / Spot / Distant lights on the device (device_lights.h light_sample<LT_DELTA>, the IsDeltaLight branches of the three
+    EstimateDirect restatements, Power and the device-built spatial light grid): golden images of the reference's light classes."""
+    g = golden("render_delta.npz")
+    W, H, spp, depth = (int(v) for v in g["cfg"])
+    integ = {"path_spatial": lambda: gpu.PathIntegrator(depth, 1.0, "spatial"), "path_power": lambda: gpu.PathIntegrator(depth, 1.0, "power"),
+             "path_uniform": lambda: gpu.PathIntegrator(depth, 1.0, "uniform"), "whitted": lambda: gpu.WhittedIntegrator(depth),
+             "direct_all": lambda: gpu.DirectLightingIntegrator("all", depth), "direct_one": lambda: gpu.DirectLightingIntegrator("one", depth),
+             "volpath": lambda: gpu.VolPathIntegrator(depth, 1.0, "spatial")}[name]()
+    scene = gpu.Scene(scenes.delta_cornell())
+    img, st = integ.Render(scene, W, H, spp)
+    assert (st["rays_closest"], st["rays_any"]) == tuple(int(v) for v in g[name + "_rays"])
+    assert biteq(img[..., :3], g[name][..., :3])
+    if name == "path_spatial":   # the light grid built on the device equals the host restatement, delta lights included
+        dev, host = scene.light_grid_table("spatial", on_host=False), scene.light_grid_table("spatial", on_host=True)
+        assert biteq(dev, host)
+
 
 @pytest.mark.parametrize("kind", ["matte", "mirror", "glass", "medium"])
 def test_sphere_matches_oracle(gpu, kind):

@@ -225,6 +225,28 @@ def test_smooth_normal_images(name, gx):
     assert (st["rays_closest"], st["rays_any"]) == tuple(int(v) for v in g[name + "_rays"])
     assert biteq(img, g[name])
 
+DELTA_CASES = ["path_spatial", "path_power", "path_uniform", "whitted", "direct_all", "direct_one", "volpath"]
+
+
+def _delta_integrator(gx, name, depth):
+    return {"path_spatial": lambda: gx.PathIntegrator(depth, 1.0, "spatial"), "path_power": lambda: gx.PathIntegrator(depth, 1.0, "power"),
+            "path_uniform": lambda: gx.PathIntegrator(depth, 1.0, "uniform"), "whitted": lambda: gx.WhittedIntegrator(depth),
+            "direct_all": lambda: gx.DirectLightingIntegrator("all", depth), "direct_one": lambda: gx.DirectLightingIntegrator("one", depth),
+            "volpath": lambda: gx.VolPathIntegrator(depth, 1.0, "spatial")}[name]()
+
+
+@pytest.mark.parametrize("name", DELTA_CASES)
+def test_delta_light_images(name, gx):
+    """PointLight / SpotLight / DistantLight (the reference's AddSpotLight / AddDistLight, ui/ModelList.cpp:149-161, plus a point
+    light): Sample_Li, Power, DistantLight::Preprocess, the IsDeltaLight branches of EstimateDirect with and without media, the
+    spatial / power / uniform light distributions over a mix of delta and area lights.  Images and ray counts of the reference's own
+    light classes under the restated integrators."""
+    g = golden("render_delta.npz")
+    W, H, spp, depth = (int(v) for v in g["cfg"])
+    img, st = ol.OracleScene(scenes.delta_cornell()).render(_delta_integrator(gx, name, depth), W, H, spp)
+    assert (st["rays_closest"], st["rays_any"]) == tuple(int(v) for v in g[name + "_rays"])
+    assert biteq(img, g[name])
+
 
 def test_cfg2_reproduces_the_recorded_reference_run(gx):
     """the complete reference traced 16 058 662 closest-hit and 12 329 468 any-hit rays
