@@ -2,7 +2,8 @@
  * of libgnxr.so (include/gnxr.h) instead of the pbr:: classes.
  *
  *   scene      materials of RenderThread.cpp:79-103, AddModel (a .3d mesh, ModelList.cpp:47-69; optional), AddCornell
- *              (:71-118), AddAreaLight (:120-147), AddSkyLight (:163-170; --sky), camera of RenderThread.cpp:60-68
+ *              (:71-118), AddAreaLight (:120-147), AddSpotLight / AddDistLight (:149-161; --spot / --dist), AddSkyLight (:163-170;
+ *              --sky), camera of RenderThread.cpp:60-68
  *   integrator WhittedIntegrator(5, ...) as RenderThread.cpp:163 instantiates it, or --integrator path|volpath|direct
  *   loop       `while (renderFlag) { integrator->Render(...); emit PaintBuffer(getUCbuffer()) }` (:168-186) for --frames
  *              iterations: every Render() result is folded into the running mean and tone-mapped to RGBA8 as
@@ -20,7 +21,7 @@
 static void usage(const char *argv0) {
     fprintf(stderr,
             "usage: %s [--width W] [--height H] [--spp N] [--frames F] [--depth D] [--integrator whitted|path|volpath|direct]\n"
-            "          [--model mesh.3d] [--model-material matte|plastic|metal|glass] [--sky] [--device I] --out image.png\n"
+            "          [--model mesh.3d] [--model-material matte|plastic|metal|glass] [--sky] [--spot] [--dist] [--device I] --out image.png\n"
             "renders the reference's default scene (ui/RenderThread.cpp) through libgnxr.so\n",
             argv0);
 }
@@ -34,7 +35,7 @@ static void usage(const char *argv0) {
     } while (0)
 
 int main(int argc, char **argv) {
-    int width = 500, height = 500, spp = 32, frames = 1, depth = 5, device = 0, sky = 0;   /* WIDTH / HEIGHT, HaltonSampler(32), Whitted(5) */
+    int width = 500, height = 500, spp = 32, frames = 1, depth = 5, device = 0, sky = 0, spot = 0, dist = 0;   /* WIDTH / HEIGHT, HaltonSampler(32), Whitted(5) */
     const char *integrator = "whitted", *model = NULL, *model_material = "matte", *out = NULL;
     for (int i = 1; i < argc; ++i) {
         const char *a = argv[i];
@@ -50,6 +51,8 @@ int main(int argc, char **argv) {
         else if (ARG("--model-material")) model_material = argv[++i];
         else if (ARG("--out")) out = argv[++i];
         else if (!strcmp(a, "--sky")) sky = 1;
+        else if (!strcmp(a, "--spot")) spot = 1;   /* AddSpotLight, commented out at RenderThread.cpp:138 */
+        else if (!strcmp(a, "--dist")) dist = 1;   /* AddDistLight, RenderThread.cpp:141 */
         else { usage(argv[0]); return !strcmp(a, "--help") || !strcmp(a, "-h") ? 0 : 2; }
 #undef ARG
     }
@@ -80,6 +83,8 @@ int main(int argc, char **argv) {
     if (model) CHECK(gnxr_builder_add_model_3d(b, model, m_dragon));
     CHECK(gnxr_builder_add_cornell(b, m_red, m_blue, m_white));
     CHECK(gnxr_builder_add_area_light(b, m_dragon));   /* the reference hands the light quad the dragon material (:133) */
+    if (spot) CHECK(gnxr_builder_add_spot_light(b));
+    if (dist) CHECK(gnxr_builder_add_dist_light(b));
     if (sky) CHECK(gnxr_builder_add_sky_light(b));
     gnxr_scene_desc desc;
     CHECK(gnxr_builder_desc(b, &desc));
