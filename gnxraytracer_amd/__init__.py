@@ -220,8 +220,10 @@ class SceneBuilder:
         c = (C.c_float * 3)(*[float(v) for v in center])
         return _check(lib().gnxr_builder_add_sphere(self._h, c, float(radius), int(material), int(medium_inside), int(medium_outside)))
 
-    def set_camera(self, eye=(0, 0, 5), look=(0, 0, 0), up=(0, 1, 0), fov=90.0, lens_radius=0.0, focal_distance=3.0):
-        cam = Camera(_f3(eye), _f3(look), _f3(up), fov, lens_radius, focal_distance)
+    def set_camera(self, eye=(0, 0, 5), look=(0, 0, 0), up=(0, 1, 0), fov=90.0, lens_radius=0.0, focal_distance=3.0, orthographic=False):
+        """CreatePerspectiveCamera (camera/Perspective.cpp:114-135) or, orthographic=True, CreateOrthographicCamera
+        (camera/Orthographic.cpp:94-121) on LookAt(eye, look, up)."""
+        cam = Camera(_f3(eye), _f3(look), _f3(up), fov, lens_radius, focal_distance, int(bool(orthographic)))
         _check(lib().gnxr_builder_set_camera(self._h, C.byref(cam)))
 
     def set_camera_medium(self, medium):

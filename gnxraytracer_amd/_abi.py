@@ -43,7 +43,7 @@ class Light(C.Structure):
 
 class Camera(C.Structure):
     _fields_ = [("eye", f32 * 3), ("look", f32 * 3), ("up", f32 * 3), ("fov_deg", f32), ("lens_radius", f32),
-                ("focal_distance", f32)]
+                ("focal_distance", f32), ("orthographic", i32)]
 
 
 class Medium(C.Structure):

@@ -115,7 +115,7 @@ struct DCamera {
     float c2w[16];   // CameraToWorld
     float lens_radius, focal_distance;
     int32_t medium;
-    int32_t _pad;
+    int32_t ortho;    // OrthographicCamera (camera/Orthographic.cpp) instead of PerspectiveCamera
 };
 
 struct DEnv {         // InfiniteAreaLight tables

@@ -96,6 +96,7 @@ GX_DEV void camera_ray(const DCamera &cam, const DSamplerTables &st, int px, int
     V3 pCamera = xform_point(cam.r2c, V3(pfx, pfy, 0));
     V3 dir = normalize(V3(pCamera.x, pCamera.y, pCamera.z));
     V3 oc(0, 0, 0), dc = dir;
+    if (cam.ortho) { oc = pCamera; dc = V3(0, 0, 1); }   // OrthographicCamera::GenerateRayDifferential, camera/Orthographic.cpp:45-47
     if (cam.lens_radius > 0) {
         float dx, dy;
         concentric_sample_disk(lx, ly, &dx, &dy);
@@ -146,7 +147,28 @@ GX_DEV RayDiff camera_ray_diff(const DCamera &cam, const DSamplerTables &st, int
     V3 dxCamera = xform_point(cam.r2c, V3(1, 0, 0)) - xform_point(cam.r2c, V3(0, 0, 0));
     V3 dyCamera = xform_point(cam.r2c, V3(0, 1, 0)) - xform_point(cam.r2c, V3(0, 0, 0));
     V3 rxO, ryO, rxD, ryD;
-    if (cam.lens_radius > 0) {
+    if (cam.ortho) {   // camera/Orthographic.cpp:62-78; dxCamera = RasterToCamera(Vector3f(1, 0, 0)) (Orthographic.h:22-23)
+        V3 dxo = xform_vector(cam.r2c, V3(1, 0, 0)), dyo = xform_vector(cam.r2c, V3(0, 1, 0));
+        if (cam.lens_radius > 0) {
+            float ddx, ddy;
+            concentric_sample_disk(lx, ly, &ddx, &ddy);
+            float plx = cam.lens_radius * ddx, ply = cam.lens_radius * ddy;
+            // ray->d after the lens update: Normalize(pFocus - pLens) with pFocus = pCamera + (focalDistance / 1) * (0, 0, 1)
+            V3 pF0 = pCamera + V3(0, 0, 1) * (cam.focal_distance / 1.f);
+            V3 dMain = normalize(pF0 - V3(plx, ply, 0));
+            float ft = cam.focal_distance / dMain.z;
+            V3 pFocus = pCamera + dxo + (ft * V3(0, 0, 1));
+            rxO = V3(plx, ply, 0);
+            rxD = normalize(pFocus - rxO);
+            pFocus = pCamera + dyo + (ft * V3(0, 0, 1));
+            ryO = V3(plx, ply, 0);
+            ryD = normalize(pFocus - ryO);
+        } else {
+            rxO = pCamera + dxo;
+            ryO = pCamera + dyo;
+            rxD = ryD = V3(0, 0, 1);
+        }
+    } else if (cam.lens_radius > 0) {
         float ddx, ddy;
         concentric_sample_disk(lx, ly, &ddx, &ddy);
         float plx = cam.lens_radius * ddx, ply = cam.lens_radius * ddy;

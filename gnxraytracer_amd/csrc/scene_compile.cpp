@@ -457,7 +457,13 @@ DCamera make_camera(const gnxr_camera &c, int W, int H, int medium) {
     float sxmin, sxmax, symin, symax;
     if (frame > 1.f) { sxmin = -frame; sxmax = frame; symin = -1.f; symax = 1.f; }
     else { sxmin = -1.f; sxmax = 1.f; symin = -1.f / frame; symax = 1.f / frame; }
-    Xf c2s = perspective(c.fov_deg, 1e-2f, 1000.f);
+    if (c.orthographic) {   // CreateOrthographicCamera: ScreenScale = 2 (Orthographic.cpp:108-114)
+        const float ScreenScale = 2.0f;
+        sxmin *= ScreenScale; sxmax *= ScreenScale; symin *= ScreenScale; symax *= ScreenScale;
+    }
+    // Perspective(fov, 1e-2, 1000) (Perspective.cpp:18) or Orthographic(0, 10) = Scale(1, 1, 1 / (zFar - zNear)) * Translate(0, 0, -zNear)
+    // (Orthographic.h:18, Transform.cpp:282-285)
+    Xf c2s = c.orthographic ? xmul(scale(1, 1, 1 / (10.f - 0.f)), translate(Vec3(0, 0, -0.f))) : perspective(c.fov_deg, 1e-2f, 1000.f);
     Xf s2r = xmul(xmul(scale((float)W, (float)H, 1), scale(1 / (sxmax - sxmin), 1 / (symin - symax), 1)), translate(Vec3(-sxmin, -symax, 0)));
     Xf r2c = xmul(xinverse(c2s), xinverse(s2r));
     memcpy(d.r2c, r2c.m.m, 64);
@@ -465,6 +471,7 @@ DCamera make_camera(const gnxr_camera &c, int W, int H, int medium) {
     d.lens_radius = c.lens_radius;
     d.focal_distance = c.focal_distance;
     d.medium = medium;
+    d.ortho = c.orthographic ? 1 : 0;
     return d;
 }
 

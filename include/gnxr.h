@@ -148,6 +148,8 @@ typedef struct gnxr_camera {
     float fov_deg;
     float lens_radius;
     float focal_distance;
+    int32_t orthographic;   /* 0: PerspectiveCamera (camera/Perspective.cpp) ; 1: OrthographicCamera (camera/Orthographic.cpp:
+                               Orthographic(0, 10), screen window x 2 as CreateOrthographicCamera sets it; fov_deg unused) */
 } gnxr_camera;
 
 /* ---- media: media/{Homogeneous,GridDensity}Medium.cpp (VolPath, config 5) ---------- */

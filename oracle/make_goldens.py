@@ -231,6 +231,7 @@ def main():
     direct_goldens(cornell_path, zoo_path)
     texture_goldens()
     delta_goldens()
+    ortho_goldens()
     # cfg 2 at full size: the counts the survey recorded from the COMPLETE reference
     img, cnt = render(cornell_path, 256, 256, 64)
     checksum = float(img[..., :3].astype(np.float64).sum())
@@ -358,6 +359,28 @@ def delta_goldens():
     save("render_delta.npz", **out)
 
 
+def ortho_goldens():
+    # ---- 16: OrthographicCamera (camera/Orthographic.cpp; CreateOrthographicCamera: Orthographic(0, 10), screen window x 2) on the
+    # textured scene, so that its offset rays (rxOrigin = o + dxCamera, parallel directions) reach the texture filters
+    tex_path = os.path.join(G, "tex_smile_96x80.hdr")
+    b = scenes.textured_cornell(tex_path)
+    b.set_camera(eye=(0.2, 0.1, 5.0), look=(0.0, -0.2, 0.0), orthographic=True)
+    path = scene_file(b, "ortho")
+    out = {}
+    W, H, spp, depth = 72, 64, 8, 5
+    for name, integ, args in [("path", gx.PathIntegrator(depth, 1.0, "spatial"), [0, 0, 0]), ("whitted", gx.WhittedIntegrator(depth), [0, 0, 2]),
+                              ("volpath", gx.VolPathIntegrator(depth, 1.0, "spatial"), [0, 0, 1])]:
+        raw = ol.run_ref(path, "render", None, [W, H, spp, depth, 1.0] + args)
+        out[name] = np.frombuffer(raw[:W * H * 16], np.float32).reshape(H, W, 4).copy()
+        out[name + "_rays"] = np.frombuffer(raw[W * H * 16:W * H * 16 + 16], np.uint64).copy()
+        oimg, st = ol.OracleScene(b).render(integ, W, H, spp)
+        same = oimg.view(np.uint32) == out[name].view(np.uint32)
+        print("ortho", name, "rays", out[name + "_rays"], (st["rays_closest"], st["rays_any"]), "identical %.3f%%" % (100 * same.mean()), "maxabs", float(np.abs(oimg - out[name]).max()))
+        assert same.all()
+    out["cfg"] = np.array([W, H, spp, depth], np.int32)
+    save("render_ortho.npz", **out)
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["direct"]:   # only section 13
         direct_goldens(scene_file(scenes.cornell(), "cornell"), scene_file(scenes.material_zoo(), "zoo"))
@@ -365,5 +388,7 @@ if __name__ == "__main__":
         texture_goldens()
     elif sys.argv[1:] == ["delta"]:      # only section 15
         delta_goldens()
+    elif sys.argv[1:] == ["ortho"]:      # only section 16
+        ortho_goldens()
     else:
         main()

@@ -622,6 +622,7 @@ struct Camera {
     V3 dxCamera, dyCamera;
     Float lensRadius, focalDistance;
     int medium = -1;
+    bool orthographic = false;   // OrthographicCamera, camera/Orthographic.{h,cpp}
     Camera() {}
     Camera(const gnxr_camera &c, int W, int H) {
         // RenderThread.cpp:62-68
@@ -633,7 +634,13 @@ struct Camera {
         if (frame > 1.f) { sxmin = -frame; sxmax = frame; symin = -1.f; symax = 1.f; }
         else { sxmin = -1.f; sxmax = 1.f; symin = -1.f / frame; symax = 1.f / frame; }
         lensRadius = c.lens_radius; focalDistance = c.focal_distance;
-        Xform cameraToScreen = Perspective(c.fov_deg, 1e-2f, 1000.f);
+        orthographic = c.orthographic != 0;
+        if (orthographic) {   // CreateOrthographicCamera, Orthographic.cpp:94-121: ScreenScale = 2
+            float ScreenScale = 2.0f;
+            sxmin *= ScreenScale; sxmax *= ScreenScale; symin *= ScreenScale; symax *= ScreenScale;
+        }
+        // Orthographic(0, 10) = Scale(1, 1, 1 / (zFar - zNear)) * Translate(0, 0, -zNear), Transform.cpp:282-285
+        Xform cameraToScreen = orthographic ? XMul(Scale(1, 1, 1 / (10.f - 0.f)), Translate(V3(0, 0, -0.f))) : Perspective(c.fov_deg, 1e-2f, 1000.f);
         // Camera.h:64-70
         Xform screenToRaster = XMul(XMul(Scale(W, H, 1), Scale(1 / (sxmax - sxmin), 1 / (symin - symax), 1)), Translate(V3(-sxmin, -symax, 0)));
         Xform rasterToScreen = XInverse(screenToRaster);
@@ -641,12 +648,17 @@ struct Camera {
         rasterToCamera = r2c.m;
         dxCamera = XPoint(rasterToCamera, V3(1, 0, 0)) - XPoint(rasterToCamera, V3(0, 0, 0));
         dyCamera = XPoint(rasterToCamera, V3(0, 1, 0)) - XPoint(rasterToCamera, V3(0, 0, 0));
+        if (orthographic) {   // Orthographic.h:22-23: vector transforms
+            dxCamera = XVector(rasterToCamera, V3(1, 0, 0));
+            dyCamera = XVector(rasterToCamera, V3(0, 1, 0));
+        }
     }
     // GenerateRayDifferential, Perspective.cpp:62-112 + Transform::operator()(RayDifferential), Transform.h:246-256
     Ray GenerateRay(const P2 &pFilm, const P2 &pLens) const {
         V3 pCamera = XPoint(rasterToCamera, V3(pFilm.x, pFilm.y, 0));
         V3 dir = Normalize(V3(pCamera.x, pCamera.y, pCamera.z));
         V3 o(0, 0, 0), d = dir;
+        if (orthographic) { o = pCamera; d = V3(0, 0, 1); }   // Orthographic.cpp:45-47
         if (lensRadius > 0) {
             P2 dsk = ConcentricSampleDisk(pLens);
             P2 pl(lensRadius * dsk.x, lensRadius * dsk.y);
@@ -668,7 +680,23 @@ struct Camera {
         Ray ray(ow, dw, tMax, medium);
         // offset rays, Perspective.cpp:86-106 (camera space), then CameraToWorld: plain point / vector transforms
         V3 rxO, ryO, rxD, ryD;
-        if (lensRadius > 0) {
+        if (orthographic) {   // Orthographic.cpp:62-78 (`o`, `d`: the camera-space main ray after the lens update)
+            if (lensRadius > 0) {
+                P2 dsk = ConcentricSampleDisk(pLens);
+                P2 pl(lensRadius * dsk.x, lensRadius * dsk.y);
+                Float ft = focalDistance / d.z;
+                V3 pFocus = pCamera + dxCamera + (ft * V3(0, 0, 1));
+                rxO = V3(pl.x, pl.y, 0);
+                rxD = Normalize(pFocus - rxO);
+                pFocus = pCamera + dyCamera + (ft * V3(0, 0, 1));
+                ryO = V3(pl.x, pl.y, 0);
+                ryD = Normalize(pFocus - ryO);
+            } else {
+                rxO = o + dxCamera;
+                ryO = o + dyCamera;
+                rxD = ryD = d;
+            }
+        } else if (lensRadius > 0) {
             P2 dsk = ConcentricSampleDisk(pLens);
             P2 pl(lensRadius * dsk.x, lensRadius * dsk.y);
             V3 dx = Normalize(pCamera + dxCamera);

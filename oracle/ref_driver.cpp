@@ -27,6 +27,7 @@
 #undef private
 #undef protected
 #include "camera/Perspective.h"
+#include "camera/Orthographic.h"
 #include "core/Interaction.h"
 #include "core/Light.h"
 #include "core/Reflection.h"
@@ -814,7 +815,7 @@ int main(int argc, char **argv) {
         Transform lookat = LookAt(Point3f(c.eye[0], c.eye[1], c.eye[2]), Point3f(c.look[0], c.look[1], c.look[2]), Vector3f(c.up[0], c.up[1], c.up[2]));
         Transform c2w = Inverse(lookat), c2wEnd = c2w;
         AnimatedTransform anim(&c2w, 0.0f, &c2wEnd, 1.0f);
-        std::unique_ptr<PerspectiveCamera> cam(CreatePerspectiveCamera(W, H, anim));
+        std::unique_ptr<Camera> cam(c.orthographic ? (Camera *)CreateOrthographicCamera(W, H, anim) : (Camera *)CreatePerspectiveCamera(W, H, anim));
         HaltonSampler sampler(1, Bounds2i(Point2i(0, 0), Point2i(W, H)), false);
         size_t n = in.size() / 24;
         const int64_t *q = (const int64_t *)in.data();
@@ -994,7 +995,7 @@ int main(int argc, char **argv) {
         Transform lookat = LookAt(Point3f(c.eye[0], c.eye[1], c.eye[2]), Point3f(c.look[0], c.look[1], c.look[2]), Vector3f(c.up[0], c.up[1], c.up[2]));
         Transform c2w = Inverse(lookat), c2wEnd = c2w;
         AnimatedTransform anim(&c2w, 0.0f, &c2wEnd, 1.0f);
-        std::unique_ptr<PerspectiveCamera> cam(CreatePerspectiveCamera(W, H, anim));
+        std::unique_ptr<Camera> cam(c.orthographic ? (Camera *)CreateOrthographicCamera(W, H, anim) : (Camera *)CreatePerspectiveCamera(W, H, anim));
         HaltonSampler proto(spp, Bounds2i(Point2i(0, 0), Point2i(W, H)), false);
         RefLightDistribution ld(scene, strat);
         std::vector<int> nLightSamples;

@@ -411,6 +411,27 @@ def test_delta_lights_match_reference(gpu, name):
         dev, host = scene.light_grid_table("spatial", on_host=False), scene.light_grid_table("spatial", on_host=True)
         assert biteq(dev, host)
 
+@pytest.mark.parametrize("name", ["path", "whitted", "volpath", "lens_whitted", "lens_path"])
+def test_orthographic_camera_matches_reference(gpu, name):
+    """OrthographicCamera on the device (camera_ray / camera_ray_diff): golden images of the reference's camera class; the thin-lens
+    variants (CreateOrthographicCamera hard-codes lensRadius = 0) compare with the oracle."""
+    g = golden("render_ortho.npz")
+    W, H, spp, depth = (int(v) for v in g["cfg"])
+    b = scenes.textured_cornell(os.path.join(GOLDEN, "tex_smile_96x80.hdr"))
+    lens = name.startswith("lens_")
+    b.set_camera(eye=(0.2, 0.1, 5.0), look=(0.0, -0.2, 0.0), orthographic=True, lens_radius=0.2 if lens else 0.0, focal_distance=6.0)
+    key = name.split("_")[-1]
+    integ = {"path": lambda: gpu.PathIntegrator(depth, 1.0, "spatial"), "whitted": lambda: gpu.WhittedIntegrator(depth),
+             "volpath": lambda: gpu.VolPathIntegrator(depth, 1.0, "spatial")}[key]()
+    img, st = integ.Render(gpu.Scene(b), W, H, spp)
+    if not lens:
+        assert (st["rays_closest"], st["rays_any"]) == tuple(int(v) for v in g[key + "_rays"])
+        assert biteq(img[..., :3], g[key][..., :3])
+    else:
+        oimg, ost = ol.OracleScene(b).render(integ, W, H, spp)
+        assert (st["rays_closest"], st["rays_any"]) == (ost["rays_closest"], ost["rays_any"])
+        assert biteq(img[..., :3], oimg[..., :3])
+
 
 @pytest.mark.parametrize("kind", ["matte", "mirror", "glass", "medium"])
 def test_sphere_matches_oracle(gpu, kind):

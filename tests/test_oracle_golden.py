@@ -247,6 +247,22 @@ def test_delta_light_images(name, gx):
     assert (st["rays_closest"], st["rays_any"]) == tuple(int(v) for v in g[name + "_rays"])
     assert biteq(img, g[name])
 
+def _ortho_scene():
+    b = scenes.textured_cornell(os.path.join(GOLDEN, "tex_smile_96x80.hdr"))
+    b.set_camera(eye=(0.2, 0.1, 5.0), look=(0.0, -0.2, 0.0), orthographic=True)
+    return b
+
+
+@pytest.mark.parametrize("name", ["path", "whitted", "volpath"])
+def test_orthographic_camera_images(name, gx):
+    """OrthographicCamera::GenerateRayDifferential (camera/Orthographic.cpp:36-92) as CreateOrthographicCamera builds it, on the
+    textured scene (the offset rays feed the texture filters under Whitted / VolPath): the reference's camera class."""
+    g = golden("render_ortho.npz")
+    W, H, spp, depth = (int(v) for v in g["cfg"])
+    img, st = ol.OracleScene(_ortho_scene()).render(_textured_integrator(gx, name, depth), W, H, spp)
+    assert (st["rays_closest"], st["rays_any"]) == tuple(int(v) for v in g[name + "_rays"])
+    assert biteq(img, g[name])
+
 
 def test_cfg2_reproduces_the_recorded_reference_run(gx):
     """the complete reference traced 16 058 662 closest-hit and 12 329 468 any-hit rays
