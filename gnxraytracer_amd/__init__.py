@@ -126,6 +126,16 @@ class SceneBuilder:
     def AddSkyLight(self):                            # ui/ModelList.cpp:163-170
         return _check(lib().gnxr_builder_add_sky_light(self._h))
 
+    def add_emissive_mesh(self, vertices, indices, material, lemit, n_samples=5, object_to_world=None):
+        """AddAreaLight's pattern (ui/ModelList.cpp:137-146) for any mesh: one DiffuseAreaLight per triangle."""
+        v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
+        i = np.ascontiguousarray(indices, dtype=np.int32).reshape(-1, 3)
+        m = None
+        if object_to_world is not None:
+            m = np.ascontiguousarray(object_to_world, dtype=np.float32).reshape(16).ctypes.data_as(C.POINTER(C.c_float))
+        return _check(lib().gnxr_builder_add_emissive_mesh(self._h, v.ctypes.data_as(C.POINTER(C.c_float)), len(v), i.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                           len(i), m, int(material), _f3(lemit), int(n_samples)))
+
     def AddSpotLight(self):                           # ui/ModelList.cpp:149-154 (the call is commented out in RenderThread.cpp:138)
         return _check(lib().gnxr_builder_add_spot_light(self._h))
 

@@ -193,7 +193,7 @@ struct gnxr_scene {
     int ensure_grid(int strategy, bool force_host = false) {
         if (grid_strategy == strategy && !force_host) return GNXR_OK;
         const int nl = (int)cs.desc_lights.size();
-        const bool on_device = strategy == GNXR_LIGHTS_SPATIAL && nl >= 2 && nl <= kGridMaxLights && !force_host && getenv("GNXR_HOST_LIGHT_GRID") == nullptr;
+        const bool on_device = strategy == GNXR_LIGHTS_SPATIAL && nl >= 2 && !force_host && getenv("GNXR_HOST_LIGHT_GRID") == nullptr;
         std::vector<float> table;
         build_light_grid(cs, strategy, &grid, &table, on_device);
         int rc;
@@ -208,7 +208,10 @@ struct gnxr_scene {
             bool area_only = true;
             for (const gnxr_light &l : cs.desc_lights) if (l.type != GNXR_LIGHT_AREA_TRI) area_only = false;
             const int blocks = (int)std::min<size_t>((nv + kBlock - 1) / kBlock, (size_t)g_num_cus * 8);
-            if (area_only) hipLaunchKernelGGL((k_light_grid<LT_AREA>), dim3(blocks), dim3(kBlock), 0, 0, lt, grid, (const float *)d_ri.p, grid_table.p);
+            if (nl > kGridMaxLights) {   // mesh lights: any number of lights, the table is the scratch space
+                if (area_only) hipLaunchKernelGGL((k_light_grid_any<LT_AREA>), dim3(blocks), dim3(kBlock), 0, 0, lt, grid, (const float *)d_ri.p, grid_table.p);
+                else hipLaunchKernelGGL((k_light_grid_any<LT_ALL>), dim3(blocks), dim3(kBlock), 0, 0, lt, grid, (const float *)d_ri.p, grid_table.p);
+            } else if (area_only) hipLaunchKernelGGL((k_light_grid<LT_AREA>), dim3(blocks), dim3(kBlock), 0, 0, lt, grid, (const float *)d_ri.p, grid_table.p);
             else hipLaunchKernelGGL((k_light_grid<LT_ALL>), dim3(blocks), dim3(kBlock), 0, 0, lt, grid, (const float *)d_ri.p, grid_table.p);
             HIP_TRY(hipDeviceSynchronize());
         } else if ((rc = grid_table.upload(table)) != GNXR_OK) return rc;

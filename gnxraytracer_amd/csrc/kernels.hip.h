@@ -657,6 +657,48 @@ __global__ void __launch_bounds__(kBlock) k_light_grid(DLightTables lt, DLightGr
     }
 }
 
+// The same for any number of lights (mesh lights: one light per emissive triangle): the voxel's slice of the table is the scratch
+// space.  Per light the 128 contributions are summed in the same order as above (i ascending), and the sum over the lights, the
+// floor and the Distribution1D follow in light order, so the table is the same bit for bit.
+template <int LT>
+__global__ void __launch_bounds__(kBlock) k_light_grid_any(DLightTables lt, DLightGrid g, const float *__restrict__ ri, float *__restrict__ table) {
+    const int nl = g.n_lights;
+    const long long nv = (long long)g.nvox[0] * g.nvox[1] * g.nvox[2];
+    for (long long idx = blockIdx.x * blockDim.x + threadIdx.x; idx < nv; idx += (long long)gridDim.x * blockDim.x) {
+        const int z = (int)(idx % g.nvox[2]), y = (int)((idx / g.nvox[2]) % g.nvox[1]), x = (int)(idx / ((long long)g.nvox[2] * g.nvox[1]));
+        V3 p0((float)x / (float)g.nvox[0], (float)y / (float)g.nvox[1], (float)z / (float)g.nvox[2]);
+        V3 p1((float)(x + 1) / (float)g.nvox[0], (float)(y + 1) / (float)g.nvox[1], (float)(z + 1) / (float)g.nvox[2]);
+        V3 lo(g.lo[0], g.lo[1], g.lo[2]), hi(g.hi[0], g.hi[1], g.hi[2]);
+        V3 a(lerpf(p0.x, lo.x, hi.x), lerpf(p0.y, lo.y, hi.y), lerpf(p0.z, lo.z, hi.z));
+        V3 b(lerpf(p1.x, lo.x, hi.x), lerpf(p1.y, lo.y, hi.y), lerpf(p1.z, lo.z, hi.z));
+        V3 vlo(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)), vhi(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z));
+        float *dst = table + (size_t)idx * g.stride;
+        float sum = 0;
+        for (int j = 0; j < nl; ++j) {
+            float c = 0.f;
+            for (int i = 0; i < 128; ++i) {
+                V3 po(lerpf(ri[i], vlo.x, vhi.x), lerpf(ri[128 + i], vlo.y, vhi.y), lerpf(ri[256 + i], vlo.z, vhi.z));
+                LightSample ls = light_sample<LT>(lt, j, po, ri[384 + i], ri[512 + i]);
+                if (ls.pdf > 0) c += ls.Li.y() / ls.pdf;
+            }
+            dst[nl + j] = c;
+            sum += c;
+        }
+        const float avg = sum / (float)(128 * nl);
+        const float minC = (avg > 0) ? (float)(.001 * (double)avg) : 1.f;
+        float cdf = 0;   // Distribution1D ctor, Sampling.h:22-35: running cdf[j + 1], parked in dst[j] until funcInt is known
+        for (int j = 0; j < nl; ++j) {
+            const float f = fmaxf(dst[nl + j], minC);
+            dst[nl + j] = f;
+            cdf = cdf + f / (float)nl;
+            dst[j] = cdf;
+        }
+        const float funcInt = cdf;
+        for (int j = 0; j < nl; ++j) dst[j] = (funcInt == 0) ? (float)(j + 1) / (float)nl : dst[j] / funcInt;
+        dst[2 * nl] = funcInt;
+    }
+}
+
 // test hook: the device's float libm (device_math.h) on caller-supplied arguments
 static __global__ void k_libm_probe(int fn, const float *x, const float *x2, long long n, float *out) {
     for (long long i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {

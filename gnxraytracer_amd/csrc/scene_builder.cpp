@@ -514,6 +514,25 @@ int gnxr_builder_add_area_light(gnxr_builder *b, int32_t material) {
     return first;
 }
 
+int gnxr_builder_add_emissive_mesh(gnxr_builder *b, const float *vertices, int32_t n_vertices, const int32_t *indices, int32_t n_triangles,
+                                   const float *o2w16, int32_t material, const float lemit[3], int32_t n_samples) {
+    if (!b || !lemit) return GNXR_ERR_INVALID;
+    int first = gnxr_builder_add_mesh(b, vertices, n_vertices, indices, n_triangles, o2w16, material, -1, -1);
+    if (first < 0) return first;
+    for (int i = 0; i < n_triangles; ++i) {
+        gnxr_light l;
+        memset(&l, 0, sizeof(l));
+        l.type = GNXR_LIGHT_AREA_TRI;
+        l.tri = first + i;
+        l.two_sided = 0;
+        l.n_samples = n_samples;
+        memcpy(l.le, lemit, 12);
+        b->b.lights.push_back(l);
+        b->b.tri_light[first + i] = (int)b->b.lights.size() - 1;
+    }
+    return first;
+}
+
 // AddSkyLight, ui/ModelList.cpp:163-170 (image "1" never loads -> gradient)
 int gnxr_builder_add_sky_light(gnxr_builder *b) {
     if (!b) return GNXR_ERR_INVALID;

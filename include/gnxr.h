@@ -367,6 +367,10 @@ int gnxr_builder_add_cornell(gnxr_builder *b, int32_t material1, int32_t materia
                              int32_t material3);                                      /* ModelList.cpp:71-118 */
 int gnxr_builder_add_floor(gnxr_builder *b, int32_t material);                        /* ModelList.cpp:20-45  */
 int gnxr_builder_add_area_light(gnxr_builder *b, int32_t material);                   /* ModelList.cpp:120-147 */
+/* AddAreaLight's pattern for any mesh: one DiffuseAreaLight(Lemit, nSamples, triangle, twoSided = false) per triangle
+ * (ModelList.cpp:137-146); returns the first triangle index */
+int gnxr_builder_add_emissive_mesh(gnxr_builder *b, const float *vertices, int32_t n_vertices, const int32_t *indices, int32_t n_triangles,
+                                   const float *object_to_world16, int32_t material, const float lemit[3], int32_t n_samples);
 int gnxr_builder_add_sky_light(gnxr_builder *b);                                      /* ModelList.cpp:163-170 */
 int gnxr_builder_add_spot_light(gnxr_builder *b);                                     /* AddSpotLight, ModelList.cpp:149-154 */
 int gnxr_builder_add_dist_light(gnxr_builder *b);                                     /* AddDistLight, ModelList.cpp:156-161 */

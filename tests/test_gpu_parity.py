@@ -543,3 +543,25 @@ def test_c_caller_renders_the_default_scene(gpu, tmp_path):
             pos += 12 + n
         raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(H, W * 4 + 1)
         assert (raw[:, 1:].reshape(H, W, 4) == rgba8).all() and rgba8[..., :3].max() > 100
+
+
+def test_light_grid_with_many_lights(gpu):
+    """More lights than the unrolled k_light_grid handles (16): the general kernel uses the voxel's table slice as scratch and must
+    produce the host restatement's bits; the render (spatial light selection over 22 lights) matches the oracle."""
+    b = scenes.cornell()
+    white = b.MatteMaterial(scenes.WHITE, 60.0)
+    quad = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+    d0 = b.desc().n_lights
+    for k in range(10):   # ten more emissive quads = 20 more one-triangle lights, spread over the box
+        x, z = -2.0 + 0.4 * k, -1.5 + 0.3 * k
+        v = np.array([[x, 2.3 - 0.05 * k, z], [x + 0.3, 2.3 - 0.05 * k, z], [x + 0.3, 2.3 - 0.05 * k, z + 0.3], [x, 2.3 - 0.05 * k, z + 0.3]], np.float32)
+        b.add_emissive_mesh(v, quad, white, (3.0 + k, 4.0, 5.0 - 0.3 * k))
+    assert b.desc().n_lights == d0 + 20
+    scene = gpu.Scene(b)
+    dev, host = scene.light_grid_table("spatial", on_host=False), scene.light_grid_table("spatial", on_host=True)
+    assert biteq(dev, host)
+    integ = gpu.PathIntegrator(5, 1.0, "spatial")
+    img, st = integ.Render(scene, 64, 48, 8)
+    oimg, ost = ol.OracleScene(b).render(integ, 64, 48, 8)
+    assert (st["rays_closest"], st["rays_any"]) == (ost["rays_closest"], ost["rays_any"])
+    assert biteq(img[..., :3], oimg[..., :3])
