@@ -332,8 +332,8 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     }
     // (media in the scene are fine: these integrators never look at them -- a medium boundary without material is passed
     // through by the main ray, WhittedIntegrator.cpp:34-35, and blocks shadow rays like any other surface, Light.cpp:28-31)
-    if (whitted && (n_records > 64 || p.max_depth > 32)) {
-        set_error("Whitted / DirectLighting on the device: at most 64 light samples per vertex (every light is sampled at every vertex), depth 32");
+    if (whitted && (n_records > 256 || p.max_depth > 32)) {
+        set_error("Whitted / DirectLighting on the device: at most 256 light samples per vertex (every light is sampled at every vertex), depth 32");
         return GNXR_ERR_UNSUPPORTED;
     }
     bool textured_scene = false;

@@ -560,8 +560,8 @@ def test_light_grid_with_many_lights(gpu):
     scene = gpu.Scene(b)
     dev, host = scene.light_grid_table("spatial", on_host=False), scene.light_grid_table("spatial", on_host=True)
     assert biteq(dev, host)
-    integ = gpu.PathIntegrator(5, 1.0, "spatial")
-    img, st = integ.Render(scene, 64, 48, 8)
-    oimg, ost = ol.OracleScene(b).render(integ, 64, 48, 8)
-    assert (st["rays_closest"], st["rays_any"]) == (ost["rays_closest"], ost["rays_any"])
-    assert biteq(img[..., :3], oimg[..., :3])
+    for integ in (gpu.PathIntegrator(5, 1.0, "spatial"), gpu.DirectLightingIntegrator("all", 3), gpu.WhittedIntegrator(3)):   # "all": 110 records per vertex
+        img, st = integ.Render(scene, 64, 48, 8)
+        oimg, ost = ol.OracleScene(b).render(integ, 64, 48, 8)
+        assert (st["rays_closest"], st["rays_any"]) == (ost["rays_closest"], ost["rays_any"])
+        assert biteq(img[..., :3], oimg[..., :3])
