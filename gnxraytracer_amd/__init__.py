@@ -169,7 +169,7 @@ class SceneBuilder:
         return _check(lib().gnxr_builder_add_inf_light_data(self._h, rgb.ctypes.data_as(C.POINTER(C.c_float)), w, h, m,
                                                             _f3(power)))
 
-    def add_mesh(self, vertices, indices, material, object_to_world=None, medium_inside=-1, medium_outside=-1, uv=None, normals=None):
+    def add_mesh(self, vertices, indices, material, object_to_world=None, medium_inside=-1, medium_outside=-1, uv=None, normals=None, tangents=None):
         """TriangleMesh(ObjectToWorld, nTriangles, vertexIndices, nVertices, P, S = nullptr, N = normals, UV = uv, ...): uv is the
         per-vertex (u, v) array of the mesh or None (Triangle::GetUVs defaults, what every mesh of the reference gets); normals the
         per-vertex object-space shading normals or None (flat shading)."""
@@ -193,6 +193,15 @@ class SceneBuilder:
                               minv[0, 2] * x + minv[1, 2] * y + minv[2, 2] * z], 1).astype(np.float32)
             corner = np.ascontiguousarray(n[i].reshape(-1, 9))
             _check(lib().gnxr_builder_set_triangle_normals(self._h, first, len(i), corner.ctypes.data_as(C.POINTER(C.c_float))))
+        if tangents is not None:   # TriangleMesh::s: s[i] = ObjectToWorld(S[i]), a plain vector transform (Triangle.cpp:49-52)
+            t = np.asarray(tangents, dtype=np.float32).reshape(-1, 3)
+            if object_to_world is not None:
+                mm = np.asarray(object_to_world, dtype=np.float32).reshape(4, 4)
+                x, y, z = t[:, 0].copy(), t[:, 1].copy(), t[:, 2].copy()
+                t = np.stack([mm[0, 0] * x + mm[0, 1] * y + mm[0, 2] * z, mm[1, 0] * x + mm[1, 1] * y + mm[1, 2] * z,
+                              mm[2, 0] * x + mm[2, 1] * y + mm[2, 2] * z], 1).astype(np.float32)
+            corner = np.ascontiguousarray(t[i].reshape(-1, 9))
+            _check(lib().gnxr_builder_set_triangle_tangents(self._h, first, len(i), corner.ctypes.data_as(C.POINTER(C.c_float))))
         return first
 
     def add_medium(self, medium, density=None):

@@ -73,7 +73,7 @@ class SceneDesc(C.Structure):
         ("grid_density", C.POINTER(f32)), ("env_rgb", C.POINTER(f32)),
         ("camera", Camera), ("camera_medium", i32), ("n_spheres", i32), ("spheres", C.POINTER(Sphere)),
         ("n_textures", i32), ("_pad", i32), ("textures", C.POINTER(Texture)), ("texels", C.POINTER(f32)),
-        ("tri_uv", C.POINTER(f32)), ("tri_n", C.POINTER(f32)),
+        ("tri_uv", C.POINTER(f32)), ("tri_n", C.POINTER(f32)), ("tri_s", C.POINTER(f32)),
     ]
 
 
@@ -155,6 +155,7 @@ PROTOTYPES = {
     "gnxr_builder_set_material_texture": (C.c_int, [VP, i32, i32, i32]),
     "gnxr_builder_set_triangle_uv": (C.c_int, [VP, i32, i32, P(f32)]),
     "gnxr_builder_set_triangle_normals": (C.c_int, [VP, i32, i32, P(f32)]),
+    "gnxr_builder_set_triangle_tangents": (C.c_int, [VP, i32, i32, P(f32)]),
     "gnxr_builder_set_camera": (C.c_int, [VP, P(Camera)]),
     "gnxr_builder_desc": (C.c_int, [VP, P(SceneDesc)]),
     "gnxr_write_synthetic_3d": (C.c_int, [C.c_char_p, i32, u32]),

@@ -121,7 +121,7 @@ struct gnxr_scene {
     DevBuf<DSphere> spheres;
     DevBuf<DMaterial> materials, materials_single;
     DevBuf<DTexture> textures;
-    DevBuf<float> tex_texels, ewa_lut, tri_uv, tri_n;
+    DevBuf<float> tex_texels, ewa_lut, tri_uv, tri_n, tri_s;
     DevBuf<DLight> lights;
     DevBuf<int32_t> infinite;
     DevBuf<uint16_t> perms;
@@ -256,12 +256,12 @@ int gnxr_scene_create(const gnxr_scene_desc *desc, gnxr_scene **out) {
     for (const DNode &n : cs.nodes) if ((n.meta & 0xffffu) > 127) s->wide_ok = false;
 #define UP(field) if ((rc = s->field.upload(cs.field)) != GNXR_OK) { delete s; return rc; }
     UP(nodes) UP(nodes4) UP(tris) UP(lights) UP(perms) UP(primes) UP(prime_sums) UP(prime_magic)
-    UP(dmedia) UP(grid_density) UP(tri_media) UP(spheres) UP(textures) UP(tex_texels) UP(ewa_lut) UP(tri_uv) UP(tri_n)
+    UP(dmedia) UP(grid_density) UP(tri_media) UP(spheres) UP(textures) UP(tex_texels) UP(ewa_lut) UP(tri_uv) UP(tri_n) UP(tri_s)
     UP(env_texels) UP(env_cond_func) UP(env_cond_cdf) UP(env_cond_int) UP(env_marg_func) UP(env_marg_cdf)
 #undef UP
     {   // materials, preceded by one record that carries the texture tables (tex_tables(), device_texture.h)
         DTexTables tt;
-        tt.textures = s->textures.p; tt.texels = reinterpret_cast<const float4 *>(s->tex_texels.p); tt.ewa_lut = s->ewa_lut.p; tt.tri_uv = cs.tri_uv.empty() ? nullptr : s->tri_uv.p; tt.tri_n = cs.tri_n.empty() ? nullptr : s->tri_n.p;   // (an empty upload still allocates)
+        tt.textures = s->textures.p; tt.texels = reinterpret_cast<const float4 *>(s->tex_texels.p); tt.ewa_lut = s->ewa_lut.p; tt.tri_uv = cs.tri_uv.empty() ? nullptr : s->tri_uv.p; tt.tri_n = cs.tri_n.empty() ? nullptr : s->tri_n.p; tt.tri_s = cs.tri_s.empty() ? nullptr : s->tri_s.p;   // (an empty upload still allocates)
         for (int k = 0; k < 2; ++k) {
             const std::vector<DMaterial> &src = k == 0 ? cs.materials : cs.materials_single;
             std::vector<DMaterial> up(src.size() + 1);

@@ -20,6 +20,7 @@ struct DTexTables {
     const float *ewa_lut;                // MIPMap::weightLut[128]
     const float *tri_uv;                 // null, or per leaf-order triangle (u,v) x 3 corners + 2 pad floats (TriangleMesh::uv)
     const float *tri_n;                  // null, or per leaf-order triangle 3 shading normals (12 floats; zeros == none) (TriangleMesh::n)
+    const float *tri_s;                  // the same for the shading tangents (TriangleMesh::s)
 };
 
 // The tables travel in the slot BEFORE the first material (the material array is uploaded with one leading record) instead of in
@@ -183,40 +184,52 @@ GX_DEV bool tri_dpduv(V3 p0, V3 p1, V3 p2, const TriUV &uv, V3 *dpdu, V3 *dpdv) 
 }
 // TriangleMesh::n of a triangle; false when it has none
 struct TriN { V3 n0, n1, n2; };
-GX_DEV bool tri_normals(const DTexTables &tt, int leaf, TriN *out) {
-    if (!tt.tri_n || leaf < 0) return false;
-    const float4 *q = reinterpret_cast<const float4 *>(tt.tri_n + (size_t)leaf * 12);
+GX_DEV bool tri_normals(const float *table, int leaf, TriN *out) {
+    if (!table || leaf < 0) return false;
+    const float4 *q = reinterpret_cast<const float4 *>(table + (size_t)leaf * 12);
     float4 a = q[0], b = q[1], c = q[2];
     out->n0 = V3(a.x, a.y, a.z); out->n1 = V3(a.w, b.x, b.y); out->n2 = V3(b.z, b.w, c.x);
     return a.x != 0 || a.y != 0 || a.z != 0 || a.w != 0 || b.x != 0 || b.y != 0 || b.z != 0 || b.w != 0 || c.x != 0;
 }
-// The shading-geometry block of Triangle::Intersect for a triangle with per-vertex normals (shape/Triangle.cpp:228-297, mesh->s ==
-// nullptr): interpolated shading normal, the (ss, ts) frame, dndu / dndv, and SetShadingGeometry(ss, ts, dndu, dndv, true), which
+// The shading-geometry block of Triangle::Intersect for a triangle with per-vertex normals and / or tangents (shape/Triangle.cpp:
+// 228-297): interpolated shading normal, the (ss, ts) frame, dndu / dndv, and SetShadingGeometry(ss, ts, dndu, dndv, true), which
 // flips the GEOMETRIC normal onto the shading normal's side.  In: the flat SurfacePoint's n and the unshaded dpdu.  Out: n (flipped),
 // shading.n, shading.dpdu (= ss), shading.dpdv (= ts), dndu, dndv.
 struct ShadingGeom { V3 n, sn, sdpdu, sdpdv, dndu, dndv; };
-GX_DEV ShadingGeom tri_shading_geometry(const TriN &tn, const TriHit &h, const TriUV &uv, V3 n, V3 dpdu) {
+GX_DEV ShadingGeom tri_shading_geometry(const TriN *tnp, const TriN *tsp, const TriHit &h, const TriUV &uv, V3 n, V3 dpdu) {
     ShadingGeom g;
-    V3 ns = (h.b0 * tn.n0 + h.b1 * tn.n1 + h.b2 * tn.n2);
-    if (length_sq(ns) > 0) ns = normalize(ns);
-    else ns = n;
+    V3 ns = n;
+    if (tnp) {
+        ns = (h.b0 * tnp->n0 + h.b1 * tnp->n1 + h.b2 * tnp->n2);
+        if (length_sq(ns) > 0) ns = normalize(ns);
+        else ns = n;
+    }
     V3 ss = normalize(dpdu);
+    if (tsp) {   // mesh->s, Triangle.cpp:242-250
+        ss = (h.b0 * tsp->n0 + h.b1 * tsp->n1 + h.b2 * tsp->n2);
+        if (length_sq(ss) > 0) ss = normalize(ss);
+        else ss = normalize(dpdu);
+    }
     V3 ts = cross(ss, ns);
     if (length_sq(ts) > 0.f) {
         ts = normalize(ts);
         ss = cross(ts, ns);
     } else coordinate_system(ns, &ss, &ts);
-    const float duv02_0 = uv.u0 - uv.u2, duv02_1 = uv.v0 - uv.v2, duv12_0 = uv.u1 - uv.u2, duv12_1 = uv.v1 - uv.v2;
-    V3 dn1 = tn.n0 - tn.n2, dn2 = tn.n1 - tn.n2;
-    float determinant = duv02_0 * duv12_1 - duv02_1 * duv12_0;
-    if ((double)fabsf(determinant) < 1e-8) {
-        V3 dn = cross(tn.n2 - tn.n0, tn.n1 - tn.n0);
-        if (length_sq(dn) == 0) g.dndu = g.dndv = V3(0, 0, 0);
-        else coordinate_system(dn, &g.dndu, &g.dndv);
-    } else {
-        float invDet = 1 / determinant;
-        g.dndu = (duv12_1 * dn1 - duv02_1 * dn2) * invDet;
-        g.dndv = (-duv12_0 * dn1 + duv02_0 * dn2) * invDet;
+    g.dndu = g.dndv = V3(0, 0, 0);
+    if (tnp) {
+        const TriN &tn = *tnp;
+        const float duv02_0 = uv.u0 - uv.u2, duv02_1 = uv.v0 - uv.v2, duv12_0 = uv.u1 - uv.u2, duv12_1 = uv.v1 - uv.v2;
+        V3 dn1 = tn.n0 - tn.n2, dn2 = tn.n1 - tn.n2;
+        float determinant = duv02_0 * duv12_1 - duv02_1 * duv12_0;
+        if ((double)fabsf(determinant) < 1e-8) {
+            V3 dn = cross(tn.n2 - tn.n0, tn.n1 - tn.n0);
+            if (length_sq(dn) == 0) g.dndu = g.dndv = V3(0, 0, 0);
+            else coordinate_system(dn, &g.dndu, &g.dndv);
+        } else {
+            float invDet = 1 / determinant;
+            g.dndu = (duv12_1 * dn1 - duv02_1 * dn2) * invDet;
+            g.dndv = (-duv12_0 * dn1 + duv02_0 * dn2) * invDet;
+        }
     }
     // SetShadingGeometry(ss, ts, dndu, dndv, true), Interaction.cpp:36-54
     g.sn = normalize(cross(ss, ts));
@@ -227,7 +240,7 @@ GX_DEV ShadingGeom tri_shading_geometry(const TriN &tn, const TriHit &h, const T
 // SurfacePoint of a triangle hit with its attributes: per-corner uvs (`uv`, defaults when it has none) and, when `tn` is given,
 // per-vertex normals.  Material::Bump then runs on the shading geometry (core/Material.cpp:16-52 with the constant-0 displacement).
 // *dndu / *dndv receive shading.dndu / dndv (zero without normals).
-GX_DEV SurfacePoint surface_point_attr(V3 p0, V3 p1, V3 p2, const TriHit &h, bool has_bump, const TriUV &uv, const TriN *tn, V3 *dndu, V3 *dndv) {
+GX_DEV SurfacePoint surface_point_attr(V3 p0, V3 p1, V3 p2, const TriHit &h, bool has_bump, const TriUV &uv, const TriN *tn, const TriN *ts, V3 *dndu, V3 *dndv) {
     SurfacePoint s;
     s.valid = true;
     *dndu = *dndv = V3(0, 0, 0);
@@ -241,8 +254,8 @@ GX_DEV SurfacePoint surface_point_attr(V3 p0, V3 p1, V3 p2, const TriHit &h, boo
     s.p = h.b0 * p0 + h.b1 * p1 + h.b2 * p2;
     s.n = normalize(cross(dp02, dp12));
     V3 sn = s.n, sdpdu = dpdu, sdpdv = dpdv;
-    if (tn) {
-        ShadingGeom g = tri_shading_geometry(*tn, h, uv, s.n, dpdu);
+    if (tn || ts) {   // `if (mesh->n || mesh->s)`, Triangle.cpp:228
+        ShadingGeom g = tri_shading_geometry(tn, ts, h, uv, s.n, dpdu);
         s.n = g.n; sn = g.sn; sdpdu = g.sdpdu; sdpdv = g.sdpdv;
         *dndu = g.dndu; *dndv = g.dndv;
     }
@@ -261,9 +274,9 @@ GX_DEV SurfacePoint surface_point_attr(V3 p0, V3 p1, V3 p2, const TriHit &h, boo
 
 // the general-queue kernels shade every triangle hit through this: attributes from the scene tables (defaults when absent)
 GX_DEV SurfacePoint surface_point_tables(const DTexTables &tt, int leaf, V3 p0, V3 p1, V3 p2, const TriHit &h, bool has_bump, V3 *dndu, V3 *dndv) {
-    TriN tn;
-    const bool hasN = tri_normals(tt, leaf, &tn);
-    return surface_point_attr(p0, p1, p2, h, has_bump, tri_uvs(tt, leaf), hasN ? &tn : nullptr, dndu, dndv);
+    TriN tn, ts;
+    const bool hasN = tri_normals(tt.tri_n, leaf, &tn), hasS = tri_normals(tt.tri_s, leaf, &ts);
+    return surface_point_attr(p0, p1, p2, h, has_bump, tri_uvs(tt, leaf), hasN ? &tn : nullptr, hasS ? &ts : nullptr, dndu, dndv);
 }
 
 // uv of the hit (`uvHit = b0 * uv[0] + b1 * uv[1] + b2 * uv[2]`, Triangle.cpp:205) and the UNSHADED dpdu / dpdv

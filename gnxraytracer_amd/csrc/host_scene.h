@@ -26,6 +26,7 @@ struct Builder {
     std::vector<float> texels;
     std::vector<float> tri_uv;     // empty, or 6 floats per triangle (defaults for triangles never given uvs)
     std::vector<float> tri_n;      // empty, or 9 floats per triangle (zeros for triangles without normals)
+    std::vector<float> tri_s;      // empty, or 9 floats per triangle (zeros for triangles without tangents)
     std::vector<float> env_rgb;
     int env_w = 0, env_h = 0;
     gnxr_camera camera;
@@ -58,6 +59,7 @@ struct CompiledScene {
     std::vector<float> ewa_lut;                // MIPMap::weightLut
     std::vector<float> tri_uv;                 // empty, or 8 floats per leaf-order triangle: (u,v) x 3 corners + pad
     std::vector<float> tri_n;                  // empty, or 12 floats per leaf-order triangle: 3 shading normals + pad (zeros == none)
+    std::vector<float> tri_s;                  // the same for TriangleMesh::s (shading tangents)
     std::vector<DLight> lights;
     std::vector<int32_t> infinite_lights;
     // sampler

@@ -555,7 +555,7 @@ __global__ void __launch_bounds__(kBlock) k_trace_closest_api(DScene sc, const g
             load_tri(sc.tris, leaf, &p0, &p1, &p2);
             V3 nn = normalize(cross(p0 - p2, p1 - p2));
             const DTexTables &tt = tex_tables(sc.materials);
-            if (tt.tri_n) {   // per-vertex normals flip isect->n onto the shading side (SetShadingGeometry(..., true), Triangle.cpp:296)
+            if (tt.tri_n || tt.tri_s) {   // per-vertex normals / tangents flip isect->n onto the shading side (SetShadingGeometry(..., true), Triangle.cpp:296)
                 V3 dndu, dndv;
                 SurfacePoint sp = surface_point_tables(tt, leaf, p0, p1, p2, h, false, &dndu, &dndv);
                 if (sp.valid) nn = sp.n;

@@ -165,6 +165,7 @@ int Builder::add_mesh(const float *verts, int nv, const int32_t *idx, int nt, co
         tri_med_out.push_back(med_out);
         if (!tri_uv.empty()) { const float def[6] = {0, 0, 1, 0, 1, 1}; tri_uv.insert(tri_uv.end(), def, def + 6); }
         if (!tri_n.empty()) tri_n.insert(tri_n.end(), 9, 0.f);
+        if (!tri_s.empty()) tri_s.insert(tri_s.end(), 9, 0.f);
     }
     return first_tri;
 }
@@ -199,6 +200,7 @@ void Builder::fill_desc(gnxr_scene_desc *d) const {
     d->texels = texels.empty() ? nullptr : texels.data();
     d->tri_uv = tri_uv.empty() ? nullptr : tri_uv.data();
     d->tri_n = tri_n.empty() ? nullptr : tri_n.data();
+    d->tri_s = tri_s.empty() ? nullptr : tri_s.data();
 }
 
 // ---- `.3d` text meshes: shape/plyRead.h:19-48 ----
@@ -659,6 +661,13 @@ int gnxr_builder_set_triangle_normals(gnxr_builder *b, int32_t first, int32_t n,
     if (!b || !tri_n || first < 0 || n < 0 || (size_t)first + (size_t)n > b->b.indices.size() / 3) return GNXR_ERR_INVALID;
     if (b->b.tri_n.empty()) b->b.tri_n.assign(b->b.indices.size() / 3 * 9, 0.f);
     memcpy(&b->b.tri_n[(size_t)first * 9], tri_n, (size_t)n * 9 * sizeof(float));
+    return GNXR_OK;
+}
+
+int gnxr_builder_set_triangle_tangents(gnxr_builder *b, int32_t first, int32_t n, const float *tri_s) {
+    if (!b || !tri_s || first < 0 || n < 0 || (size_t)first + (size_t)n > b->b.indices.size() / 3) return GNXR_ERR_INVALID;
+    if (b->b.tri_s.empty()) b->b.tri_s.assign(b->b.indices.size() / 3 * 9, 0.f);
+    memcpy(&b->b.tri_s[(size_t)first * 9], tri_s, (size_t)n * 9 * sizeof(float));
     return GNXR_OK;
 }
 

@@ -854,9 +854,11 @@ bool compile_scene(const gnxr_scene_desc *d, CompiledScene *cs) {
     // dpdu / dpdv, the shading frame and dndu / dndv from them); everything else stays on the kernels with the defaults folded in.
     cs->tri_uv.clear();
     cs->tri_n.clear();
-    if (d->tri_uv || d->tri_n) {
+    cs->tri_s.clear();
+    if (d->tri_uv || d->tri_n || d->tri_s) {
         if (d->tri_uv) cs->tri_uv.assign((size_t)d->n_triangles * 8, 0.f);
         if (d->tri_n) cs->tri_n.assign((size_t)d->n_triangles * 12, 0.f);
+        if (d->tri_s) cs->tri_s.assign((size_t)d->n_triangles * 12, 0.f);
         std::vector<int> attr_copy(d->n_materials, -1);
         const float def[6] = {0, 0, 1, 0, 1, 1}, zero9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int li = 0; li < d->n_triangles; ++li) {
@@ -873,6 +875,13 @@ bool compile_scene(const gnxr_scene_desc *d, CompiledScene *cs) {
                 const bool hasN = memcmp(nn, zero9, 36) != 0;
                 if (hasN && d->tri_light[prim] >= 0) { set_error("triangle %d: per-vertex normals on an emissive triangle are not supported", prim); return false; }
                 custom = custom || hasN;
+            }
+            if (d->tri_s) {
+                const float *sv = d->tri_s + 9 * (size_t)prim;
+                memcpy(&cs->tri_s[(size_t)li * 12], sv, 36);
+                const bool hasS = memcmp(sv, zero9, 36) != 0;
+                if (hasS && d->tri_light[prim] >= 0) { set_error("triangle %d: per-vertex tangents on an emissive triangle are not supported", prim); return false; }
+                custom = custom || hasS;
             }
             DTri &t = cs->tris[li];
             if (t.material < 0 || !custom) continue;

@@ -214,8 +214,9 @@ typedef struct gnxr_scene_desc {
     const float *tri_n;         /* n_triangles * 9 or NULL: WORLD-space shading normals of each triangle's three corners = TriangleMesh::n
                                    looked up through the vertex indices (shape/Triangle.cpp:228-297: interpolated shading normal,
                                    shading frame, dndu / dndv, geometric normal flipped onto its side); three zero vectors == the
-                                   triangle has no normals.  Not allowed on emissive triangles.  Per-vertex tangents (TriangleMesh::s)
-                                   are not supported.                                                                        */
+                                   triangle has no normals.  Not allowed on emissive triangles.                                */
+    const float *tri_s;         /* n_triangles * 9 or NULL: WORLD-space shading tangents of the corners = TriangleMesh::s (the `ss`
+                                   of Triangle.cpp:242-250); three zero vectors == none.  Not allowed on emissive triangles.   */
 } gnxr_scene_desc;
 
 typedef enum gnxr_integrator {
@@ -390,6 +391,7 @@ int gnxr_builder_set_triangle_uv(gnxr_builder *b, int32_t first_triangle, int32_
 /* per-corner WORLD-space shading normals (n_triangles * 9 floats); a caller with object-space normals applies the mesh's
  * ObjectToWorld as TriangleMesh's constructor does (Transform::operator()(Normal3f): the inverse transpose) */
 int gnxr_builder_set_triangle_normals(gnxr_builder *b, int32_t first_triangle, int32_t n_triangles, const float *tri_n);
+int gnxr_builder_set_triangle_tangents(gnxr_builder *b, int32_t first_triangle, int32_t n_triangles, const float *tri_s);   /* TriangleMesh::s, world space */
 int gnxr_builder_add_sphere(gnxr_builder *b, const float center[3], float radius, int32_t material, int32_t medium_inside,
                             int32_t medium_outside);                                      /* returns the sphere index */
 int gnxr_builder_set_camera(gnxr_builder *b, const gnxr_camera *cam);

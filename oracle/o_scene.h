@@ -134,6 +134,7 @@ struct Scene {
     std::vector<ImageTexture> textures; // gnxr_material::kd_texture / ks_texture - 1
     std::vector<float> triUV;           // empty (Triangle::GetUVs defaults) or 6 floats per triangle, authoring order
     std::vector<float> triN;            // empty or 9 floats per triangle (TriangleMesh::n through the indices; zeros == none)
+    std::vector<float> triS;            // the same for TriangleMesh::s
     // BVH
     std::vector<LinearBVHNode> nodes;
     std::vector<int> orderedPrims;  // BVH leaf order -> authoring index (primitives.swap(orderedPrims), BVHAccel.cpp:171)
@@ -175,6 +176,7 @@ struct Scene {
         cameraMedium = d->camera_medium;
         if (d->tri_uv) triUV.assign(d->tri_uv, d->tri_uv + 6 * (size_t)d->n_triangles);
         if (d->tri_n) triN.assign(d->tri_n, d->tri_n + 9 * (size_t)d->n_triangles);
+        if (d->tri_s) triS.assign(d->tri_s, d->tri_s + 9 * (size_t)d->n_triangles);
         textures.resize(d->n_textures);
         for (int i = 0; i < d->n_textures; ++i) textures[i].Build(d->textures[i], d->texels + d->textures[i].texel_offset);
         if (d->n_spheres > 0) {
@@ -389,33 +391,49 @@ struct Scene {
         // Triangle.cpp:223-226 (no reverseOrientation / handedness swap on this path)
         si.n = si.sn = Normalize(Cross(dp02, dp12));
         si.p = b0 * p0 + b1 * p1 + b2 * p2;
-        // shading geometry of a triangle with per-vertex normals, Triangle.cpp:228-297 (mesh->s == nullptr, no reverseOrientation)
-        if (!triN.empty()) {
-            const float *q = &triN[9 * (size_t)tri];
-            V3 n0(q[0], q[1], q[2]), n1(q[3], q[4], q[5]), n2(q[6], q[7], q[8]);
-            if (n0 != V3() || n1 != V3() || n2 != V3()) {
-                V3 ns = (b0 * n0 + b1 * n1 + b2 * n2);
-                if (ns.LengthSquared() > 0) ns = Normalize(ns);
-                else ns = si.n;
-                V3 ss = Normalize(si.dpdu);
+        // shading geometry of a triangle with per-vertex normals and / or tangents, Triangle.cpp:228-297 (no reverseOrientation)
+        {
+            auto corner = [&](const std::vector<float> &tab, V3 *a, V3 *b, V3 *c) {
+                if (tab.empty()) return false;
+                const float *q = &tab[9 * (size_t)tri];
+                *a = V3(q[0], q[1], q[2]); *b = V3(q[3], q[4], q[5]); *c = V3(q[6], q[7], q[8]);
+                return *a != V3() || *b != V3() || *c != V3();
+            };
+            V3 n0, n1, n2, s0, s1, s2;
+            const bool hasN = corner(triN, &n0, &n1, &n2), hasS = corner(triS, &s0, &s1, &s2);
+            if (hasN || hasS) {
+                V3 ns;
+                if (hasN) {
+                    ns = (b0 * n0 + b1 * n1 + b2 * n2);
+                    if (ns.LengthSquared() > 0) ns = Normalize(ns);
+                    else ns = si.n;
+                } else ns = si.n;
+                V3 ss;
+                if (hasS) {
+                    ss = (b0 * s0 + b1 * s1 + b2 * s2);
+                    if (ss.LengthSquared() > 0) ss = Normalize(ss);
+                    else ss = Normalize(si.dpdu);
+                } else ss = Normalize(si.dpdu);
                 V3 ts = Cross(ss, ns);
                 if (ts.LengthSquared() > 0.f) {
                     ts = Normalize(ts);
                     ss = Cross(ts, ns);
                 } else CoordinateSystem(ns, &ss, &ts);
                 V3 dndu, dndv;
-                V3 dn1 = n0 - n2, dn2 = n1 - n2;
-                Float determinantN = duv02[0] * duv12[1] - duv02[1] * duv12[0];
-                bool degenerateUVN = std::abs(determinantN) < 1e-8;
-                if (degenerateUVN) {
-                    V3 dn = Cross(n2 - n0, n1 - n0);
-                    if (dn.LengthSquared() == 0) dndu = dndv = V3(0, 0, 0);
-                    else CoordinateSystem(dn, &dndu, &dndv);
-                } else {
-                    Float invDet = 1 / determinantN;
-                    dndu = (duv12[1] * dn1 - duv02[1] * dn2) * invDet;
-                    dndv = (-duv12[0] * dn1 + duv02[0] * dn2) * invDet;
-                }
+                if (hasN) {
+                    V3 dn1 = n0 - n2, dn2 = n1 - n2;
+                    Float determinantN = duv02[0] * duv12[1] - duv02[1] * duv12[0];
+                    bool degenerateUVN = std::abs(determinantN) < 1e-8;
+                    if (degenerateUVN) {
+                        V3 dn = Cross(n2 - n0, n1 - n0);
+                        if (dn.LengthSquared() == 0) dndu = dndv = V3(0, 0, 0);
+                        else CoordinateSystem(dn, &dndu, &dndv);
+                    } else {
+                        Float invDet = 1 / determinantN;
+                        dndu = (duv12[1] * dn1 - duv02[1] * dn2) * invDet;
+                        dndv = (-duv12[0] * dn1 + duv02[0] * dn2) * invDet;
+                    }
+                } else dndu = dndv = V3(0, 0, 0);
                 si.dndu = dndu; si.dndv = dndv;
                 si.SetShadingGeometry(ss, ts, true);   // shading.n = Normalize(Cross(ss, ts)); n = Faceforward(n, shading.n)
             }

@@ -95,6 +95,7 @@ struct SceneFile {
     std::vector<std::string> texturePaths;     // the image file each ImageTexture loads (the texels themselves stay behind)
     std::vector<float> triUV;                  // file version 3: empty or 6 floats per triangle
     std::vector<float> triN;                   // file version 4: empty or 9 floats per triangle (zeros == no normals)
+    std::vector<float> triS;                   // file version 5: the same for tangents
 };
 
 bool readScene(const char *path, SceneFile *s) {
@@ -131,6 +132,10 @@ bool readScene(const char *path, SceneFile *s) {
     if (ok && ver >= 4) {
         int32_t hasN = 0;
         ok = fread(&hasN, 4, 1, f) == 1 && (!hasN || rd(s->triN, 9 * (size_t)s->nt));
+    }
+    if (ok && ver >= 5) {
+        int32_t hasS = 0;
+        ok = fread(&hasS, 4, 1, f) == 1 && (!hasS || rd(s->triS, 9 * (size_t)s->nt));
     }
     fclose(f);
     return ok;
@@ -211,7 +216,13 @@ struct RefScene {
                 N[k] = Normal3f(sf.triN[9 * (size_t)t + 3 * k], sf.triN[9 * (size_t)t + 3 * k + 1], sf.triN[9 * (size_t)t + 3 * k + 2]);
                 hasN = hasN || N[k].x != 0 || N[k].y != 0 || N[k].z != 0;
             }
-            auto mesh = std::make_shared<TriangleMesh>(identity, 1, vi, 3, P, nullptr, hasN ? N : nullptr, sf.triUV.empty() ? nullptr : UV, nullptr);
+            Vector3f S[3];
+            bool hasS = false;
+            if (!sf.triS.empty()) for (int k = 0; k < 3; ++k) {
+                S[k] = Vector3f(sf.triS[9 * (size_t)t + 3 * k], sf.triS[9 * (size_t)t + 3 * k + 1], sf.triS[9 * (size_t)t + 3 * k + 2]);
+                hasS = hasS || S[k].x != 0 || S[k].y != 0 || S[k].z != 0;
+            }
+            auto mesh = std::make_shared<TriangleMesh>(identity, 1, vi, 3, P, hasS ? S : nullptr, hasN ? N : nullptr, sf.triUV.empty() ? nullptr : UV, nullptr);
             meshes.push_back(mesh);
             auto tri = std::make_shared<Triangle>(&identity, &identityInv, false, mesh, 0);
             shapes.push_back(tri);

@@ -174,7 +174,7 @@ def write_scene_file(builder, path):
         return C.string_at(ptr, n * C.sizeof(ct))
 
     with open(path, "wb") as f:
-        f.write(b"GNXS" + struct.pack("<i", 4))
+        f.write(b"GNXS" + struct.pack("<i", 5))
         f.write(struct.pack("<8i", nv, nt, d.n_materials, d.n_lights, d.n_media, d.env_width, d.env_height, d.camera_medium))
         f.write(bytes(d.camera))
         f.write(arr(d.vertices, 3 * nv, C.c_float))
@@ -210,6 +210,8 @@ def write_scene_file(builder, path):
         # per-corner shading normals (version 4)
         f.write(struct.pack("<i", 1 if d.tri_n else 0))
         f.write(arr(d.tri_n, 9 * nt, C.c_float))
+        f.write(struct.pack("<i", 1 if d.tri_s else 0))   # per-corner shading tangents (version 5)
+        f.write(arr(d.tri_s, 9 * nt, C.c_float))
 
 
 def run_ref(scene_path, cmd, in_bytes, args=(), stderr=None):

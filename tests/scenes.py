@@ -326,7 +326,14 @@ def smooth_cornell(tex_path, medium_ball=True):
     b.add_mesh(v, t, smile, uv=uv, normals=n)
     v, t, uv, n = uv_sphere_mesh((0.0, 0.0, 0.0), 1.0, 6, 8)
     m = np.array([[0.7, 0, 0, 1.4], [0, 0.35, 0, 0.9], [0, 0, 0.5, -0.8], [0, 0, 0, 1]], np.float32)
-    b.add_mesh(v, t, disney_preset(b), object_to_world=m, uv=uv, normals=n)
+    # per-vertex tangents (TriangleMesh::s) along the parallels; they vanish at the poles (the `ss.LengthSquared() > 0` fallback)
+    tang = np.stack([-n[:, 2], np.zeros(len(n), np.float32), n[:, 0]], 1).astype(np.float32)
+    b.add_mesh(v, t, disney_preset(b), object_to_world=m, uv=uv, normals=n, tangents=tang)
+    # tangents WITHOUT normals (`mesh->n || mesh->s`): a flat-shaded metal panel whose anisotropic frame follows the given tangents
+    quad = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+    panel = np.array([[-2.3, -2.45, 1.9], [-1.1, -2.45, 1.9], [-1.1, -2.1, 0.9], [-2.3, -2.1, 0.9]], np.float32)
+    aniso = b.add_material(type=gx._abi.MAT_METAL, eta=(0.2, 0.9, 1.1), k=(3.9, 2.4, 2.2), urough=0.05, vrough=0.3, remap_roughness=1)
+    b.add_mesh(panel, quad, aniso, tangents=[[1, 0, 0.4], [0.8, 0, 0.6], [0.6, 0.1, 0.8], [0.9, 0, 0.3]])
     if medium_ball:
         hom = gx.Medium()
         hom.type = gx._abi.MEDIUM_HOMOGENEOUS
