@@ -245,6 +245,10 @@ class SceneBuilder:
         cam = Camera(_f3(eye), _f3(look), _f3(up), fov, lens_radius, focal_distance, int(bool(orthographic)))
         _check(lib().gnxr_builder_set_camera(self._h, C.byref(cam)))
 
+    def set_bvh_split_method(self, method):
+        """BVHAccel(prims, 1, SplitMethod::SAH | SplitMethod::HLBVH) (accelerator/BVHAccel.h:24-29); the reference uses SAH."""
+        _check(lib().gnxr_builder_set_bvh_split_method(self._h, {"sah": 0, "hlbvh": 1}[method]))
+
     def set_camera_medium(self, medium):
         _check(lib().gnxr_builder_set_camera_medium(self._h, int(medium)))
 
@@ -267,6 +271,7 @@ class Scene:
         self._h = C.c_void_p()
         self._keep = builder_or_desc
         d = builder_or_desc.desc() if isinstance(builder_or_desc, SceneBuilder) else builder_or_desc
+        self.n_triangles = int(d.n_triangles)
         _check(lib().gnxr_scene_create(C.byref(d), C.byref(self._h)))
 
     def close(self):
@@ -282,6 +287,15 @@ class Scene:
         return {"bvh_nodes": n.value, "bvh_max_depth": dmax.value, "light_voxels": nv.value}
 
     # Aggregate seam: Scene::Intersect / IntersectP, batched
+    def bvh(self):
+        """Test hook: (bounds [n, 6], meta [n, 3] = offset / nPrimitives / axis, primitive order) of the flattened binary BVH."""
+        n = C.c_int64(0)
+        _check(lib().gnxr_scene_bvh(self._h, None, None, None, 0, C.byref(n)))
+        bounds = np.zeros((n.value, 6), np.float32); meta = np.zeros((n.value, 3), np.int32); order = np.zeros(self.n_triangles, np.int32)
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+        _check(lib().gnxr_scene_bvh(self._h, bounds.ctypes.data_as(C.POINTER(C.c_float)), ip(meta), ip(order), n.value, C.byref(n)))
+        return bounds, meta, order
+
     def light_grid_table(self, strategy="spatial", on_host=False):
         """Test hook: the light-selection table (device-built or host-built)."""
         code = {"spatial": _abi.LIGHTS_SPATIAL, "uniform": _abi.LIGHTS_UNIFORM, "power": _abi.LIGHTS_POWER}[strategy]

@@ -74,6 +74,7 @@ class SceneDesc(C.Structure):
         ("camera", Camera), ("camera_medium", i32), ("n_spheres", i32), ("spheres", C.POINTER(Sphere)),
         ("n_textures", i32), ("_pad", i32), ("textures", C.POINTER(Texture)), ("texels", C.POINTER(f32)),
         ("tri_uv", C.POINTER(f32)), ("tri_n", C.POINTER(f32)), ("tri_s", C.POINTER(f32)),
+        ("bvh_split_method", i32), ("_pad2", i32),
     ]
 
 
@@ -156,6 +157,8 @@ PROTOTYPES = {
     "gnxr_builder_set_triangle_uv": (C.c_int, [VP, i32, i32, P(f32)]),
     "gnxr_builder_set_triangle_normals": (C.c_int, [VP, i32, i32, P(f32)]),
     "gnxr_builder_set_triangle_tangents": (C.c_int, [VP, i32, i32, P(f32)]),
+    "gnxr_builder_set_bvh_split_method": (C.c_int, [VP, i32]),
+    "gnxr_scene_bvh": (C.c_int, [VP, P(f32), P(i32), P(i32), i64, P(i64)]),
     "gnxr_builder_set_camera": (C.c_int, [VP, P(Camera)]),
     "gnxr_builder_desc": (C.c_int, [VP, P(SceneDesc)]),
     "gnxr_write_synthetic_3d": (C.c_int, [C.c_char_p, i32, u32]),

@@ -9,6 +9,8 @@
 #include <mutex>
 #include <vector>
 
+#include <hipcub/hipcub.hpp>
+
 #include "host_scene.h"
 #include "kernels.hip.h"
 #include "kernel_instances.h"
@@ -220,6 +222,46 @@ struct gnxr_scene {
     }
 };
 
+// ---- HLBVH, the device stage (BVHAccel.cpp:377-397): Morton codes of the centroids and the stable radix sort by code.
+// Bounds3::Offset (Geometry.h), `centroidOffset * mortonScale`, EncodeMorton3 / LeftShift3 (BVHAccel.cpp:68-100).
+namespace {
+__device__ __forceinline__ uint32_t left_shift3(uint32_t x) {
+    if (x == (1u << 10)) --x;
+    x = (x | (x << 16)) & 0x30000ffu;
+    x = (x | (x << 8)) & 0x300f00fu;
+    x = (x | (x << 4)) & 0x30c30c3u;
+    x = (x | (x << 2)) & 0x9249249u;
+    return x;
+}
+__global__ void __launch_bounds__(kBlock) k_morton_codes(const float *__restrict__ cen, int n, float lx, float ly, float lz, float hx, float hy, float hz,
+                                                         uint32_t *__restrict__ codes, uint32_t *__restrict__ prims) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float ox = cen[3 * (size_t)i] - lx, oy = cen[3 * (size_t)i + 1] - ly, oz = cen[3 * (size_t)i + 2] - lz;
+        if (hx > lx) ox /= hx - lx;
+        if (hy > ly) oy /= hy - ly;
+        if (hz > lz) oz /= hz - lz;
+        const float sc = (float)(1 << 10);   // mortonScale
+        codes[i] = (left_shift3((uint32_t)(oz * sc)) << 2) | (left_shift3((uint32_t)(oy * sc)) << 1) | left_shift3((uint32_t)(ox * sc));
+        prims[i] = (uint32_t)i;
+    }
+}
+bool device_morton_sort(const float *centroids3, int n, const float lo[3], const float hi[3], uint32_t *codes_sorted, uint32_t *prims_sorted) {
+    if (ensure_device() != GNXR_OK) return false;
+    DevBuf<float> d_cen;
+    DevBuf<uint32_t> k_in, k_out, v_in, v_out;
+    DevBuf<unsigned char> tmp;
+    if (d_cen.upload(centroids3, 3 * (size_t)n) || k_in.alloc(n) || k_out.alloc(n) || v_in.alloc(n) || v_out.alloc(n)) return false;
+    hipLaunchKernelGGL(k_morton_codes, dim3(grid_for(n)), dim3(kBlock), 0, 0, (const float *)d_cen.p, n, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], k_in.p, v_in.p);
+    size_t bytes = 0;   // RadixSort sorts the 30 Morton bits, least significant digit first: a stable sort by the code (BVHAccel.cpp:102-141)
+    if (hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k_in.p, k_out.p, v_in.p, v_out.p, n, 0, 30) != hipSuccess) return false;
+    if (tmp.alloc(bytes)) return false;
+    if (hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes, k_in.p, k_out.p, v_in.p, v_out.p, n, 0, 30) != hipSuccess) return false;
+    if (hipMemcpy(codes_sorted, k_out.p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    if (hipMemcpy(prims_sorted, v_out.p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    return true;
+}
+}  // namespace
+
 extern "C" {
 
 int gnxr_init(int device_id) {
@@ -248,7 +290,7 @@ int gnxr_scene_create(const gnxr_scene_desc *desc, gnxr_scene **out) {
     if (rc) return rc;
     gnxr_scene *s = new (std::nothrow) gnxr_scene();
     if (!s) return GNXR_ERR_OOM;
-    if (!compile_scene(desc, &s->cs)) { delete s; return GNXR_ERR_INVALID; }
+    if (!compile_scene(desc, &s->cs, device_morton_sort)) { delete s; return GNXR_ERR_INVALID; }
     CompiledScene &cs = s->cs;
     if (cs.bvh_max_depth + 1 > 64) { set_error("BVH depth %d exceeds the 64-entry traversal stack (BVHAccel.cpp:661)", cs.bvh_max_depth); delete s; return GNXR_ERR_UNSUPPORTED; }
     s->stack_size = cs.bvh_max_depth + 1 <= 32 ? 32 : 64;
@@ -674,6 +716,22 @@ int gnxr_render(gnxr_scene *s, const gnxr_render_params *p, float *rgba_out, gnx
             if ((y / sr) % sc == p->shard_index)
                 HIP_TRY(hipMemcpy(rgba_out + (size_t)y * p->width * 4, s->out.p + (size_t)y * p->width, (size_t)p->width * sizeof(float4), hipMemcpyDeviceToHost));
     }
+    return GNXR_OK;
+}
+
+int gnxr_scene_bvh(const gnxr_scene *s, float *bounds6, int32_t *meta3, int32_t *ordered, int64_t node_capacity, int64_t *n_nodes) {
+    if (!s || !n_nodes) { set_error("bad argument"); return GNXR_ERR_INVALID; }
+    const CompiledScene &cs = s->cs;
+    *n_nodes = (int64_t)cs.nodes.size();
+    if (!bounds6 || !meta3 || !ordered || node_capacity < *n_nodes) return GNXR_OK;
+    for (size_t i = 0; i < cs.nodes.size(); ++i) {
+        const DNode &n = cs.nodes[i];
+        bounds6[6 * i + 0] = n.lo[0]; bounds6[6 * i + 1] = n.lo[1]; bounds6[6 * i + 2] = n.lo[2];
+        bounds6[6 * i + 3] = n.hi0; bounds6[6 * i + 4] = n.hi1; bounds6[6 * i + 5] = n.hi2;
+        const int nPrims = (int)(n.meta & 0xffffu);
+        meta3[3 * i + 0] = n.offset; meta3[3 * i + 1] = nPrims; meta3[3 * i + 2] = nPrims ? 0 : (int)(n.meta >> 16);
+    }
+    for (size_t i = 0; i < cs.tris.size(); ++i) ordered[i] = cs.tris[i].prim;
     return GNXR_OK;
 }
 

@@ -31,6 +31,7 @@ struct Builder {
     int env_w = 0, env_h = 0;
     gnxr_camera camera;
     int camera_medium = -1;
+    int bvh_split_method = 0;
     Builder();
     int add_mesh(const float *verts, int nv, const int32_t *idx, int nt, const Xf &o2w, int material, int med_in, int med_out);
     void fill_desc(gnxr_scene_desc *d) const;
@@ -87,7 +88,10 @@ struct CompiledScene {
     std::vector<gnxr_light> desc_lights;
 };
 
-bool compile_scene(const gnxr_scene_desc *d, CompiledScene *out);
+// HLBVH (GNXR_BVH_HLBVH): Morton codes of the primitive centroids inside [lo, hi] (BVHAccel.cpp:378-394) and the stable radix sort
+// of (code, primitive) pairs by code (:397, RadixSort :102-141) are the caller's (api.hip: on the device); n entries each.
+typedef bool (*MortonSortFn)(const float *centroids3, int n, const float lo[3], const float hi[3], uint32_t *codes_sorted, uint32_t *prims_sorted);
+bool compile_scene(const gnxr_scene_desc *d, CompiledScene *out, MortonSortFn morton_sort = nullptr);
 DCamera make_camera(const gnxr_camera &c, int W, int H, int medium);      // camera/Perspective.cpp:114-135, core/Camera.h:54-75
 DHalton make_halton(int W, int H);                                          // samplers/HaltonSampler.cpp:33-60
 // light-selection table: dense restatement of core/LightDistribution.cpp (uniform / power / spatial)

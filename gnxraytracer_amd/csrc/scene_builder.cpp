@@ -201,6 +201,7 @@ void Builder::fill_desc(gnxr_scene_desc *d) const {
     d->tri_uv = tri_uv.empty() ? nullptr : tri_uv.data();
     d->tri_n = tri_n.empty() ? nullptr : tri_n.data();
     d->tri_s = tri_s.empty() ? nullptr : tri_s.data();
+    d->bvh_split_method = bvh_split_method;
 }
 
 // ---- `.3d` text meshes: shape/plyRead.h:19-48 ----
@@ -684,6 +685,12 @@ int gnxr_builder_add_sphere(gnxr_builder *b, const float center[3], float radius
 int gnxr_builder_set_camera(gnxr_builder *b, const gnxr_camera *cam) {
     if (!b || !cam) return GNXR_ERR_INVALID;
     b->b.camera = *cam;
+    return GNXR_OK;
+}
+
+int gnxr_builder_set_bvh_split_method(gnxr_builder *b, int32_t method) {
+    if (!b || (method != GNXR_BVH_SAH && method != GNXR_BVH_HLBVH)) return GNXR_ERR_INVALID;
+    b->b.bvh_split_method = method;
     return GNXR_OK;
 }
 

@@ -217,7 +217,16 @@ typedef struct gnxr_scene_desc {
                                    triangle has no normals.  Not allowed on emissive triangles.                                */
     const float *tri_s;         /* n_triangles * 9 or NULL: WORLD-space shading tangents of the corners = TriangleMesh::s (the `ss`
                                    of Triangle.cpp:242-250); three zero vectors == none.  Not allowed on emissive triangles.   */
+    int32_t bvh_split_method;   /* gnxr_bvh_split_method: how BVHAccel(prims, 1, splitMethod) builds the tree */
+    int32_t _pad2;
 } gnxr_scene_desc;
+
+/* enum class SplitMethod, accelerator/BVHAccel.h:24 (same order).  The reference builds BVHAccel(prims, 1) = SAH. */
+typedef enum gnxr_bvh_split_method {
+    GNXR_BVH_SAH = 0,    /* recursiveBuild with the surface-area heuristic, BVHAccel.cpp:191-367 (host)                          */
+    GNXR_BVH_HLBVH = 1   /* HLBVHBuild, BVHAccel.cpp:369-626: Morton codes + radix sort on the device, LBVH treelets and the SAH
+                            upper tree over at most 4096 treelets on the host                                                   */
+} gnxr_bvh_split_method;
 
 typedef enum gnxr_integrator {
     GNXR_INTEGRATOR_PATH = 0,    /* integrators/PathIntegrator.cpp:62-208   */
@@ -297,6 +306,10 @@ int gnxr_set_profiling(int flags);
 /* -- scene (replaces `Scene(make_shared<BVHAccel>(prims,1), lights)`, RenderThread.cpp:155) */
 int gnxr_scene_create(const gnxr_scene_desc *desc, gnxr_scene **out);
 void gnxr_scene_destroy(gnxr_scene *scene);
+/* Test hook: the flattened binary BVH (the reference's LinearBVHNode[]: per node 6 floats of bounds into `bounds6`, then
+ * offset / nPrimitives / axis into `meta3`) and the primitive order (`ordered`, n_triangles entries); *n_nodes receives the node
+ * count, arrays are filled when node_capacity allows. */
+int gnxr_scene_bvh(const gnxr_scene *scene, float *bounds6, int32_t *meta3, int32_t *ordered, int64_t node_capacity, int64_t *n_nodes);
 int gnxr_scene_info(const gnxr_scene *scene, int32_t *n_bvh_nodes, int32_t *bvh_max_depth,
                     int32_t *n_light_voxels);
 
@@ -395,6 +408,7 @@ int gnxr_builder_set_triangle_tangents(gnxr_builder *b, int32_t first_triangle, 
 int gnxr_builder_add_sphere(gnxr_builder *b, const float center[3], float radius, int32_t material, int32_t medium_inside,
                             int32_t medium_outside);                                      /* returns the sphere index */
 int gnxr_builder_set_camera(gnxr_builder *b, const gnxr_camera *cam);
+int gnxr_builder_set_bvh_split_method(gnxr_builder *b, int32_t method);               /* gnxr_bvh_split_method */
 int gnxr_builder_set_camera_medium(gnxr_builder *b, int32_t medium);                  /* Camera::medium, core/Camera.h; -1 == none */                 /* RenderThread.cpp:60-68 */
 /* The returned description points into builder-owned memory, valid until the next builder
  * call or gnxr_builder_destroy.                                                            */

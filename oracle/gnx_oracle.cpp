@@ -53,6 +53,22 @@ int gnxo_scene_bvh(const gnxo_scene *s, float *bounds6, int32_t *offset, int32_t
     return 0;
 }
 
+// Replace the scene's BVH by one handed in (bounds6 / offset / nprims / axis per node, leaf order -> authoring index): lets the
+// oracle traverse the tree the compiled reference built with another SplitMethod (HLBVH) without restating that builder.
+int gnxo_scene_set_bvh(gnxo_scene *s, const float *bounds6, const int32_t *offset, const int32_t *nprims, const int32_t *axis, int64_t nNodes,
+                       const int32_t *ordered, int64_t nOrdered) {
+    Scene &sc = s->scene;
+    sc.nodes.assign((size_t)nNodes, LinearBVHNode());
+    for (int64_t i = 0; i < nNodes; ++i) {
+        LinearBVHNode &n = sc.nodes[i];
+        n.bounds.pMin = V3(bounds6[6 * i + 0], bounds6[6 * i + 1], bounds6[6 * i + 2]);
+        n.bounds.pMax = V3(bounds6[6 * i + 3], bounds6[6 * i + 4], bounds6[6 * i + 5]);
+        n.offset = offset[i]; n.nPrimitives = (uint16_t)nprims[i]; n.axis = (uint8_t)axis[i]; n.pad = 0;
+    }
+    sc.orderedPrims.assign(ordered, ordered + nOrdered);
+    return 0;
+}
+
 // SamplerIntegrator::Render, core/Integrator.cpp:225-319.  The pixel loop ignores pixelBounds.pMin,
 // box-averages without rayWeight and writes (x + y*W)*4 + c (ui/FrameBuffer.h:136).  The two libc
 // rand() draws (:262-263) do not reach any output and are not reproduced.

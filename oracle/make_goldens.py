@@ -232,6 +232,7 @@ def main():
     texture_goldens()
     delta_goldens()
     ortho_goldens()
+    hlbvh_goldens()
     # cfg 2 at full size: the counts the survey recorded from the COMPLETE reference
     img, cnt = render(cornell_path, 256, 256, 64)
     checksum = float(img[..., :3].astype(np.float64).sum())
@@ -381,6 +382,34 @@ def ortho_goldens():
     save("render_ortho.npz", **out)
 
 
+def hlbvh_goldens():
+    # ---- 17: BVHAccel(prims, 1, SplitMethod::HLBVH) of the compiled reference: the flattened LinearBVHNode[] and primitive order for
+    # the 2k-triangle mesh scene and the material zoo, and images rendered through that tree (oracle traversing the dumped tree)
+    mesh = os.path.join(G, "mesh_2k.3d")
+    out = {}
+    for name, b in [("mesh2k", scenes.dragon_cornell(2000, "glass+metal", mesh_path=mesh)), ("smooth", scenes.smooth_cornell(os.path.join(G, "tex_smile_96x80.hdr")))]:
+        b.set_bvh_split_method("hlbvh")
+        path = scene_file(b, "hlbvh_" + name)
+        raw = ol.run_ref(path, "bvh", None)
+        nn = struct.unpack("<i", raw[:4])[0]
+        rec = np.frombuffer(raw[4:4 + nn * 36], np.uint8).reshape(nn, 36)
+        out[name + "_bounds"] = rec[:, :24].copy().view(np.float32).reshape(nn, 6)
+        out[name + "_meta"] = rec[:, 24:].copy().view(np.int32).reshape(nn, 3)
+        out[name + "_order"] = np.frombuffer(raw[4 + nn * 36:], np.int32).copy()
+        W, H, spp, depth = 64, 48, 8, 5
+        raw = ol.run_ref(path, "render", None, [W, H, spp, depth, 1.0, 0, 0, 0])
+        out[name + "_img"] = np.frombuffer(raw[:W * H * 16], np.float32).reshape(H, W, 4).copy()
+        out[name + "_rays"] = np.frombuffer(raw[W * H * 16:W * H * 16 + 16], np.uint64).copy()
+        osc = ol.OracleScene(b)
+        osc.set_bvh(out[name + "_bounds"], out[name + "_meta"], out[name + "_order"])
+        oimg, st = osc.render(gx.PathIntegrator(depth, 1.0, "spatial"), W, H, spp)
+        same = oimg.view(np.uint32) == out[name + "_img"].view(np.uint32)
+        print("hlbvh", name, "nodes", nn, "rays", out[name + "_rays"], (st["rays_closest"], st["rays_any"]), "identical %.3f%%" % (100 * same.mean()))
+        assert same.all()
+    out["cfg"] = np.array([64, 48, 8, 5], np.int32)
+    save("bvh_hlbvh.npz", **out)
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["direct"]:   # only section 13
         direct_goldens(scene_file(scenes.cornell(), "cornell"), scene_file(scenes.material_zoo(), "zoo"))
@@ -390,5 +419,7 @@ if __name__ == "__main__":
         delta_goldens()
     elif sys.argv[1:] == ["ortho"]:      # only section 16
         ortho_goldens()
+    elif sys.argv[1:] == ["hlbvh"]:      # only section 17
+        hlbvh_goldens()
     else:
         main()

@@ -96,6 +96,7 @@ struct SceneFile {
     std::vector<float> triUV;                  // file version 3: empty or 6 floats per triangle
     std::vector<float> triN;                   // file version 4: empty or 9 floats per triangle (zeros == no normals)
     std::vector<float> triS;                   // file version 5: the same for tangents
+    int32_t splitMethod = 0;                   // file version 6: BVHAccel::SplitMethod
 };
 
 bool readScene(const char *path, SceneFile *s) {
@@ -137,6 +138,7 @@ bool readScene(const char *path, SceneFile *s) {
         int32_t hasS = 0;
         ok = fread(&hasS, 4, 1, f) == 1 && (!hasS || rd(s->triS, 9 * (size_t)s->nt));
     }
+    if (ok && ver >= 6) ok = fread(&s->splitMethod, 4, 1, f) == 1;
     fclose(f);
     return ok;
 }
@@ -256,7 +258,7 @@ struct RefScene {
                 else lights[i] = std::make_shared<DistantLight>(l2w, S3(l.le), Vector3f(l.center[0], l.center[1], l.center[2]));
             }
         }
-        bvh = std::make_shared<BVHAccel>(prims, 1);
+        bvh = std::make_shared<BVHAccel>(prims, 1, sf.splitMethod == 1 ? BVHAccel::SplitMethod::HLBVH : BVHAccel::SplitMethod::SAH);
         counting = std::make_shared<CountingAggregate>(bvh);
         scene.reset(new Scene(counting, lights));
     }

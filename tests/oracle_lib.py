@@ -80,6 +80,13 @@ class OracleScene:
         olib().gnxo_scene_bvh(self._h, _fp(b), ip(off), ip(npr), ip(ax), ip(order))
         return b, off, npr, ax, order
 
+    def set_bvh(self, bounds, meta, order):
+        """Traverse a BVH handed in (e.g. the one the compiled reference built with SplitMethod::HLBVH) instead of the oracle's own."""
+        bounds = np.ascontiguousarray(bounds, np.float32); order = np.ascontiguousarray(order, np.int32)
+        cols = [np.ascontiguousarray(meta[:, k], np.int32) for k in range(3)]
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+        olib().gnxo_scene_set_bvh(self._h, _fp(bounds), ip(cols[0]), ip(cols[1]), ip(cols[2]), C.c_int64(len(bounds)), ip(order), C.c_int64(len(order)))
+
     def render(self, integrator, width, height, spp, threads=0, count_traversal=False, **kw):
         p = integrator.params(width, height, spp, **kw)
         img = np.zeros((height, width, 4), np.float32)
@@ -174,7 +181,7 @@ def write_scene_file(builder, path):
         return C.string_at(ptr, n * C.sizeof(ct))
 
     with open(path, "wb") as f:
-        f.write(b"GNXS" + struct.pack("<i", 5))
+        f.write(b"GNXS" + struct.pack("<i", 6))
         f.write(struct.pack("<8i", nv, nt, d.n_materials, d.n_lights, d.n_media, d.env_width, d.env_height, d.camera_medium))
         f.write(bytes(d.camera))
         f.write(arr(d.vertices, 3 * nv, C.c_float))
@@ -212,6 +219,7 @@ def write_scene_file(builder, path):
         f.write(arr(d.tri_n, 9 * nt, C.c_float))
         f.write(struct.pack("<i", 1 if d.tri_s else 0))   # per-corner shading tangents (version 5)
         f.write(arr(d.tri_s, 9 * nt, C.c_float))
+        f.write(struct.pack("<i", d.bvh_split_method))     # BVHAccel SplitMethod (version 6)
 
 
 def run_ref(scene_path, cmd, in_bytes, args=(), stderr=None):
