@@ -246,8 +246,8 @@ class SceneBuilder:
         _check(lib().gnxr_builder_set_camera(self._h, C.byref(cam)))
 
     def set_bvh_split_method(self, method):
-        """BVHAccel(prims, 1, SplitMethod::SAH | SplitMethod::HLBVH) (accelerator/BVHAccel.h:24-29); the reference uses SAH."""
-        _check(lib().gnxr_builder_set_bvh_split_method(self._h, {"sah": 0, "hlbvh": 1}[method]))
+        """BVHAccel(prims, 1, SplitMethod::SAH | HLBVH | Middle | EqualCounts) (accelerator/BVHAccel.h:24-29); the reference uses SAH."""
+        _check(lib().gnxr_builder_set_bvh_split_method(self._h, {"sah": 0, "hlbvh": 1, "middle": 2, "equal_counts": 3}[method]))
 
     def set_camera_medium(self, medium):
         _check(lib().gnxr_builder_set_camera_medium(self._h, int(medium)))

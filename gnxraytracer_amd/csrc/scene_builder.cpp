@@ -689,7 +689,7 @@ int gnxr_builder_set_camera(gnxr_builder *b, const gnxr_camera *cam) {
 }
 
 int gnxr_builder_set_bvh_split_method(gnxr_builder *b, int32_t method) {
-    if (!b || (method != GNXR_BVH_SAH && method != GNXR_BVH_HLBVH)) return GNXR_ERR_INVALID;
+    if (!b || method < GNXR_BVH_SAH || method > GNXR_BVH_EQUAL_COUNTS) return GNXR_ERR_INVALID;
     b->b.bvh_split_method = method;
     return GNXR_OK;
 }

@@ -24,6 +24,7 @@ struct BvhBuilder {
     std::vector<PrimInfo> info;
     std::vector<BuildNode> nodes;
     std::vector<int> ordered;
+    int method = GNXR_BVH_SAH;   // SAH, Middle or EqualCounts for build(); HLBVH has build_hlbvh()
 
     int build(int start, int end) {
         int me = (int)nodes.size();
@@ -43,7 +44,16 @@ struct BvhBuilder {
         int dim = cb.max_extent();
         int mid = (start + end) / 2;
         if (cb.hi[dim] == cb.lo[dim]) return leaf();
-        if (n <= 2) {
+        bool partitioned = false;
+        if (method == GNXR_BVH_MIDDLE) {   // BVHAccel.cpp:243-258; falls through to EqualCounts when everything lands on one side
+            float pmid = (cb.lo[dim] + cb.hi[dim]) / 2;
+            PrimInfo *midPtr = std::partition(&info[start], &info[end - 1] + 1, [dim, pmid](const PrimInfo &pi) { return pi.c[dim] < pmid; });
+            mid = (int)(midPtr - &info[0]);
+            partitioned = mid != start && mid != end;
+            if (!partitioned) mid = (start + end) / 2;
+        }
+        if (partitioned) {
+        } else if (n <= 2 || method == GNXR_BVH_MIDDLE || method == GNXR_BVH_EQUAL_COUNTS) {   // EqualCounts, BVHAccel.cpp:259-268 (and SAH with <= 2 primitives, :273-282)
             std::nth_element(&info[start], &info[mid], &info[end - 1] + 1,
                              [dim](const PrimInfo &a, const PrimInfo &b) { return a.c[dim] < b.c[dim]; });
         } else {
@@ -75,8 +85,10 @@ struct BvhBuilder {
             });
             mid = (int)(pmid - &info[0]);
         }
-        int c0 = build(start, mid);
+        // `node->InitInterior(dim, recursiveBuild(.., start, mid, ..), recursiveBuild(.., mid, end, ..))` (BVHAccel.cpp:355-360): g++
+        // evaluates the arguments right to left, so the SECOND half is built first and its primitives come first in orderedPrims
         int c1 = build(mid, end);
+        int c0 = build(start, mid);
         nodes[me].child[0] = c0; nodes[me].child[1] = c1;
         Box3 u = nodes[c0].b; u.grow(nodes[c1].b);
         nodes[me].b = u; nodes[me].axis = dim; nodes[me].n = 0;
@@ -903,7 +915,8 @@ bool compile_scene(const gnxr_scene_desc *d, CompiledScene *cs, MortonSortFn mor
     }
     bb.nodes.reserve(2 * (size_t)d->n_triangles);
     bb.ordered.reserve(d->n_triangles);
-    if (d->bvh_split_method != GNXR_BVH_SAH && d->bvh_split_method != GNXR_BVH_HLBVH) { set_error("unknown BVH split method %d", d->bvh_split_method); return false; }
+    if (d->bvh_split_method < GNXR_BVH_SAH || d->bvh_split_method > GNXR_BVH_EQUAL_COUNTS) { set_error("unknown BVH split method %d", d->bvh_split_method); return false; }
+    bb.method = d->bvh_split_method;
     int root = d->bvh_split_method == GNXR_BVH_HLBVH ? bb.build_hlbvh(morton_sort) : bb.build(0, d->n_triangles);
     if (root < 0) return false;
     cs->nodes.clear();

@@ -224,8 +224,10 @@ typedef struct gnxr_scene_desc {
 /* enum class SplitMethod, accelerator/BVHAccel.h:24 (same order).  The reference builds BVHAccel(prims, 1) = SAH. */
 typedef enum gnxr_bvh_split_method {
     GNXR_BVH_SAH = 0,    /* recursiveBuild with the surface-area heuristic, BVHAccel.cpp:191-367 (host)                          */
-    GNXR_BVH_HLBVH = 1   /* HLBVHBuild, BVHAccel.cpp:369-626: Morton codes + radix sort on the device, LBVH treelets and the SAH
+    GNXR_BVH_HLBVH = 1,  /* HLBVHBuild, BVHAccel.cpp:369-626: Morton codes + radix sort on the device, LBVH treelets and the SAH
                             upper tree over at most 4096 treelets on the host                                                   */
+    GNXR_BVH_MIDDLE = 2, /* recursiveBuild, split at the midpoint of the centroid bounds, BVHAccel.cpp:243-258 (host)            */
+    GNXR_BVH_EQUAL_COUNTS = 3 /* recursiveBuild, nth_element at the median, BVHAccel.cpp:259-268 (host)                          */
 } gnxr_bvh_split_method;
 
 typedef enum gnxr_integrator {

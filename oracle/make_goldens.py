@@ -387,8 +387,11 @@ def hlbvh_goldens():
     # the 2k-triangle mesh scene and the material zoo, and images rendered through that tree (oracle traversing the dumped tree)
     mesh = os.path.join(G, "mesh_2k.3d")
     out = {}
-    for name, b in [("mesh2k", scenes.dragon_cornell(2000, "glass+metal", mesh_path=mesh)), ("smooth", scenes.smooth_cornell(os.path.join(G, "tex_smile_96x80.hdr")))]:
-        b.set_bvh_split_method("hlbvh")
+    for name, method, b in [("mesh2k", "hlbvh", scenes.dragon_cornell(2000, "glass+metal", mesh_path=mesh)),
+                            ("smooth", "hlbvh", scenes.smooth_cornell(os.path.join(G, "tex_smile_96x80.hdr"))),
+                            ("middle", "middle", scenes.dragon_cornell(2000, "glass+metal", mesh_path=mesh)),
+                            ("equal", "equal_counts", scenes.dragon_cornell(2000, "glass+metal", mesh_path=mesh))]:
+        b.set_bvh_split_method(method)
         path = scene_file(b, "hlbvh_" + name)
         raw = ol.run_ref(path, "bvh", None)
         nn = struct.unpack("<i", raw[:4])[0]

@@ -258,7 +258,8 @@ struct RefScene {
                 else lights[i] = std::make_shared<DistantLight>(l2w, S3(l.le), Vector3f(l.center[0], l.center[1], l.center[2]));
             }
         }
-        bvh = std::make_shared<BVHAccel>(prims, 1, sf.splitMethod == 1 ? BVHAccel::SplitMethod::HLBVH : BVHAccel::SplitMethod::SAH);
+        bvh = std::make_shared<BVHAccel>(prims, 1, sf.splitMethod == 1 ? BVHAccel::SplitMethod::HLBVH : sf.splitMethod == 2 ? BVHAccel::SplitMethod::Middle
+                                                  : sf.splitMethod == 3 ? BVHAccel::SplitMethod::EqualCounts : BVHAccel::SplitMethod::SAH);
         counting = std::make_shared<CountingAggregate>(bvh);
         scene.reset(new Scene(counting, lights));
     }

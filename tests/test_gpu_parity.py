@@ -567,18 +567,22 @@ def test_light_grid_with_many_lights(gpu):
         assert biteq(img[..., :3], oimg[..., :3])
 
 
-@pytest.mark.parametrize("name", ["mesh2k", "smooth"])
+@pytest.mark.parametrize("name", ["mesh2k", "smooth", "middle", "equal", "sah"])
 def test_hlbvh_build_matches_reference(gpu, name):
     """GNXR_BVH_HLBVH: Morton codes + radix sort on the device, LBVH treelets and the SAH upper tree on the host must
     give the LinearBVHNode[] and primitive order of the reference's BVHAccel(prims, 1, SplitMethod::HLBVH), bit for bit; rendering
     through it gives the reference's image and ray counts, and the traversal statistics of the oracle walking the same tree."""
     g = golden("bvh_hlbvh.npz")
     W, H, spp, depth = (int(v) for v in g["cfg"])
-    b = scenes.dragon_cornell(2000, "glass+metal", mesh_path=os.path.join(GOLDEN, "mesh_2k.3d")) if name == "mesh2k" else \
-        scenes.smooth_cornell(os.path.join(GOLDEN, "tex_smile_96x80.hdr"))
-    b.set_bvh_split_method("hlbvh")
+    b = scenes.smooth_cornell(os.path.join(GOLDEN, "tex_smile_96x80.hdr")) if name == "smooth" else \
+        scenes.dragon_cornell(2000, "glass+metal", mesh_path=os.path.join(GOLDEN, "mesh_2k.3d"))
+    b.set_bvh_split_method({"middle": "middle", "equal": "equal_counts", "sah": "sah"}.get(name, "hlbvh"))   # the other BVHAccel::SplitMethod values ride along
     scene = gpu.Scene(b)
     bounds, meta, order = scene.bvh()
+    if name == "sah":   # the default build against the dump of BVHAccel(prims, 1) that pins the oracle (bvh_mesh2k.npz)
+        gs = golden("bvh_mesh2k.npz")
+        assert biteq(bounds, gs["bounds"]) and (meta == gs["meta"]).all() and (order == gs["order"]).all()
+        return
     assert bounds.shape == g[name + "_bounds"].shape and biteq(bounds, g[name + "_bounds"])
     assert (meta == g[name + "_meta"]).all() and (order == g[name + "_order"]).all()
     integ = gpu.PathIntegrator(depth, 1.0, "spatial")

@@ -264,13 +264,13 @@ def test_orthographic_camera_images(name, gx):
     assert biteq(img, g[name])
 
 def _hlbvh_scene(name):
-    b = scenes.dragon_cornell(2000, "glass+metal", mesh_path=os.path.join(GOLDEN, "mesh_2k.3d")) if name == "mesh2k" else \
-        scenes.smooth_cornell(os.path.join(GOLDEN, "tex_smile_96x80.hdr"))
-    b.set_bvh_split_method("hlbvh")
+    b = scenes.smooth_cornell(os.path.join(GOLDEN, "tex_smile_96x80.hdr")) if name == "smooth" else \
+        scenes.dragon_cornell(2000, "glass+metal", mesh_path=os.path.join(GOLDEN, "mesh_2k.3d"))
+    b.set_bvh_split_method({"middle": "middle", "equal": "equal_counts"}.get(name, "hlbvh"))   # the other BVHAccel::SplitMethod values ride along
     return b
 
 
-@pytest.mark.parametrize("name", ["mesh2k", "smooth"])
+@pytest.mark.parametrize("name", ["mesh2k", "smooth", "middle", "equal"])
 def test_oracle_traverses_the_reference_hlbvh_tree(name, gx):
     """BVHAccel(prims, 1, SplitMethod::HLBVH) of the compiled reference, dumped as LinearBVHNode[] + primitive order: the oracle
     traverses that tree (it does not restate the HLBVH builder) and reproduces the image and ray counts the reference rendered
