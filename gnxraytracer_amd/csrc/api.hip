@@ -498,7 +498,8 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
             // rays per atomic: kTraceChunk for big launches; for thin ones (late bounces) small enough that every wave gets a chunk --
             // the number of atomics stays <= the number of waves, well under the ~88/us a single address sustains
             const long long waves = (long long)blocks * (kBlock / 64);
-            const int chunk = (int)std::min<long long>(kTraceChunk, std::max<long long>(64, ((total + waves - 1) / waves + 63) / 64 * 64));
+            static const int chunk_max = getenv("GNXR_TRACE_CHUNK") ? std::max(64, atoi(getenv("GNXR_TRACE_CHUNK")) / 64 * 64) : kTraceChunk;   // tuning knob
+            const int chunk = (int)std::min<long long>(chunk_max, std::max<long long>(64, ((total + waves - 1) / waves + 63) / 64 * 64));
 #define GX_TRACE(C, W, S) hipLaunchKernelGGL((k_trace<C, W, S>), dim3(blocks), dim3(kBlock), lds, stream, sc, pa, w, &dctr->cursor, dctr, lds_entries, s->trace_spill.p, chunk)
             if (spheres) {
                 if (counting) GX_TRACE(true, false, true); else if (wide) GX_TRACE(false, true, true); else GX_TRACE(false, false, true);
