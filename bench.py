@@ -229,7 +229,8 @@ def main():
             dist.destroy_process_group()
         return
 
-    spp_done = min(args.steps * sps, args.spp)
+    spp_timed = args.steps * sps                 # samples per pixel traced inside the timed region (wraps around the Halton range beyond --spp)
+    spp_done = min(spp_timed, args.spp)
     detail = "Mrays/s (path tracing, closest-hit + shadow + MIS rays), " + ("volume Cornell 512x512 (cfg 5)" if args.workload == "cfg5" else "dragon-stand-in Cornell 1920x1080")
     metric = detail
     if args.workload == "cfg3":   # the headline metric under BASELINE.json's own name: `value` is its Mrays/s half, `wall_to_1024spp_s` the other
@@ -255,15 +256,15 @@ def main():
                                f"VolPathIntegrator maxDepth {args.max_depth} rr 1 spatial, Halton({args.spp}), {W}x{H}" if args.workload == "cfg5" else
                                f"cfg3: Cornell + synthetic {args.tris}-tri mesh (stand-in for absent dragon.3d), Glass+Metal, "
                                f"PathIntegrator maxDepth {args.max_depth} rr 1 spatial, Halton({args.spp}), {W}x{H}",
-                   "spp_per_step": sps, "steps_per_pass": fuse, "spp_rendered": spp_done, "sharding": f"rows y % {world} == rank" if world > 1 else "none",
+                   "spp_per_step": sps, "steps_per_pass": fuse, "spp_rendered": spp_done, "spp_timed": spp_timed, "sharding": f"rows y % {world} == rank" if world > 1 else "none",
                    "gather": "RCCL gather of row shards to rank 0 (in timed region)" if world > 1 else "n/a"},
-        "wall_to_1024spp_s": dt_max * (1024.0 / spp_done),
-        "wall_to_full_spp_s": dt_max * (float(args.spp) / spp_done),
+        "wall_to_1024spp_s": dt_max * (1024.0 / spp_timed),
+        "wall_to_full_spp_s": dt_max * (float(args.spp) / spp_timed),
         "wall_measured_s": dt_max,
         # the metric excludes scene build / upload like the reference's timeConsume (core/Integrator.cpp:228,317);
         # the end-to-end figure is reported beside it
         "scene_setup_s": scene_setup_s,
-        "wall_end_to_end_s": scene_setup_s + dt_max * (float(args.spp) / spp_done),
+        "wall_end_to_end_s": scene_setup_s + dt_max * (float(args.spp) / spp_timed),
         "rays": {"closest": tot["rays_closest"], "any": tot["rays_any"], "per_camera_sample": rays / max(1, tot["camera_samples"])},
     }
 
