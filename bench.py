@@ -1,31 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: Mrays/s (+ wall-clock to 1024 spp) on the "dragon" Cornell scene.
 
-Workload (BASELINE.json configs[2]): Cornell box + ~100k-triangle mesh, Glass + Metal, PathIntegrator
-maxDepth 8, rrThreshold 1, "spatial" light sampling, HaltonSampler(1024), 1920x1080.  The mesh is the
-seeded SYNTHETIC stand-in for the reference's dragon.3d, which is absent from the snapshot
+Workloads (BASELINE.json `configs`):
+  cfg3 (default, the headline metric)  Cornell box + ~100k-triangle mesh, Glass + Metal, PathIntegrator maxDepth 8,
+        rrThreshold 1, "spatial" light sampling, HaltonSampler(1024), 1920x1080.
+  cfg4  the same geometry with Metal / Plastic / Disney / Glass quarters + InfiniteAreaLight over a 1000x500 lat-long map
+        (a deterministic synthetic map of MonValley1000.hdr's size: the reference's HDR cannot travel to the GPU box).
+  cfg5  VolPathIntegrator, GridDensityMedium (the reference's density grid) + HomogeneousMedium, 512x512 @256 spp.
+The mesh is the seeded SYNTHETIC stand-in for the reference's dragon.3d, which is absent from the snapshot
 (.MISSING_LARGE_BLOBS) -- numbers are not comparable with anyone else's "dragon".
 
-A step = one pass of the hot path over one batch: `--spp-per-step` (default 128) consecutive Halton samples
-of every pixel (265 M camera samples at 1080p, 47 GB of path state in the 288 GB of HBM; bigger batches keep
-the late, thin bounces of a pass from under-filling the GPU: 8 -> 2262, 16 -> 2554 Mrays/s on an earlier
-build, 32 -> 2997, 64 -> 3065, 128 -> 3107 on the final one).  The default --steps 8 therefore renders the
-full 1024 spp image and `wall_to_1024spp_s` is measured, not extrapolated.
+A step = one pass of the hot path over one batch: `--spp-per-step` (default 128) consecutive Halton samples of every pixel.
+The default --steps 8 renders the full 1024 spp image, so `wall_to_1024spp_s` is measured, not extrapolated.
 
-With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) image rows are interleaved over
-the ranks, no collective runs during rendering, and the final FrameBuffer is gathered to rank 0 with one
-RCCL gather inside the timed region.  value = rays traced by all ranks / max-over-ranks time.  A rank owns
-1/N of the rows, so it submits N consecutive steps to the library as one pass (`steps_per_pass` in the
-JSON): the same samples of the same pixels with the same results, batched so that its kernel launches stay
-as thick as the single-GPU ones (measured on one GPU with rank 0's share: 75 % -> ~95 % per-rank efficiency
-at N = 8, tests/dev_shard_eff.py).
+--gpus N > 1: one rank per GPU.  When no launcher has set WORLD_SIZE, bench.py starts its own ranks
+(`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process, before anything touches the GPU),
+passes the child's output through and exits with its code; under a launcher it checks that the world size is N.  Image rows
+are interleaved over the ranks, no collective runs during rendering, and the final FrameBuffer is gathered to rank 0 with one
+RCCL gather inside the timed region.  value = rays traced by all ranks / max-over-ranks time.
 
-Ray = one Scene::Intersect or Scene::IntersectP query (closest-hit, shadow and MIS rays), the unit the
-reference was profiled in.
+Ray = one Scene::Intersect or Scene::IntersectP query (closest-hit, shadow and MIS rays), the unit the reference was
+profiled in.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,9 +35,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, MI355X_MICROARCH.md
+WORKLOADS = ("cfg3", "cfg4", "cfg5")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
@@ -52,9 +54,10 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--save-image", type=str, default="")
     ap.add_argument("--fuse-steps", type=int, default=0, help="steps a rank submits as one pass (default: the number of ranks)")
-    ap.add_argument("--workload", choices=["cfg3", "cfg5"], default="cfg3",
-                    help="cfg3 (default, the headline metric) or cfg5: VolPathIntegrator + GridDensityMedium + HomogeneousMedium 512x512 @256spp")
-    args = ap.parse_args()
+    ap.add_argument("--workload", choices=WORKLOADS, default="cfg3")
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
     if args.workload == "cfg5":   # BASELINE.json configs[4]; explicit flags still win
         d = ap.parse_args([])
         if args.width == d.width and args.height == d.height: args.width, args.height = 512, 512
@@ -62,6 +65,48 @@ def parse():
         if args.spp_per_step == d.spp_per_step: args.spp_per_step = 128
         if args.steps == d.steps: args.steps = args.spp // args.spp_per_step
     return args
+
+
+# ------------------------------------------------------------------------------------------------ rank launch
+def launch_plan(args, env):
+    """What this process has to do about --gpus (pure function of the arguments and the environment; tests/test_host_logic.py):
+       ("run", world)         render as one of `world` ranks (world == 1: no process group)
+       ("spawn", n)           no launcher around us: start n ranks as a child process and relay its result
+       ("error", message)     the launcher's world size contradicts --gpus"""
+    ws = env.get("WORLD_SIZE")
+    if ws is None:
+        return ("run", 1) if args.gpus == 1 else ("spawn", args.gpus)
+    try:
+        world = int(ws)
+    except ValueError:
+        return ("error", f"WORLD_SIZE={ws!r} is not a number")
+    if world != args.gpus:
+        return ("error", f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    return ("run", world)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n, argv):
+    """Start the ranks as a CHILD (never exec: this may run under a profiler that has initialised the GPU), relay stdout / stderr."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def host_cores():
+    """Every core this process may run on (the affinity mask of the box's share), stated in the JSON."""
+    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 
 
 def cpu_baseline(builder, args):
@@ -79,18 +124,18 @@ def cpu_baseline(builder, args):
 
     vol = args.workload == "cfg5"
     integ = (gx.VolPathIntegrator if vol else gx.PathIntegrator)(args.max_depth, 1.0, "spatial")
-    # same scene / camera / sampler type on a bounded sample: cfg 3: 1/4 of the pixels x 24 spp, cfg 5: all pixels x 32 spp
-    # (10-15 s of CPU work for each of the two baselines)
-    w, h, spp = (args.width, args.height, 32) if vol else (960, 540, 24)
-    # a 1-GPU box gives this job a 16-core share of the host (more OpenMP threads only oversubscribe it)
-    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    cores = host_cores()
+    # same scene / camera / sampler type on a bounded sample: cfg 3/4: 1/4 of the pixels, cfg 5: all pixels; the number of
+    # samples scales with the cores so that each of the two baselines is 10-15 s of CPU work
+    w, h = (args.width, args.height) if vol else (960, 540)
+    spp = max(8, min(args.spp, int(round((32 if vol else 24) * cores / 16.0))))
     osc = ol.OracleScene(builder)
     osc.render(integ, 64, 36, args.spp, threads=cores, spp_begin=0, spp_end=1)   # touch the tables once
     img, st = osc.render(integ, w, h, args.spp, threads=cores, spp_begin=0, spp_end=spp)
     rays = st["rays_closest"] + st["rays_any"]
     port = {"value": rays / st["seconds_render"] / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": f"{w}x{h} px, samples 0..{spp - 1} of HaltonSampler({args.spp}), same scene; {rays} rays in {st['seconds_render']:.1f} s; "
-                      "oracle = CPU restatement of the reference path, OpenMP over pixel columns (core/Integrator.cpp:256), no printf"}
+                      f"oracle = CPU restatement of the reference path, OpenMP over pixel columns (core/Integrator.cpp:256) on all {cores} cores of the affinity mask, no printf"}
     if not os.path.exists(ol.REF_BIN):
         return port
     try:
@@ -104,7 +149,7 @@ def cpu_baseline(builder, args):
         rrays = int(cnt[0]) + int(cnt[1])
         return {"value": rrays / secs / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "reference",
                 "sample": f"{w}x{h} px, {spp} spp (HaltonSampler({spp})), same scene; {rrays} rays in {secs:.1f} s; the reference's own classes "
-                          "(compiled from its sources) under the restated Render/Li loop, OpenMP over pixel columns, no printf",
+                          f"(compiled from its sources) under the restated Render/Li loop, OpenMP over pixel columns on all {cores} cores of the affinity mask, no printf",
                 "port": {"value": port["value"], "sample": port["sample"]}}
     except Exception as e:   # the binary is optional: fall back to the port
         port["reference_error"] = str(e)[-120:]
@@ -115,19 +160,93 @@ def cpu_baseline(builder, args):
         return port
 
 
+# ------------------------------------------------------------------------------------------------ roofline
+def git_head():
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL, text=True).strip()
+    except Exception:
+        return None
+
+
+def load_profile_json(name, args, sps, world):
+    """profiles/<name>: counter figures per launch, valid only for the launch size they were measured on (`_measured_on`)."""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None
+    try:
+        tj = json.load(open(path))
+    except Exception:
+        return None
+    on = tj.get("_measured_on", {})
+    if (on.get("workload"), on.get("spp_per_step"), on.get("width"), on.get("height")) != (args.workload, sps, args.width, args.height) or world != 1:
+        return None
+    return tj
+
+
+def roofline(kernel, secs, launches, units, unit_name, bytes_per_unit, byte_terms, args, sps, world, valu_peak_ginst, extra):
+    """Two ceilings for the dominant kernel, each a fraction <= 1 of a stated peak; `bound` names the higher one.
+    hbm : ALGORITHMIC bytes per unit (counted on the walk that is timed) x units per launch / HIP-event launch time vs 8 TB/s;
+          beside it the bytes the PMC counters saw (`traffic`, separate FETCH_SIZE / WRITE_SIZE passes, profiles/).
+    valu: VALU wave-instructions per unit (SQ_INSTS_VALU of a kept --pmc pass) x units / time vs the issue rate a saturating
+          v_fma_f32 loop reaches on this device (measured in this run by gnxr_probe_valu_peak)."""
+    avg_s = secs / launches
+    upl = units / launches
+    hbm_alg = upl * bytes_per_unit / avg_s / 1e9
+    r = {"kernel": kernel, "launches": launches, "avg_launch_ms": avg_s * 1e3, unit_name + "_per_launch": upl,
+         "bytes_per_" + unit_name[:-1]: bytes_per_unit, "byte_model": byte_terms}
+    r.update(extra)
+    hbm = {"achieved": hbm_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_alg / HBM_PEAK_GBS}
+    traffic = None
+    tj = load_profile_json("traffic_latest.json", args, sps, world)
+    if tj and kernel in tj:
+        traffic = tj[kernel].get("hbm_bytes_per_launch")
+        hbm["traffic_source"] = {"file": "profiles/traffic_latest.json", "commit": tj.get("_measured_on", {}).get("commit"),
+                                 "raw_bytes_per_launch": tj[kernel].get("hbm_bytes_per_launch_uncorrected")}
+        hbm["hbm_frac_measured"] = traffic / avg_s / 1e9 / HBM_PEAK_GBS   # FETCH x 2 (gfx950 correction) + WRITE, over the HIP-event time
+    valu = None
+    pj = load_profile_json("pmc_latest.json", args, sps, world)
+    if pj and kernel in pj and valu_peak_ginst:
+        k = pj[kernel]
+        per_unit = k["valu_insts_per_launch"] / upl
+        ach = k["valu_insts_per_launch"] / avg_s / 1e9
+        valu = {"achieved": ach, "peak": valu_peak_ginst, "unit": "G wave-instr/s", "frac": ach / valu_peak_ginst,
+                "wave_insts_per_" + unit_name[:-1]: per_unit, "lane_util": k.get("lane_util"), "valu_busy_pmc": k.get("valu_busy"),
+                "wait_frac": k.get("wait_frac"), "waves_per_simd": k.get("waves_per_simd"),
+                "source": {"file": "profiles/pmc_latest.json", "commit": pj.get("_measured_on", {}).get("commit")},
+                "peak_source": "gnxr_probe_valu_peak in this run: independent v_fma_f32 chains, 8 waves per SIMD on every CU"}
+    pick = valu if (valu and valu["frac"] >= hbm["frac"]) else hbm
+    r.update({"bound": "valu" if pick is valu else "hbm", "achieved": pick["achieved"], "peak": pick["peak"], "unit": pick["unit"],
+              "frac": pick["frac"], "traffic": traffic, "hbm": hbm, "valu": valu})
+    return r
+
+
+# ------------------------------------------------------------------------------------------------ the benchmark
 def main():
     args = parse()
+    plan = launch_plan(args, os.environ)
+    if plan[0] == "error":
+        print("bench.py: " + plan[1], file=sys.stderr)
+        sys.exit(2)
+    if plan[0] == "spawn":   # before torch / HIP are touched
+        sys.exit(spawn_ranks(plan[1], sys.argv[1:]))
+
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = plan[1]
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # GNXR_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks: ranks share the visible devices and
     # the collectives run on host copies.  The measured configuration is always nccl (= RCCL), one rank per GPU.
     backend = os.environ.get("GNXR_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    n_visible = torch.cuda.device_count()
+    if world > 1 and backend == "nccl" and n_visible < world:
+        if rank == 0:
+            print(f"bench.py: --gpus {world} over RCCL needs {world} visible devices, found {n_visible} "
+                  "(GNXR_BENCH_BACKEND=gloo rehearses the rank logic on fewer)", file=sys.stderr)
+        sys.exit(2)
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, n_visible)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(dev_index)
@@ -135,6 +254,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == world
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
@@ -144,15 +264,24 @@ def main():
 
     gx.init(dev_index)
     W, H = args.width, args.height
-    # every rank builds the same scene (replicated: ~12 MB of tables); rank 0 writes the mesh file once
+    # every rank builds the same scene (replicated: ~12 MB of tables, + 22 MB of env-map tables for cfg 4); rank 0 writes the
+    # synthetic input files once
     mesh_path = os.path.join(ROOT, "gpurun_out", "_meshes", f"synthetic_dragon_{args.tris}_1.3d")
-    if rank == 0 and args.workload == "cfg3":
+    env_path = None
+    if args.workload == "cfg4":
+        env_path = os.path.join(ROOT, "gpurun_out", "_meshes", "synthetic_env_1000x500.hdr")
+    if rank == 0 and args.workload in ("cfg3", "cfg4"):
         scenes.synthetic_mesh_path(args.tris)
+        if env_path:
+            scenes.synthetic_env_path(1000, 500)
     if world > 1:
         dist.barrier()
     if args.workload == "cfg5":
         builder = scenes.volume_cornell_cfg5(1.0)
         integ = gx.VolPathIntegrator(args.max_depth, 1.0, "spatial")
+    elif args.workload == "cfg4":
+        builder = scenes.dragon_cornell(args.tris, "zoo", env=env_path, mesh_path=mesh_path)
+        integ = gx.PathIntegrator(args.max_depth, 1.0, "spatial")
     else:
         builder = scenes.dragon_cornell(args.tris, "glass+metal", mesh_path=mesh_path)
         integ = gx.PathIntegrator(args.max_depth, 1.0, "spatial")
@@ -194,7 +323,7 @@ def main():
         torch.cuda.synchronize()
 
     tot = dict(rays_closest=0, rays_any=0, seconds_closest=0.0, seconds_nee=0.0, seconds_shade=0.0, launches_closest=0,
-               launches_nee=0, rays_closest_nee=0, camera_samples=0, kernel_launches=0)
+               launches_nee=0, rays_closest_nee=0, camera_samples=0, kernel_launches=0, media_segments=0)
     sync()
     t0 = time.perf_counter()
     i = 0
@@ -231,13 +360,21 @@ def main():
 
     spp_timed = args.steps * sps                 # samples per pixel traced inside the timed region (wraps around the Halton range beyond --spp)
     spp_done = min(spp_timed, args.spp)
-    detail = "Mrays/s (path tracing, closest-hit + shadow + MIS rays), " + ("volume Cornell 512x512 (cfg 5)" if args.workload == "cfg5" else "dragon-stand-in Cornell 1920x1080")
+    names = {"cfg3": "dragon-stand-in Cornell 1920x1080", "cfg4": "dragon-stand-in Cornell + environment light 1920x1080 (cfg 4)", "cfg5": "volume Cornell 512x512 (cfg 5)"}
+    detail = "Mrays/s (path tracing, closest-hit + shadow + MIS rays), " + names[args.workload]
     metric = detail
     if args.workload == "cfg3":   # the headline metric under BASELINE.json's own name: `value` is its Mrays/s half, `wall_to_1024spp_s` the other
         try:
             metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
         except Exception:
-            metric = "Mrays/sec + wall-clock to 1024spp, dragon Cornell 1920\u00d71080"
+            metric = "Mrays/sec + wall-clock to 1024spp, dragon Cornell 1920×1080"
+    wl = {"cfg5": f"cfg5: Cornell + GridDensityMedium (reference density grid 100x100x40, sigma_a 10 sigma_s 90) + HomogeneousMedium, "
+                  f"VolPathIntegrator maxDepth {args.max_depth} rr 1 spatial, Halton({args.spp}), {W}x{H}",
+          "cfg4": f"cfg4: Cornell + synthetic {args.tris}-tri mesh (stand-in for absent dragon.3d) in Glass / Metal / Plastic / Disney quarters + "
+                  f"InfiniteAreaLight over a synthetic 1000x500 lat-long map (stand-in for MonValley1000.hdr, which cannot travel), "
+                  f"PathIntegrator maxDepth {args.max_depth} rr 1 spatial, Halton({args.spp}), {W}x{H}",
+          "cfg3": f"cfg3: Cornell + synthetic {args.tris}-tri mesh (stand-in for absent dragon.3d), Glass+Metal, "
+                  f"PathIntegrator maxDepth {args.max_depth} rr 1 spatial, Halton({args.spp}), {W}x{H}"}[args.workload]
     result = {
         "metric": metric,
         "metric_detail": detail,
@@ -252,12 +389,11 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"cfg5: Cornell + GridDensityMedium (reference density grid 100x100x40, sigma_a 10 sigma_s 90) + HomogeneousMedium, "
-                               f"VolPathIntegrator maxDepth {args.max_depth} rr 1 spatial, Halton({args.spp}), {W}x{H}" if args.workload == "cfg5" else
-                               f"cfg3: Cornell + synthetic {args.tris}-tri mesh (stand-in for absent dragon.3d), Glass+Metal, "
-                               f"PathIntegrator maxDepth {args.max_depth} rr 1 spatial, Halton({args.spp}), {W}x{H}",
-                   "spp_per_step": sps, "steps_per_pass": fuse, "spp_rendered": spp_done, "spp_timed": spp_timed, "sharding": f"rows y % {world} == rank" if world > 1 else "none",
-                   "gather": "RCCL gather of row shards to rank 0 (in timed region)" if world > 1 else "n/a"},
+        "config": {"workload": wl, "spp_per_step": sps, "steps_per_pass": fuse, "spp_rendered": spp_done, "spp_timed": spp_timed,
+                   "sharding": f"rows y % {world} == rank" if world > 1 else "none",
+                   "gather": "RCCL gather of row shards to rank 0 (in timed region)" if world > 1 else "n/a",
+                   "world_size": dist.get_world_size() if world > 1 else 1, "backend": (backend if world > 1 else "none"),
+                   "devices_visible": n_visible, "commit": git_head()},
         "wall_to_1024spp_s": dt_max * (1024.0 / spp_timed),
         "wall_to_full_spp_s": dt_max * (float(args.spp) / spp_timed),
         "wall_measured_s": dt_max,
@@ -270,35 +406,34 @@ def main():
 
     # ---- roofline of the dominant kernel (rank 0's launches, HIP events on the render stream)
     if not args.no_kernel_timing and tot["launches_closest"] > 0:
-        # mean nodes visited / triangles tested per ray from the counting variant of the same kernels (untimed)
-        gx.lib().gnxr_set_profiling(2)
+        valu_peak = gx.probe_valu_peak()   # G wave-instructions / s a saturating v_fma_f32 loop reaches on this device, now
+        # untimed counting pass of one sample per pixel: the WIDE (4-wide, speculative) walk that the timed kernel performs,
+        # and the tracking-loop steps of k_vol_media
+        gx.lib().gnxr_set_profiling(4)
         stc = integ.RenderDevice(scene, out.data_ptr(), W, H, args.spp, stream=stream, spp_begin=0, spp_end=1, samples_per_pass=1, **shard)
         gx.lib().gnxr_set_profiling(0)
         torch.cuda.synchronize()
         nr = stc["rays_closest"] + stc["rays_any"]
-        n_nodes, n_tris = stc["nodes_visited"] / nr, stc["tris_tested"] / nr
-        b_ray = 136.0 + 32.0 * n_nodes + 48.0 * n_tris
-        # k_trace traces every ray of the pass (continuation, shadow and MIS rays); seconds_closest / launches_closest
-        # are its HIP-event time and launch count
-        name, secs, launches, krays = "k_trace", tot["seconds_closest"], tot["launches_closest"], rays
-        achieved = krays * b_ray / secs / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:   # PMC bytes per launch belong to the launch size they were measured on (profiles/README.md)
-                tj = json.load(open(tpath))
-                on = tj.get("_measured_on", {})
-                if (on.get("workload"), on.get("spp_per_step"), on.get("width"), on.get("height")) == (args.workload, sps, W, H) and world == 1:
-                    traffic = tj.get(name, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                              "traffic": traffic, "kernel": name, "launches": launches, "avg_launch_ms": secs / launches * 1e3,
-                              "rays_per_launch": krays / launches, "bytes_per_ray": b_ray, "nodes_per_ray": n_nodes, "tris_per_ray": n_tris,
-                              "kernel_seconds": {"k_trace": tot["seconds_closest"], "k_nee_combine": tot["seconds_nee"], "k_shade": tot["seconds_shade"]},
-                              "note": "algorithmic bytes (SURVEY 8d) / HIP-event kernel time; the 11 MB BVH lives in L2/Infinity Cache, "
-                                      "so measured HBM traffic is far below the algorithmic figure and frac can pass 1: the kernel is "
-                                      "bound by VALU issue, not by HBM (DESIGN.md section 4)"}
+        n4, n_tris = stc["nodes_visited"] / nr, stc["tris_tested"] / nr
+        kernel_seconds = {"k_trace": tot["seconds_closest"], ("k_vol_media" if args.workload == "cfg5" else "k_nee_combine"): tot["seconds_nee"],
+                          ("k_vol_step+compaction" if args.workload == "cfg5" else "k_shade+compaction"): tot["seconds_shade"]}
+        if args.workload == "cfg5" and tot["launches_nee"] > 0 and tot["seconds_nee"] >= tot["seconds_closest"]:
+            # k_vol_media dominates cfg 5: unit = one medium segment (Medium::Sample / Medium::Tr of the ray in flight).
+            # bytes: 32 B ray + 16 B vs record + 16 B result per segment, 8 density loads of 4 B per tracking step
+            # (two Halton draws per step read the permutation table: 2 B x digits, L2-resident, not charged)
+            steps = stc["media_steps"] / max(1, stc["media_segments"])
+            b_seg = 64.0 + 32.0 * steps
+            result["roofline"] = roofline("k_vol_media", tot["seconds_nee"], tot["launches_nee"], tot["media_segments"], "segments", b_seg,
+                                          "64 B per segment (ray, state, result) + 32 B per tracking step (8 density loads)", args, sps, world, valu_peak,
+                                          {"tracking_steps_per_segment": steps, "kernel_seconds": kernel_seconds})
+        else:
+            b_ray = 136.0 + 128.0 * n4 + 48.0 * n_tris   # SURVEY 8(d) with the node term of the tree that is walked: 128-B DNode4
+            result["roofline"] = roofline("k_trace", tot["seconds_closest"], tot["launches_closest"], rays, "rays", b_ray,
+                                          "136 B records + 128 B x 4-wide nodes visited (speculative visits included) + 48 B x triangles tested, "
+                                          "counted by k_trace<COUNT, WIDE> on the timed walk", args, sps, world, valu_peak,
+                                          {"nodes4_per_ray": n4, "tris_per_ray": n_tris, "kernel_seconds": kernel_seconds})
+        result["roofline"]["note"] = ("the 11 MB of BVH + triangles live in L2 / Infinity Cache, so the algorithmic byte model over-states what "
+                                      "reaches HBM (see hbm.hbm_frac_measured); the kernel is bound by VALU issue at partial lane utilisation")
     if args.save_image and rank == 0:
         np.save(args.save_image, acc.cpu().numpy())
     if world == 1 and not args.no_cpu_baseline:

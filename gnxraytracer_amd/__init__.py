@@ -441,6 +441,13 @@ def eval_libm(fn, x, x2=None):
     return out
 
 
+def probe_valu_peak():
+    """Measurement hook: VALU issue rate of the device in 1e9 wave64 instructions / s (independent v_fma_f32 chains, 8 waves per SIMD)."""
+    v = C.c_double(0.0)
+    _check(lib().gnxr_probe_valu_peak(C.byref(v)))
+    return v.value
+
+
 def framebuffer_update(running_mean, frame, frame_count):
     """FrameBuffer::update_f_u_c (ui/FrameBuffer.h:127-149): running mean + 1-exp(-4x) tone map to RGBA8."""
     h, w = frame.shape[:2]

@@ -5,10 +5,10 @@ include/gnxr.h field for field (tests/test_abi.py checks sizes and exported symb
 """
 import ctypes as C
 
-GNXR_ABI_VERSION = 3
+GNXR_ABI_VERSION = 4
 
 # gnxr_status
-OK, ERR_INVALID, ERR_NO_DEVICE, ERR_OOM, ERR_UNSUPPORTED, ERR_IO = 0, -1, -2, -3, -4, -5
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_OOM, ERR_UNSUPPORTED, ERR_IO, ERR_RUNTIME = 0, -1, -2, -3, -4, -5, -6
 # gnxr_material_type
 MAT_NONE, MAT_MATTE, MAT_MIRROR, MAT_GLASS, MAT_METAL, MAT_PLASTIC, MAT_DISNEY = range(7)
 # gnxr_light_type
@@ -93,6 +93,7 @@ class Stats(C.Structure):
         ("kernel_launches", u32), ("passes", u32),
         ("seconds_closest", C.c_double), ("seconds_nee", C.c_double), ("seconds_shade", C.c_double),
         ("launches_closest", u32), ("launches_nee", u32), ("rays_closest_nee", u64),
+        ("media_segments", u64), ("media_steps", u64),
     ]
 
 
@@ -115,6 +116,7 @@ PROTOTYPES = {
     "gnxr_shutdown": (None, []),
     "gnxr_last_error": (C.c_char_p, []),
     "gnxr_set_profiling": (C.c_int, [C.c_int]),
+    "gnxr_probe_valu_peak": (C.c_int, [P(C.c_double)]),
     "gnxr_scene_create": (C.c_int, [P(SceneDesc), P(VP)]),
     "gnxr_scene_destroy": (None, [VP]),
     "gnxr_scene_info": (C.c_int, [VP, P(i32), P(i32), P(i32)]),

@@ -25,16 +25,25 @@ GX_WHITTED_INSTANCES(X)
 GX_VOL_INSTANCES(X)
 #undef X
 
+namespace { int hip_status(hipError_t e); }
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
         hipError_t e_ = (expr);                                                                         \
         if (e_ != hipSuccess) {                                                                         \
             set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);       \
-            return e_ == hipErrorOutOfMemory ? GNXR_ERR_OOM : GNXR_ERR_NO_DEVICE;                        \
+            return hip_status(e_);                                                                      \
         }                                                                                               \
     } while (0)
 
 namespace {
+
+// hipError_t -> gnxr_status: allocation failures, "there is no (such) device", and everything else (a failed launch, an
+// invalid argument, a fault reported at the next synchronisation) as GNXR_ERR_RUNTIME
+int hip_status(hipError_t e) {
+    if (e == hipErrorOutOfMemory) return GNXR_ERR_OOM;
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver || e == hipErrorNotInitialized) return GNXR_ERR_NO_DEVICE;
+    return GNXR_ERR_RUNTIME;
+}
 
 int g_device = -1;
 int g_num_cus = 256;
@@ -66,7 +75,9 @@ struct KernelTimer {
 };
 
 int ensure_device() {
-    if (g_device >= 0) return GNXR_OK;
+    // the current device is per host thread in HIP: a call from a thread other than the one that ran gnxr_init (the Qt
+    // RenderThread of INTEGRATION.md) must not silently land on device 0
+    if (g_device >= 0) { HIP_TRY(hipSetDevice(g_device)); return GNXR_OK; }
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
@@ -154,8 +165,10 @@ struct gnxr_scene {
     Counters *h_counters = nullptr;  // pinned
     int stack_size = 32;
     bool wide_ok = true;   // 4-wide traversal usable (leaf sizes / triangle count fit the reference encoding)
-    std::mutex render_mutex;
+    std::recursive_mutex render_mutex;   // one render in flight per handle; gnxr_render holds it around its staging buffer too
+    int device = 0;                      // the HIP device the tables live on
 
+    int bind() const { HIP_TRY(hipSetDevice(device)); return GNXR_OK; }
     ~gnxr_scene() { if (h_counters) (void)hipHostFree(h_counters); }
 
     DScene device_scene(int W, int H) {
@@ -197,7 +210,19 @@ struct gnxr_scene {
         const int nl = (int)cs.desc_lights.size();
         const bool on_device = strategy == GNXR_LIGHTS_SPATIAL && nl >= 2 && !force_host && getenv("GNXR_HOST_LIGHT_GRID") == nullptr;
         std::vector<float> table;
-        build_light_grid(cs, strategy, &grid, &table, on_device);
+        build_light_grid(cs, strategy, &grid, &table, /*layout_only=*/true);
+        {   // the dense spatial table holds nvox^3 x (2 lights + 1) floats: refuse what cannot fit instead of failing inside an allocation
+            const unsigned long long bytes = (unsigned long long)grid.nvox[0] * grid.nvox[1] * grid.nvox[2] * (unsigned long long)grid.stride * sizeof(float);
+            size_t free_b = 0, total_b = 0;
+            unsigned long long limit = 64ull << 30;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) limit = std::min<unsigned long long>(limit, free_b / 2);
+            if (bytes > limit) {
+                set_error("spatial light distribution: %d x %d x %d voxels x %d lights need %.1f GB (limit %.1f GB); use GNXR_LIGHTS_POWER or GNXR_LIGHTS_UNIFORM for this many lights",
+                          grid.nvox[0], grid.nvox[1], grid.nvox[2], nl, bytes * 1e-9, limit * 1e-9);
+                return GNXR_ERR_UNSUPPORTED;
+            }
+        }
+        if (!on_device) build_light_grid(cs, strategy, &grid, &table, false);
         int rc;
         if (on_device) {
             const size_t nv = (size_t)grid.nvox[0] * grid.nvox[1] * grid.nvox[2];
@@ -262,7 +287,50 @@ bool device_morton_sort(const float *centroids3, int n, const float lo[3], const
 }
 }  // namespace
 
+namespace {
+// Issue-rate probe: 8 independent fp32 FMA chains per lane, no memory traffic; with 8 waves on every SIMD the loop is bound by
+// VALU issue alone.  The result is written so that the chains cannot be folded away.
+__global__ void __launch_bounds__(256) k_valu_peak(float *out, int iters, float a, float b) {
+    float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            x0 = __builtin_fmaf(x0, a, b); x1 = __builtin_fmaf(x1, a, b); x2 = __builtin_fmaf(x2, a, b); x3 = __builtin_fmaf(x3, a, b);
+            x4 = __builtin_fmaf(x4, a, b); x5 = __builtin_fmaf(x5, a, b); x6 = __builtin_fmaf(x6, a, b); x7 = __builtin_fmaf(x7, a, b);
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = ((x0 + x1) + (x2 + x3)) + ((x4 + x5) + (x6 + x7));
+}
+}  // namespace
+
 extern "C" {
+
+int gnxr_probe_valu_peak(double *giga_wave_insts_per_s) {
+    if (!giga_wave_insts_per_s) { set_error("null argument"); return GNXR_ERR_INVALID; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    const int blocks = g_num_cus * 8, iters = 4096;   // 8 blocks x 4 waves per CU = 8 waves per SIMD
+    DevBuf<float> out;
+    if ((rc = out.alloc((size_t)blocks * 256)) != GNXR_OK) return rc;
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    double best = 0;
+    for (int rep = 0; rep < 4; ++rep) {   // the first launch warms the clocks up
+        (void)hipEventRecord(a, 0);
+        hipLaunchKernelGGL(k_valu_peak, dim3(blocks), dim3(256), 0, 0, out.p, iters, 1.0000001f, 1e-9f);
+        (void)hipEventRecord(b, 0);
+        if (hipEventSynchronize(b) != hipSuccess) break;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, a, b) == hipSuccess && ms > 0)
+            best = std::max(best, (double)blocks * 4 /* waves */ * (double)iters * 64 /* FMAs per iteration */ / (ms * 1e-3) / 1e9);
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    HIP_TRY(hipGetLastError());
+    *giga_wave_insts_per_s = best;
+    return GNXR_OK;
+}
 
 int gnxr_init(int device_id) {
     int n = 0;
@@ -290,6 +358,7 @@ int gnxr_scene_create(const gnxr_scene_desc *desc, gnxr_scene **out) {
     if (rc) return rc;
     gnxr_scene *s = new (std::nothrow) gnxr_scene();
     if (!s) return GNXR_ERR_OOM;
+    s->device = g_device;
     if (!compile_scene(desc, &s->cs, device_morton_sort)) { delete s; return GNXR_ERR_INVALID; }
     CompiledScene &cs = s->cs;
     if (cs.bvh_max_depth + 1 > 64) { set_error("BVH depth %d exceeds the 64-entry traversal stack (BVHAccel.cpp:661)", cs.bvh_max_depth); delete s; return GNXR_ERR_UNSUPPORTED; }
@@ -380,7 +449,8 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     }
     bool textured_scene = false;
     for (const DMaterial &m : s->cs.materials) if (m.shade_class == 3) textured_scene = true;
-    std::lock_guard<std::mutex> lock(s->render_mutex);
+    std::lock_guard<std::recursive_mutex> lock(s->render_mutex);
+    if (int brc = s->bind()) return brc;
     auto t_start = std::chrono::steady_clock::now();
     hipStream_t stream = (hipStream_t)hip_stream;
     int rc = s->ensure_grid(p.light_strategy);
@@ -411,7 +481,14 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     }
     k = std::min(k, nsamples);
     size_t cap = (size_t)r.npix * k;
-    if (cap >= (1ull << 31)) { set_error("pass too large"); return GNXR_ERR_INVALID; }
+    // k_trace's work cursor is 32-bit unsigned: continuation rays + two NEE items per record; record slots are `record * cap + path`
+    {
+        const unsigned long long recs = whitted ? (unsigned long long)std::max(1, n_records) : 1ull;
+        if (cap >= (1ull << 31) || (unsigned long long)cap * recs >= (1ull << 31) || (unsigned long long)cap * (1ull + 2ull * recs) >= (1ull << 32)) {
+            set_error("pass too large: %zu paths x %llu NEE records per vertex overflow the 32-bit work indices; lower samples_per_pass", cap, recs);
+            return GNXR_ERR_INVALID;
+        }
+    }
 #define AL(f) if ((rc = s->f.alloc(cap)) != GNXR_OK) return rc;
     AL(ray_o) AL(ray_d) AL(beta) AL(L) AL(sh_o) AL(sh_d) AL(sh_X) AL(mis_o) AL(mis_d) AL(mis_Y) AL(nbeta) AL(meta) AL(hit) AL(queue_a) AL(queue_b) AL(queue_nee) AL(queue_c0) AL(queue_c1) AL(queue_c2) AL(queue_c3) AL(pflags) AL(pclass)
 #undef AL
@@ -457,13 +534,19 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
 
     HIP_TRY(hipMemsetAsync(s->accum.p, 0, sizeof(float4) * r.npix, stream));
     HIP_TRY(hipMemsetAsync(s->counters.p, 0, sizeof(Counters), stream));
-    hipEvent_t ev0, ev1;
-    HIP_TRY(hipEventCreate(&ev0));
-    HIP_TRY(hipEventCreate(&ev1));
+    struct EventPair {   // destroyed on every exit path
+        hipEvent_t a = nullptr, b = nullptr;
+        ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } ev;
+    HIP_TRY(hipEventCreate(&ev.a));
+    HIP_TRY(hipEventCreate(&ev.b));
+    hipEvent_t ev0 = ev.a, ev1 = ev.b;
     HIP_TRY(hipEventRecord(ev0, stream));
     unsigned long long rays_closest = 0, rays_any = 0, rays_mis = 0;
     unsigned int launches = 0, passes = 0;
-    const bool timing = (g_profiling & 1) != 0, counting = (g_profiling & 2) != 0, spheres = s->cs.n_spheres > 0;
+    // counting: bit 1 = on the reference's binary tree, bit 2 = on the timed (4-wide) walk + the medium kernel's tracking steps
+    const bool timing = (g_profiling & 1) != 0, count_wide = (g_profiling & 4) != 0, counting = (g_profiling & 2) != 0 && !count_wide, spheres = s->cs.n_spheres > 0;
+    unsigned long long media_segments = 0;
     int class_mask = 0;
     for (const DMaterial &m : s->cs.materials) class_mask |= 1 << m.shade_class;
     const bool textured = (class_mask & 8) != 0;
@@ -502,9 +585,11 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
             const int chunk = (int)std::min<long long>(chunk_max, std::max<long long>(64, ((total + waves - 1) / waves + 63) / 64 * 64));
 #define GX_TRACE(C, W, S) hipLaunchKernelGGL((k_trace<C, W, S>), dim3(blocks), dim3(kBlock), lds, stream, sc, pa, w, &dctr->cursor, dctr, lds_entries, s->trace_spill.p, chunk)
             if (spheres) {
-                if (counting) GX_TRACE(true, false, true); else if (wide) GX_TRACE(false, true, true); else GX_TRACE(false, false, true);
+                if (counting) GX_TRACE(true, false, true); else if (wide && count_wide) GX_TRACE(true, true, true); else if (wide) GX_TRACE(false, true, true);
+                else if (count_wide) GX_TRACE(true, false, true); else GX_TRACE(false, false, true);
             } else {
-                if (counting) GX_TRACE(true, false, false); else if (wide) GX_TRACE(false, true, false); else GX_TRACE(false, false, false);
+                if (counting) GX_TRACE(true, false, false); else if (wide && count_wide) GX_TRACE(true, true, false); else if (wide) GX_TRACE(false, true, false);
+                else if (count_wide) GX_TRACE(true, false, false); else GX_TRACE(false, false, false);
             }
 #undef GX_TRACE
             if (timing) timer.end(stream);
@@ -579,7 +664,9 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
                     if (timing) timer.begin(1, stream);
                     const long long mwaves = (long long)blocks * (kBlock / 64);
                     const int mchunk = (int)std::min<long long>(kMediaChunk, std::max<long long>(64, ((n_media + mwaves - 1) / mwaves + 63) / 64 * 64));
-                    hipLaunchKernelGGL(k_vol_media, dim3(blocks), dim3(kBlock), 0, stream, sc, mt, pa, va, q_media, n_media, &dctr->cursor, mchunk);
+                    if (count_wide) hipLaunchKernelGGL(k_vol_media<true>, dim3(blocks), dim3(kBlock), 0, stream, sc, mt, pa, va, q_media, n_media, &dctr->cursor, mchunk, dctr);
+                    else hipLaunchKernelGGL(k_vol_media<false>, dim3(blocks), dim3(kBlock), 0, stream, sc, mt, pa, va, q_media, n_media, &dctr->cursor, mchunk, dctr);
+                    media_segments += (unsigned long long)n_media;
                     if (timing) timer.end(stream);
                     ++launches;
                 }
@@ -678,8 +765,6 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     HIP_TRY(hipGetLastError());
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
     if (stats) {
         memset(stats, 0, sizeof(*stats));
         stats->rays_closest = rays_closest + (whitted ? s->h_counters->whitted_mis : 0);
@@ -695,6 +780,8 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
         stats->seconds_trace = timer.seconds[0] + timer.seconds[1];
         stats->launches_closest = timer.launches[0]; stats->launches_nee = timer.launches[1];
         stats->rays_closest_nee = rays_mis;
+        stats->media_segments = media_segments;
+        stats->media_steps = s->h_counters->media_steps;
     }
     return GNXR_OK;
 }
@@ -703,6 +790,8 @@ int gnxr_render(gnxr_scene *s, const gnxr_render_params *p, float *rgba_out, gnx
     if (!s || !p || !rgba_out) { set_error("null argument"); return GNXR_ERR_INVALID; }
     if (p->width <= 0 || p->height <= 0) { set_error("invalid image size"); return GNXR_ERR_INVALID; }
     size_t npx = (size_t)p->width * p->height;
+    std::lock_guard<std::recursive_mutex> lock(s->render_mutex);   // s->out is shared by every gnxr_render on this handle
+    if (int brc = s->bind()) return brc;
     int rc = s->out.alloc(npx);
     if (rc) return rc;
     HIP_TRY(hipMemset(s->out.p, 0, npx * sizeof(float4)));
@@ -739,6 +828,7 @@ int gnxr_scene_bvh(const gnxr_scene *s, float *bounds6, int32_t *meta3, int32_t 
 int gnxr_trace_closest(gnxr_scene *s, const gnxr_ray *rays, int64_t n, gnxr_hit *hits) {
     if (!s || !rays || !hits || n < 0) { set_error("bad argument"); return GNXR_ERR_INVALID; }
     if (n == 0) return GNXR_OK;
+    if (int brc = s->bind()) return brc;
     DevBuf<gnxr_ray> dr;
     DevBuf<gnxr_hit> dh;
     int rc;
@@ -753,6 +843,7 @@ int gnxr_trace_closest(gnxr_scene *s, const gnxr_ray *rays, int64_t n, gnxr_hit 
 int gnxr_trace_any(gnxr_scene *s, const gnxr_ray *rays, int64_t n, uint8_t *occluded) {
     if (!s || !rays || !occluded || n < 0) { set_error("bad argument"); return GNXR_ERR_INVALID; }
     if (n == 0) return GNXR_OK;
+    if (int brc = s->bind()) return brc;
     DevBuf<gnxr_ray> dr;
     DevBuf<unsigned char> dob;
     int rc;
@@ -821,7 +912,8 @@ int gnxr_camera_rays(const gnxr_camera *cam, int32_t width, int32_t height, cons
 
 int gnxr_light_grid_table(gnxr_scene *s, int32_t strategy, int32_t on_host, float *out, int64_t capacity, int64_t *n_floats) {
     if (!s || !n_floats) { set_error("null argument"); return GNXR_ERR_INVALID; }
-    std::lock_guard<std::mutex> lock(s->render_mutex);
+    std::lock_guard<std::recursive_mutex> lock(s->render_mutex);
+    if (int brc = s->bind()) return brc;
     int rc = s->ensure_grid(strategy, on_host != 0);
     if (rc) return rc;
     const int64_t n = (int64_t)s->grid.nvox[0] * s->grid.nvox[1] * s->grid.nvox[2] * s->grid.stride;

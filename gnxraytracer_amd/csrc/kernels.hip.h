@@ -12,8 +12,8 @@
 //   k_resolve       colObj += Li in sample order, box average                                   (A1)
 //
 // State is SoA-of-float4 in HBM (one dwordx4 per lane per field, coalesced); queues hold path slots and
-// are compacted with wave64 ballots (one atomic per wave).  No MFMA: the work is BVH pointer chasing and
-// divergent shading, bound by memory latency / bandwidth.
+// are compacted order-preservingly with wave64 ballots + a tile scan (compact_kernel.hip.h: no atomics).
+// No MFMA: the work is BVH pointer chasing and divergent shading, bound by VALU issue and memory latency.
 #pragma once
 #include "device_bsdf.h"
 #include "device_lights.h"
@@ -49,6 +49,7 @@ struct Counters {
     unsigned int cursor;                            // k_trace work cursor
     unsigned long long whitted_shadow;              // shadow rays queued by k_whitted_step
     unsigned long long whitted_mis;                 // MIS closest-hit rays queued by k_whitted_step (DirectLighting); follows whitted_shadow
+    unsigned long long media_steps;                 // tracking-loop iterations of k_vol_media<COUNT>
 };
 
 struct DScene {

@@ -1071,9 +1071,17 @@ bool compile_scene(const gnxr_scene_desc *d, CompiledScene *cs, MortonSortFn mor
     // ---- media
     cs->media.clear();
     if (d->n_media > 0) {
+        if (!d->media) { set_error("n_media > 0 without a media array"); return false; }
         cs->media.assign(d->media, d->media + d->n_media);
         int64_t total = 0;
-        for (auto &m : cs->media) if (m.type == GNXR_MEDIUM_GRID) total = std::max<int64_t>(total, m.density_offset + (int64_t)m.nx * m.ny * m.nz);
+        for (size_t i = 0; i < cs->media.size(); ++i) {   // checked before anything is copied or read
+            const gnxr_medium &m = cs->media[i];
+            if (m.type != GNXR_MEDIUM_GRID) continue;
+            if (m.nx <= 0 || m.ny <= 0 || m.nz <= 0) { set_error("medium %d: empty density grid", (int)i); return false; }
+            if (m.density_offset < 0) { set_error("medium %d: negative density_offset", (int)i); return false; }
+            if (!d->grid_density) { set_error("medium %d: GRID medium without grid_density", (int)i); return false; }
+            total = std::max<int64_t>(total, m.density_offset + (int64_t)m.nx * m.ny * m.nz);
+        }
         if (total > 0) cs->grid_density.assign(d->grid_density, d->grid_density + total);
     }
     cs->dmedia.assign(std::max<size_t>(1, cs->media.size()), DMedium());
@@ -1109,7 +1117,10 @@ bool compile_scene(const gnxr_scene_desc *d, CompiledScene *cs, MortonSortFn mor
         }
     }
     cs->camera = d->camera;
-    cs->camera_medium = d->camera_medium;
+    // Camera::medium: -1 == none.  A zero-initialised description (memset) says "inside medium 0", so the index is checked
+    // against the media that exist; without media any value means "none".
+    if (d->n_media > 0 && (d->camera_medium < -1 || d->camera_medium >= d->n_media)) { set_error("camera_medium %d out of range (%d media)", d->camera_medium, d->n_media); return false; }
+    cs->camera_medium = d->n_media > 0 ? d->camera_medium : -1;
     build_sampler_tables(cs);
     return true;
 }

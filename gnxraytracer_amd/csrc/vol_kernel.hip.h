@@ -81,7 +81,10 @@ GX_DEV int hit_medium(const DScene &sc, const DMediaTables &mt, int leaf, int ra
 // loop and refills from the wave's pool when it ends.  Results: va.mres[path], and the path's stream position va.vs[path].y.
 constexpr int kMediaChunk = 256;   // most paths a wave takes per global atomic (smaller for thin launches, chosen by the host)
 
-static __global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt, PathArrays pa, VolArrays va, const int *__restrict__ queue, int n, unsigned int *cursor, int chunk) {
+// COUNT: add the number of tracking-loop iterations to ctr->media_steps (profiling run; gnxr_set_profiling bit 2)
+template <bool COUNT>
+__global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt, PathArrays pa, VolArrays va, const int *__restrict__ queue, int n, unsigned int *cursor, int chunk, Counters *ctr) {
+    unsigned long long cntSteps = 0;
     const int lane = __lane_id();
     const unsigned total = (unsigned)n;
     unsigned poolBase = 0, poolCount = 0;
@@ -175,6 +178,7 @@ static __global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTa
         }
         // ---------------- one tracking iteration for every active lane ----------------
         if (path >= 0) {
+            if (COUNT) ++cntSteps;
             bool done = false;
             float resW = 1.f, resT = -1.f;
             bool resSigma = false;
@@ -228,6 +232,7 @@ static __global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTa
             }
         }
     }
+    if (COUNT && cntSteps) atomicAdd(&ctr->media_steps, cntSteps);
 }
 
 // LM: the lobe set every material of the scene fits in (device_bsdf.h LM_*): a scene of Matte walls and media runs the

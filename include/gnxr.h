@@ -30,15 +30,16 @@
 extern "C" {
 #endif
 
-#define GNXR_ABI_VERSION 3
+#define GNXR_ABI_VERSION 4
 
 typedef enum gnxr_status {
     GNXR_OK = 0,
     GNXR_ERR_INVALID = -1,    /* bad argument / inconsistent description            */
-    GNXR_ERR_NO_DEVICE = -2,  /* no HIP device or HIP runtime error                   */
+    GNXR_ERR_NO_DEVICE = -2,  /* no HIP device (or no such device); there is no CPU fallback */
     GNXR_ERR_OOM = -3,        /* host or device allocation failed                     */
     GNXR_ERR_UNSUPPORTED = -4,/* feature present in the description but not built    */
-    GNXR_ERR_IO = -5          /* file could not be read / written                     */
+    GNXR_ERR_IO = -5,         /* file could not be read / written                     */
+    GNXR_ERR_RUNTIME = -6     /* a HIP call failed at run time (launch, copy, synchronise); message in gnxr_last_error() */
 } gnxr_status;
 
 /* ---- materials: materials/{Matte,Mirror,Glass,Metal,Plastic,Disney}Material.cpp ---- */
@@ -282,6 +283,8 @@ typedef struct gnxr_stats {
     double seconds_shade;       /* k_shade launches                                          */
     uint32_t launches_closest, launches_nee;
     uint64_t rays_closest_nee;  /* closest-hit rays traced by k_nee (MIS rays)               */
+    uint64_t media_segments;    /* VolPath: ray segments handed to the tracking kernel (Medium::Sample / Medium::Tr calls on rays inside a medium) */
+    uint64_t media_steps;       /* VolPath: tracking-loop iterations of those segments (filled by the counting run, profiling bit 2) */
 } gnxr_stats;
 
 typedef struct gnxr_ray { float o[3]; float tmax; float d[3]; float _pad; } gnxr_ray;
@@ -301,9 +304,16 @@ void gnxr_shutdown(void);
 const char *gnxr_last_error(void);
 /* Measurement switches (process-wide).  bit 0: bracket every traversal kernel launch with HIP events on
  * the render stream and report their summed duration in gnxr_stats.seconds_trace (+ per-kernel split in
- * seconds_closest / seconds_nee); bit 1: run the counting variant of the traversal kernels and fill
- * nodes_visited / tris_tested (slower; never combine with a timed run).                              */
+ * seconds_closest / seconds_nee); bit 1: run the counting variant of the traversal kernel on the reference's BINARY
+ * tree (BVHAccel::Intersect's own node visits: comparable with the oracle's counts) and fill nodes_visited /
+ * tris_tested; bit 2: count on the walk the timed kernel performs instead -- 4-wide nodes visited, speculative visits
+ * included -- and the tracking-loop iterations of the medium kernel (media_steps).  Counting runs are slower; never
+ * combine them with a timed run.                                                                             */
 int gnxr_set_profiling(int flags);
+/* Measurement hook: the VALU issue rate of this device, in 1e9 wave64 instructions per second, reached by a kernel of
+ * independent v_fma_f32 chains with 8 waves on every SIMD -- the ceiling bench.py prices the traversal kernel's
+ * instruction stream against.                                                                                */
+int gnxr_probe_valu_peak(double *giga_wave_insts_per_s);
 
 /* -- scene (replaces `Scene(make_shared<BVHAccel>(prims,1), lights)`, RenderThread.cpp:155) */
 int gnxr_scene_create(const gnxr_scene_desc *desc, gnxr_scene **out);

@@ -74,6 +74,79 @@ def synthetic_mesh_path(n_tris, seed=1, cache_dir=None):
     return p
 
 
+def write_rgbe(path, rgb, rle=True):
+    """Radiance .hdr writer (32-bit_rle_rgbe).  rle=True writes the new-style run-length-encoded scanlines every Radiance tool
+    (and the reference's Resources/*.hdr) uses -- the branch of the builder's reader that stbi's hdr loader calls
+    `stbi__hdr_load` RLE -- rle=False the flat layout.  Data only: no reference file is copied."""
+    rgb = np.asarray(rgb, np.float64)
+    h, w, _ = rgb.shape
+    m = rgb.max(axis=2)
+    ok = m > 1e-32
+    mant, ex = np.frexp(np.where(ok, m, 1.0))           # m = mant * 2^ex, mant in [0.5, 1)
+    scale = np.where(ok, mant * 256.0 / np.where(ok, m, 1.0), 0)
+    px = np.zeros((h, w, 4), np.uint8)
+    px[..., :3] = np.clip(rgb * scale[..., None], 0, 255).astype(np.uint8)
+    px[..., 3] = np.where(ok, ex + 128, 0).astype(np.uint8)
+    with open(path, "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w))
+        if not rle or w < 8 or w >= 32768:
+            f.write(px.tobytes())
+            return
+        for j in range(h):
+            out = bytearray([2, 2, (w >> 8) & 0xff, w & 0xff])
+            for c in range(4):
+                line = px[j, :, c]
+                # run boundaries, then greedy: runs of >= 4 equal bytes become (128 + n, value), the rest literal blocks of <= 128
+                edges = np.flatnonzero(np.diff(line)) + 1
+                starts = np.concatenate([[0], edges]); ends = np.concatenate([edges, [w]])
+                lit_start = 0
+                def flush_lit(a, b):
+                    while a < b:
+                        n = min(128, b - a)
+                        out.append(n); out.extend(line[a:a + n].tobytes()); a += n
+                for a, b in zip(starts.tolist(), ends.tolist()):
+                    if b - a >= 4:
+                        flush_lit(lit_start, a)
+                        v = int(line[a])
+                        while a < b:
+                            n = min(127, b - a)
+                            out.append(128 + n); out.append(v); a += n
+                        lit_start = b
+                flush_lit(lit_start, w)
+            f.write(bytes(out))
+
+
+def synthetic_env(w=1000, h=500, seed=4):
+    """Deterministic outdoor-style lat-long radiance map at the size of the reference's Resources/MonValley1000.hdr (1000 x 500:
+    not a power of two, so MIPMap's Lanczos resample to 1024 x 512 runs): graded sky, a small bright sun (the importance table must
+    find it; peak 200, MonValley's is 69), ground, a few soft clouds.  Stand-in for the HDR, which cannot travel to the GPU box."""
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    u, v = (xx + 0.5) / w, (yy + 0.5) / h
+    sky = np.stack([0.25 + 0.5 * v, 0.45 + 0.45 * v, 1.05 - 0.25 * v], 2) * (1.3 - 0.6 * v[..., None])
+    ground = np.stack([0.22 + 0.05 * np.sin(40 * u), 0.19 + 0.04 * np.cos(31 * u), 0.12 + 0.0 * u], 2) * (0.6 + 0.8 * (v[..., None] - 0.5))
+    img = np.where((v > 0.52)[..., None], ground, sky)
+    rng = np.random.default_rng(seed)
+    for _ in range(7):   # clouds
+        cu, cv, r = rng.random(), 0.1 + 0.3 * rng.random(), 0.03 + 0.06 * rng.random()
+        du = np.minimum(np.abs(u - cu), 1 - np.abs(u - cu))
+        img += 0.9 * np.exp(-((du / (2 * r)) ** 2 + ((v - cv) / r) ** 2))[..., None] * (v < 0.5)[..., None]
+    su, sv = 0.31, 0.22   # the sun: ~3 texels wide, two orders of magnitude above the sky
+    img += (2.0e2 * np.exp(-(((u - su) * w) ** 2 + ((v - sv) * h) ** 2) / 4.0))[..., None] * np.array([1.0, 0.93, 0.82])
+    img[h - 6:, :, :] = 0.0   # a black band (RGBE exponent 0: the `e == 0` branch of the decoder) with long runs
+    return img.astype(np.float32)
+
+
+def synthetic_env_path(w=1000, h=500, cache_dir=None):
+    cache_dir = cache_dir or os.path.join(ROOT, "gpurun_out", "_meshes")
+    os.makedirs(cache_dir, exist_ok=True)
+    p = os.path.join(cache_dir, f"synthetic_env_{w}x{h}.hdr")
+    if not os.path.exists(p):
+        tmp = p + f".{os.getpid()}.tmp"
+        write_rgbe(tmp, synthetic_env(w, h), rle=True)
+        os.replace(tmp, p)
+    return p
+
+
 def dragon_cornell(n_tris=100000, material="glass", env=None, extra_materials=False, mesh_path=None):
     """cfg 3 (Glass + Metal halves) / cfg 4 (+ InfiniteAreaLight, Plastic, Disney).  The mesh is the seeded
     synthetic stand-in for the absent dragon.3d; AddModel comes first, as in RenderThread.cpp:119-133."""

@@ -215,6 +215,38 @@ def test_headline_config_at_full_resolution_against_oracle(gpu):
     assert r < RMSE_TOL and same > 0.9999     # bit-identical in every run so far; margin for MicroFacet.cpp's double sin / cos (see below)
 
 
+def test_cfg4_at_full_resolution_against_oracle(gpu):
+    """BASELINE configs[3] at its own size: the 100 k-triangle mesh in Glass / Metal / Plastic / Disney quarters inside the Cornell
+    box, lit by the area light AND an InfiniteAreaLight over a 1000 x 500 lat-long map (RLE .hdr -> builder's RGBE reader ->
+    Lanczos resample to 1024 x 512 -> 2048 x 1024 Distribution2D), 1920 x 1080, HaltonSampler(1024): two of the 1024 samples of every
+    pixel, image and ray counts against the oracle bit for bit, and 4 row shards recombine to the same image.  The map is the
+    deterministic synthetic stand-in of tests/scenes.py (the reference's MonValley1000.hdr cannot travel to the GPU box; in the
+    development container tests/test_reference_assets.py pins reader, light and materials on the real file)."""
+    env = scenes.synthetic_env_path(1000, 500)
+    b = scenes.dragon_cornell(100000, "zoo", env=env)
+    d = b.desc()
+    assert (d.env_width, d.env_height) == (1000, 500) and d.n_lights == 3
+    integ = gpu.PathIntegrator(8, 1.0, "spatial")
+    kw = dict(spp_begin=700, spp_end=702)
+    scene = gpu.Scene(b)
+    img, st = integ.Render(scene, 1920, 1080, 1024, **kw)
+    oimg, ost = ol.OracleScene(b).render(integ, 1920, 1080, 1024, **kw)
+    assert (st["rays_closest"], st["rays_any"]) == (ost["rays_closest"], ost["rays_any"])
+    same = (img[..., :3].view(np.uint32) == oimg[..., :3].view(np.uint32)).mean()
+    r, mx = rmse(img, oimg)
+    print(f"cfg4 1920x1080 samples 700-701: {same * 100:.5f} % of the values bit-identical, rmse {r:.2e}, rays {st['rays_closest']}+{st['rays_any']}")
+    assert biteq(img[..., :3], oimg[..., :3])
+    acc = np.zeros_like(img)
+    rays = 0
+    for rk in range(4):
+        part, s = integ.Render(scene, 1920, 1080, 1024, shard_index=rk, shard_count=4, shard_rows=1, **kw)
+        acc += part
+        rays += s["rays_closest"] + s["rays_any"]
+    assert (acc.view(np.uint32) == img.view(np.uint32)).all() and rays == st["rays_closest"] + st["rays_any"]
+    # escaped camera rays see the map: the sky part of the image is lit by Le alone
+    assert img[..., :3].max() > 1.0 and np.isfinite(img).all()
+
+
 def test_dragon_scene_against_oracle(gpu):
     """The headline scene at a size the oracle finishes in seconds."""
     b = scenes.dragon_cornell(100000, "glass+metal")
@@ -492,6 +524,21 @@ def test_edge_cases(gpu):
         gpu.PathIntegrator(8).Render(scene, 0, 8, 1)
     with pytest.raises(gpu.GnxrError):
         gpu.PathIntegrator(8).Render(scene, 8, 8, 4, spp_begin=3, spp_end=2)
+    # descriptions compile_scene would otherwise read out of bounds are refused: camera medium, grid media without data
+    bv = scenes.volume_cornell()
+    dv = bv.desc()
+    dv.camera_medium = 7
+    with pytest.raises(gpu.GnxrError, match="camera_medium"):
+        gpu.Scene(dv)
+    dv = bv.desc()
+    dv.grid_density = None
+    with pytest.raises(gpu.GnxrError, match="grid_density"):
+        gpu.Scene(dv)
+    dv = bv.desc()
+    dv.media[0].density_offset = -5
+    with pytest.raises(gpu.GnxrError, match="density_offset"):
+        gpu.Scene(dv)
+    dv.media[0].density_offset = 0
     # a scene without lights renders black and traces no shadow rays
     b = gpu.SceneBuilder()
     w = b.MatteMaterial((0.5, 0.5, 0.5))

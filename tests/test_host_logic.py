@@ -166,3 +166,55 @@ def test_framebuffer_save_png_round_trips(gx, tmp_path):
         assert ihdr == (w, h, 8, 6, 0, 0, 0)
         raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, w * 4 + 1)
         assert (raw[:, 0] == 0).all() and (raw[:, 1:].reshape(h, w, 4) == img).all()
+
+
+def test_bench_launch_plan():
+    """bench.py --gpus N: alone it must start its own ranks, under a launcher it must agree with WORLD_SIZE."""
+    import bench
+    a = lambda *v: bench.parse(list(v))
+    assert bench.launch_plan(a(), {}) == ("run", 1)
+    assert bench.launch_plan(a("--gpus", "1"), {"WORLD_SIZE": "1"}) == ("run", 1)
+    assert bench.launch_plan(a("--gpus", "8"), {}) == ("spawn", 8)
+    assert bench.launch_plan(a("--gpus", "8"), {"WORLD_SIZE": "8", "RANK": "3"}) == ("run", 8)
+    assert bench.launch_plan(a("--gpus", "8"), {"WORLD_SIZE": "4"})[0] == "error"
+    assert bench.launch_plan(a("--gpus", "1"), {"WORLD_SIZE": "2"})[0] == "error"      # `bench.py` under a 2-rank launcher without --gpus 2
+    assert bench.launch_plan(a("--gpus", "2"), {"WORLD_SIZE": "x"})[0] == "error"
+    with pytest.raises(SystemExit):
+        a("--gpus", "0")
+    c5 = a("--workload", "cfg5")
+    assert (c5.width, c5.height, c5.spp, c5.steps) == (512, 512, 256, 2)
+    assert a("--workload", "cfg4").workload == "cfg4" and a().workload == "cfg3"
+
+
+def test_bench_spawns_its_own_ranks(tmp_path, monkeypatch):
+    """`python bench.py --gpus 2` with no launcher around it starts `python -m torch.distributed.run --nproc-per-node 2 bench.py ...`
+    as a child and returns the child's exit code (the ranks themselves need GPUs; here the command line is what is checked)."""
+    import bench
+    seen = {}
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    rc = bench.spawn_ranks(2, ["--gpus", "2", "--steps", "4"])
+    cmd = seen["cmd"]
+    assert rc == 7 and cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "2", "--steps", "4"]
+    assert cmd[-5] == os.path.abspath(bench.__file__) and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_radiance_writer_round_trips_through_the_builder(gx, tmp_path):
+    """tests/scenes.write_rgbe (RLE and flat) -> the builder's RGBE reader: both encodings decode to the same floats, within RGBE's
+    8-bit mantissa of the source, zeros (exponent byte 0) and long runs included."""
+    img = scenes.synthetic_env(200, 64)
+    px = {}
+    for rle in (True, False):
+        p = str(tmp_path / f"e{int(rle)}.hdr")
+        scenes.write_rgbe(p, img, rle=rle)
+        b = gx.SceneBuilder()
+        b.AddInfLight(p)
+        d = b.desc()
+        px[rle] = np.ctypeslib.as_array(d.env_rgb, shape=(d.env_height, d.env_width, 3)).copy()
+    assert os.path.getsize(str(tmp_path / "e1.hdr")) < os.path.getsize(str(tmp_path / "e0.hdr"))   # runs were found
+    assert (px[True].view(np.uint32) == px[False].view(np.uint32)).all()
+    m = img.max(axis=2, keepdims=True)
+    assert (np.abs(px[True] - img) <= m / 128 + 1e-30).all() and (px[True][-1] == 0).all()

@@ -1,0 +1,73 @@
+"""Checks that need the reference tree itself (/root/reference) and the compiled reference (oracle/_ref/gnx_ref): they run
+in the development container only and are skipped on the GPU box, where neither exists.  They pin BASELINE config 4's
+inputs at their own size: the reference's Resources/MonValley1000.hdr (1000 x 500, run-length encoded) through the builder's
+RGBE reader, the 1000x500 -> 1024x512 Lanczos resample + Distribution2D of InfiniteAreaLight, and Plastic / Disney / Glass /
+Metal lit by it -- oracle against the reference's own classes, bit for bit.  No reference file is copied: the HDR is read
+where it lies."""
+import os
+import struct
+import tempfile
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import scenes
+from conftest import GOLDEN
+
+RES = "/root/reference/Resources"
+needs_ref = pytest.mark.skipif(not (ol.have_ref() and os.path.isdir(RES)), reason="needs /root/reference and oracle/_ref/gnx_ref (development container only)")
+
+
+def _stbi(path):
+    raw = ol.run_ref(None, "hdr", None, [path])   # stbi_loadf, 3rd/stb_image.h, as lights/InfiniteAreaLight.cpp:27 calls it
+    w, h = struct.unpack("<2i", raw[:8])
+    return np.frombuffer(raw[8:], np.float32).reshape(h, w, 3)
+
+
+def _builder_pixels(gx, path):
+    b = gx.SceneBuilder()
+    b.AddInfLight(path)
+    d = b.desc()
+    return np.ctypeslib.as_array(d.env_rgb, shape=(d.env_height, d.env_width, 3)).copy()
+
+
+@needs_ref
+@pytest.mark.parametrize("name", ["MonValley1000.hdr", "TropicalRuins1000.hdr"])
+def test_rgbe_reader_equals_stbi_on_the_reference_hdr(gx, name):
+    """The reference's own environment maps are new-style RLE Radiance files: the RLE branch of read_rgbe
+    (csrc/scene_builder.cpp) must return stbi_loadf's floats bit for bit."""
+    path = os.path.join(RES, name)
+    mine, ref = _builder_pixels(gx, path), _stbi(path)
+    assert mine.shape == ref.shape == (500, 1000, 3)
+    assert (mine.view(np.uint32) == ref.view(np.uint32)).all()
+
+
+@needs_ref
+def test_rgbe_reader_equals_stbi_on_the_synthetic_stand_in(gx, tmp_path):
+    """bench.py --workload cfg4 and the 1080p GPU test use a synthetic 1000 x 500 map written RLE-encoded by tests/scenes.py."""
+    p = str(tmp_path / "env.hdr")
+    scenes.write_rgbe(p, scenes.synthetic_env(1000, 500), rle=True)
+    mine, ref = _builder_pixels(gx, p), _stbi(p)
+    assert (mine.view(np.uint32) == ref.view(np.uint32)).all()
+
+
+@needs_ref
+@pytest.mark.parametrize("strategy", ["spatial", "power"])
+def test_oracle_equals_reference_classes_under_the_reference_hdr(gx, strategy):
+    """cfg 4 at a size the CPU finishes in seconds: 2 k-triangle mesh in Glass / Metal / Plastic / Disney quarters inside the
+    Cornell box, InfiniteAreaLight(MonValley1000.hdr) with the transform of ui/ModelList.cpp:172-179 -- the oracle against the
+    restated Render / Li loop on the reference's own InfiniteAreaLight, MIPMap, Distribution2D, BSDF and BVH classes."""
+    b = scenes.dragon_cornell(2000, "zoo", env=os.path.join(RES, "MonValley1000.hdr"), mesh_path=os.path.join(GOLDEN, "mesh_2k.3d"))
+    W, H, spp, depth = 96, 54, 4, 8
+    integ = gx.PathIntegrator(depth, 1.0, strategy)
+    oimg, ost = ol.OracleScene(b).render(integ, W, H, spp)
+    with tempfile.TemporaryDirectory() as td:
+        sp = os.path.join(td, "scene.bin")
+        ol.write_scene_file(b, sp)
+        raw = ol.run_ref(sp, "render", None, [W, H, spp, depth, 1.0, {"spatial": 0, "uniform": 1, "power": 2}[strategy], 4, 0])
+    rimg = np.frombuffer(raw[:W * H * 16], np.float32).reshape(H, W, 4)
+    cnt = np.frombuffer(raw[W * H * 16:W * H * 16 + 16], np.uint64)
+    assert (int(cnt[0]), int(cnt[1])) == (ost["rays_closest"], ost["rays_any"])
+    assert (oimg[..., :3].view(np.uint32) == rimg[..., :3].view(np.uint32)).all()
+    assert oimg[..., :3].max() > 0.5   # the environment actually lights the scene
