@@ -162,10 +162,14 @@ def cpu_baseline(builder, args):
 
 # ------------------------------------------------------------------------------------------------ roofline
 def git_head():
+    """HEAD of the tree this runs from; on the GPU box (.git does not travel) the stamp a post-commit hook leaves in .build_commit."""
     try:
         return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL, text=True).strip()
     except Exception:
-        return None
+        try:
+            return open(os.path.join(ROOT, ".build_commit")).read().strip() or None
+        except Exception:
+            return None
 
 
 def load_profile_json(name, args, sps, world):
@@ -427,11 +431,12 @@ def main():
                                           "64 B per segment (ray, state, result) + 32 B per tracking step (8 density loads)", args, sps, world, valu_peak,
                                           {"tracking_steps_per_segment": steps, "kernel_seconds": kernel_seconds})
         else:
-            b_ray = 136.0 + 128.0 * n4 + 48.0 * n_tris   # SURVEY 8(d) with the node term of the tree that is walked: 128-B DNode4
+            n_re = stc["leaf_retests"] / nr
+            b_ray = 136.0 + 128.0 * n4 + 48.0 * n_tris + 32.0 * n_re   # SURVEY 8(d) with the node term of the tree that is walked: 128-B DNode4
             result["roofline"] = roofline("k_trace", tot["seconds_closest"], tot["launches_closest"], rays, "rays", b_ray,
-                                          "136 B records + 128 B x 4-wide nodes visited (speculative visits included) + 48 B x triangles tested, "
-                                          "counted by k_trace<COUNT, WIDE> on the timed walk", args, sps, world, valu_peak,
-                                          {"nodes4_per_ray": n4, "tris_per_ray": n_tris, "kernel_seconds": kernel_seconds})
+                                          "136 B records + 128 B x 4-wide nodes visited (speculative visits included) + 48 B x triangles tested + "
+                                          "32 B x leaf boxes re-tested, counted by k_trace<COUNT, WIDE> on the timed walk", args, sps, world, valu_peak,
+                                          {"nodes4_per_ray": n4, "tris_per_ray": n_tris, "leaf_retests_per_ray": n_re, "kernel_seconds": kernel_seconds})
         result["roofline"]["note"] = ("the 11 MB of BVH + triangles live in L2 / Infinity Cache, so the algorithmic byte model over-states what "
                                       "reaches HBM (see hbm.hbm_frac_measured); the kernel is bound by VALU issue at partial lane utilisation")
     if args.save_image and rank == 0:

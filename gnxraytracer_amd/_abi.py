@@ -93,7 +93,7 @@ class Stats(C.Structure):
         ("kernel_launches", u32), ("passes", u32),
         ("seconds_closest", C.c_double), ("seconds_nee", C.c_double), ("seconds_shade", C.c_double),
         ("launches_closest", u32), ("launches_nee", u32), ("rays_closest_nee", u64),
-        ("media_segments", u64), ("media_steps", u64),
+        ("media_segments", u64), ("media_steps", u64), ("leaf_retests", u64),
     ]
 
 

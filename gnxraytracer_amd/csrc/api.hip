@@ -131,6 +131,7 @@ struct gnxr_scene {
     DevBuf<DNode> nodes;
     DevBuf<DNode4> nodes4;
     DevBuf<DTri> tris;
+    DevBuf<float> leaf_boxes;
     DevBuf<DSphere> spheres;
     DevBuf<DMaterial> materials, materials_single;
     DevBuf<DTexture> textures;
@@ -177,6 +178,7 @@ struct gnxr_scene {
         d.nodes4 = reinterpret_cast<const float4 *>(nodes4.p);
         d.root4 = cs.root4;
         d.tris = tris.p;
+        d.leaf_box = reinterpret_cast<const float4 *>(leaf_boxes.p);
         d.spheres = spheres.p;
         d.n_spheres = cs.n_spheres;
         d.materials = materials.p + 1;   // [0] carries the texture tables
@@ -366,7 +368,7 @@ int gnxr_scene_create(const gnxr_scene_desc *desc, gnxr_scene **out) {
     s->wide_ok = cs.tris.size() < (1u << 24) && cs.stack4_need + 1 <= 128 && getenv("GNXR_BINARY_BVH") == nullptr;
     for (const DNode &n : cs.nodes) if ((n.meta & 0xffffu) > 127) s->wide_ok = false;
 #define UP(field) if ((rc = s->field.upload(cs.field)) != GNXR_OK) { delete s; return rc; }
-    UP(nodes) UP(nodes4) UP(tris) UP(lights) UP(perms) UP(primes) UP(prime_sums) UP(prime_magic)
+    UP(nodes) UP(nodes4) UP(tris) UP(leaf_boxes) UP(lights) UP(perms) UP(primes) UP(prime_sums) UP(prime_magic)
     UP(dmedia) UP(grid_density) UP(tri_media) UP(spheres) UP(textures) UP(tex_texels) UP(ewa_lut) UP(tri_uv) UP(tri_n) UP(tri_s)
     UP(env_texels) UP(env_cond_func) UP(env_cond_cdf) UP(env_cond_int) UP(env_marg_func) UP(env_marg_cdf)
 #undef UP
@@ -782,6 +784,7 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
         stats->rays_closest_nee = rays_mis;
         stats->media_segments = media_segments;
         stats->media_steps = s->h_counters->media_steps;
+        stats->leaf_retests = s->h_counters->retests;
     }
     return GNXR_OK;
 }

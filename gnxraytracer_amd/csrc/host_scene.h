@@ -49,6 +49,7 @@ struct CompiledScene {
     int32_t root4 = 0;                   // root reference (a leaf ref when the scene has a single leaf)
     int stack4_need = 1;                 // worst-case traversal stack entries for nodes4
     std::vector<DTri> tris;              // leaf order
+    std::vector<float> leaf_boxes;       // 8 floats per leaf-order triangle, valid at the first triangle of each leaf: the leaf's LinearBVHNode bounds (lo.xyz hi.x | hi.yz 0 0)
     std::vector<int32_t> leaf_of_prim;   // authoring index -> leaf index
     int bvh_max_depth = 0;
     Box3 world_bound;

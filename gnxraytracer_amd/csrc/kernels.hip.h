@@ -50,6 +50,7 @@ struct Counters {
     unsigned long long whitted_shadow;              // shadow rays queued by k_whitted_step
     unsigned long long whitted_mis;                 // MIS closest-hit rays queued by k_whitted_step (DirectLighting); follows whitted_shadow
     unsigned long long media_steps;                 // tracking-loop iterations of k_vol_media<COUNT>
+    unsigned long long retests;                     // k_trace<COUNT, WIDE>: leaf boxes re-tested against a shrunken tMax (32 B each)
 };
 
 struct DScene {
@@ -57,6 +58,7 @@ struct DScene {
     const float4 *nodes4;   // DNode4[] as 8 float4 each
     int root4;
     const DTri *tris;
+    const float4 *leaf_box;   // 2 float4 per leaf-order triangle: bounds of the leaf that starts there (CompiledScene::leaf_boxes)
     const DSphere *spheres;   // tested before the BVH; hit code -2 - index
     int n_spheres;
     const DMaterial *materials;   // materials[-1] holds the DTexTables of the scene (tex_tables(), device_texture.h)

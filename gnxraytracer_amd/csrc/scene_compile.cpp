@@ -927,6 +927,14 @@ bool compile_scene(const gnxr_scene_desc *d, CompiledScene *cs, MortonSortFn mor
     cs->stack4_need = 1;
     cs->root4 = collapse(cs->nodes, 0, cs->nodes4, 0, &cs->stack4_need);
     if (cs->nodes4.empty()) cs->nodes4.push_back(DNode4());
+    // bounds of every leaf of the binary tree, addressed by the leaf's first triangle: BVHAccel::Intersect tests a leaf's OWN box when
+    // it pops the node (BVHAccel.cpp:665), the 4-wide walk re-tests it against the tMax of that moment (trace_kernel.hip.h, phase B)
+    cs->leaf_boxes.assign((size_t)d->n_triangles * 8, 0.f);
+    for (const DNode &n : cs->nodes)
+        if ((n.meta & 0xffffu) != 0) {
+            float *lb = &cs->leaf_boxes[(size_t)n.offset * 8];
+            lb[0] = n.lo[0]; lb[1] = n.lo[1]; lb[2] = n.lo[2]; lb[3] = n.hi0; lb[4] = n.hi1; lb[5] = n.hi2;
+        }
     cs->world_bound.lo = Vec3(cs->nodes[0].lo[0], cs->nodes[0].lo[1], cs->nodes[0].lo[2]);
     cs->world_bound.hi = Vec3(cs->nodes[0].hi0, cs->nodes[0].hi1, cs->nodes[0].hi2);
     // ---- spheres (outside the BVH)

@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
     float tMax = 0;
     int neg0 = 0, neg1 = 0, neg2 = 0;
     int cur = -1, toVisit = 0, leafOff = 0, leafN = 0, hitLeaf = -1, expect = -1;
-    uint32_t cntNodes = 0, cntTris = 0;
+    uint32_t cntNodes = 0, cntTris = 0, cntRetests = 0;
 #ifdef GX_TRACE_STATS
     unsigned long long st_[16] = {0};
 #endif
@@ -307,17 +307,13 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
             if (WIDE && (SPH ? hitLeaf != -1 : hitLeaf >= 0)) {   // tMax only ever shrinks after a hit: before the first hit the earlier test stands
                 // BVHAccel::Intersect tests a leaf's box when it pops it, i.e. against the CURRENT ray.tMax; the 4-wide
                 // step tested it earlier with an older tMax.  Re-test here so that exact ties (t == tMax on flat,
-                // axis-aligned boxes such as the Cornell walls) resolve as in the reference.  The leaf box is the
-                // union of its triangles' bounds (Triangle::WorldBound), recomputed exactly from the vertices.
-                V3 lo(GX_INF, GX_INF, GX_INF), hi(-GX_INF, -GX_INF, -GX_INF);
-                for (int i = 0; i < leafN; ++i) {
-                    V3 p0, p1, p2;
-                    load_tri(tris, leafOff + i, &p0, &p1, &p2);
-                    lo = V3(fminf(lo.x, fminf(p0.x, fminf(p1.x, p2.x))), fminf(lo.y, fminf(p0.y, fminf(p1.y, p2.y))), fminf(lo.z, fminf(p0.z, fminf(p1.z, p2.z))));
-                    hi = V3(fmaxf(hi.x, fmaxf(p0.x, fmaxf(p1.x, p2.x))), fmaxf(hi.y, fmaxf(p0.y, fmaxf(p1.y, p2.y))), fmaxf(hi.z, fmaxf(p0.z, fmaxf(p1.z, p2.z))));
-                }
+                // axis-aligned boxes such as the Cornell walls) resolve as in the reference.  The leaf's bounds (the floats
+                // of its LinearBVHNode) sit in a table addressed by its first triangle: two dwordx4 instead of re-reading
+                // and re-bounding the triangles.
+                const float4 b0 = sc.leaf_box[2 * (size_t)leafOff], b1 = sc.leaf_box[2 * (size_t)leafOff + 1];
                 int neg[3] = {neg0, neg1, neg2};
-                visit = slab_test(make_float4(lo.x, lo.y, lo.z, hi.x), make_float4(hi.y, hi.z, 0.f, 0.f), ro, invDir, neg, tMax);
+                if (COUNT) cntRetests++;
+                visit = slab_test(b0, b1, ro, invDir, neg, tMax);
             }
             for (int i = 0; visit && i < leafN; ++i) {
                 V3 p0, p1, p2;
@@ -362,6 +358,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
     if (COUNT) {
         atomicAdd(&ctr->nodes, (unsigned long long)cntNodes);
         atomicAdd(&ctr->tris, (unsigned long long)cntTris);
+        atomicAdd(&ctr->retests, (unsigned long long)cntRetests);
     }
 }
 

@@ -285,6 +285,7 @@ typedef struct gnxr_stats {
     uint64_t rays_closest_nee;  /* closest-hit rays traced by k_nee (MIS rays)               */
     uint64_t media_segments;    /* VolPath: ray segments handed to the tracking kernel (Medium::Sample / Medium::Tr calls on rays inside a medium) */
     uint64_t media_steps;       /* VolPath: tracking-loop iterations of those segments (filled by the counting run, profiling bit 2) */
+    uint64_t leaf_retests;      /* counting run, bit 2: leaf boxes re-tested against a shrunken tMax by the 4-wide walk (32 B each)  */
 } gnxr_stats;
 
 typedef struct gnxr_ray { float o[3]; float tmax; float d[3]; float _pad; } gnxr_ray;
