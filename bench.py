@@ -105,8 +105,25 @@ def spawn_ranks(n, argv):
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
 def host_cores():
-    """Every core this process may run on (the affinity mask of the box's share), stated in the JSON."""
-    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    """CPU cores this job can actually use: the affinity mask, capped by the cgroup's CPU quota when there is one (a 1-GPU box hands a
+    job a share of the host: its mask lists every core of the machine, its cpu.max says how many it may run on at once).  Nothing is
+    hard-coded; all three figures go into the JSON."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]       # cgroup v2
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:                                                             # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            quota = None
+    cores = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    return cores, {"affinity_mask": aff, "cgroup_cpu_quota": quota, "os_cpu_count": os.cpu_count()}
 
 
 def cpu_baseline(builder, args):
@@ -124,18 +141,22 @@ def cpu_baseline(builder, args):
 
     vol = args.workload == "cfg5"
     integ = (gx.VolPathIntegrator if vol else gx.PathIntegrator)(args.max_depth, 1.0, "spatial")
-    cores = host_cores()
-    # same scene / camera / sampler type on a bounded sample: cfg 3/4: 1/4 of the pixels, cfg 5: all pixels; the number of
-    # samples scales with the cores so that each of the two baselines is 10-15 s of CPU work
+    cores, core_info = host_cores()
+    # same scene / camera / sampler type on a bounded sample: cfg 3/4: 1/4 of the pixels, cfg 5: all pixels; one sample per pixel is
+    # timed first and the number of samples is then chosen so that each of the two baselines is about 12 s of CPU work
     w, h = (args.width, args.height) if vol else (960, 540)
-    spp = max(8, min(args.spp, int(round((32 if vol else 24) * cores / 16.0))))
     osc = ol.OracleScene(builder)
     osc.render(integ, 64, 36, args.spp, threads=cores, spp_begin=0, spp_end=1)   # touch the tables once
+    t0 = time.perf_counter()
+    osc.render(integ, w, h, args.spp, threads=cores, spp_begin=0, spp_end=1)
+    t1 = max(1e-3, time.perf_counter() - t0)
+    spp = int(max(2, min(args.spp, 12.0 / t1)))
+    print(f"[bench] cpu baseline: {cores} threads ({core_info}), 1 spp took {t1:.2f} s -> timing {spp} spp at {w}x{h}", file=sys.stderr, flush=True)
     img, st = osc.render(integ, w, h, args.spp, threads=cores, spp_begin=0, spp_end=spp)
     rays = st["rays_closest"] + st["rays_any"]
-    port = {"value": rays / st["seconds_render"] / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+    port = {"value": rays / st["seconds_render"] / 1e6, "unit": "Mrays/s", "cores": cores, "cores_detail": core_info, "kind": "port",
             "sample": f"{w}x{h} px, samples 0..{spp - 1} of HaltonSampler({args.spp}), same scene; {rays} rays in {st['seconds_render']:.1f} s; "
-                      f"oracle = CPU restatement of the reference path, OpenMP over pixel columns (core/Integrator.cpp:256) on all {cores} cores of the affinity mask, no printf"}
+                      f"oracle = CPU restatement of the reference path, OpenMP over pixel columns (core/Integrator.cpp:256) on the {cores} cores this job may use, no printf"}
     if not os.path.exists(ol.REF_BIN):
         return port
     try:
@@ -143,13 +164,14 @@ def cpu_baseline(builder, args):
         with tempfile.TemporaryDirectory() as td:
             sp = os.path.join(td, "scene.bin")
             ol.write_scene_file(builder, sp)
+            print(f"[bench] cpu baseline: compiled reference classes, {spp} spp", file=sys.stderr, flush=True)
             raw = ol.run_ref(sp, "render", None, [w, h, spp, args.max_depth, 1.0, 0, cores, 1 if vol else 0])
         cnt = np.frombuffer(raw[w * h * 16:w * h * 16 + 16], np.uint64)
         secs = struct.unpack("<d", raw[w * h * 16 + 16:w * h * 16 + 24])[0]
         rrays = int(cnt[0]) + int(cnt[1])
-        return {"value": rrays / secs / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "reference",
+        return {"value": rrays / secs / 1e6, "unit": "Mrays/s", "cores": cores, "cores_detail": core_info, "kind": "reference",
                 "sample": f"{w}x{h} px, {spp} spp (HaltonSampler({spp})), same scene; {rrays} rays in {secs:.1f} s; the reference's own classes "
-                          f"(compiled from its sources) under the restated Render/Li loop, OpenMP over pixel columns on all {cores} cores of the affinity mask, no printf",
+                          f"(compiled from its sources) under the restated Render/Li loop, OpenMP over pixel columns on the {cores} cores this job may use, no printf",
                 "port": {"value": port["value"], "sample": port["sample"]}}
     except Exception as e:   # the binary is optional: fall back to the port
         port["reference_error"] = str(e)[-120:]
@@ -289,6 +311,10 @@ def main():
     else:
         builder = scenes.dragon_cornell(args.tris, "glass+metal", mesh_path=mesh_path)
         integ = gx.PathIntegrator(args.max_depth, 1.0, "spatial")
+    def note(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
     t_setup = time.perf_counter()
     scene = gx.Scene(builder)   # gnxr_scene_create: host BVH build (the reference's SAH splits), 4-wide collapse, tables, upload
     scene_setup_s = time.perf_counter() - t_setup
@@ -314,6 +340,7 @@ def main():
         acc.add_(out)
         return st, done
 
+    note(f"scene ready in {scene_setup_s:.2f} s; {args.warmup} warm-up + {args.steps} timed steps of {sps} spp")
     for i in range(args.warmup):
         step(i, fuse)
     acc.zero_()
@@ -346,6 +373,7 @@ def main():
     dt = time.perf_counter() - t0
     gx.lib().gnxr_set_profiling(0)
 
+    note(f"timed region {dt:.3f} s")
     rays = tot["rays_closest"] + tot["rays_any"]
     tvec = torch.tensor([dt, float(rays), float(tot["rays_closest"]), float(tot["rays_any"])], dtype=torch.float64, device=coll_dev)
     if world > 1:
@@ -410,6 +438,7 @@ def main():
 
     # ---- roofline of the dominant kernel (rank 0's launches, HIP events on the render stream)
     if not args.no_kernel_timing and tot["launches_closest"] > 0:
+        note("roofline: VALU issue probe + counting pass")
         valu_peak = gx.probe_valu_peak()   # G wave-instructions / s a saturating v_fma_f32 loop reaches on this device, now
         # untimed counting pass of one sample per pixel: the WIDE (4-wide, speculative) walk that the timed kernel performs,
         # and the tracking-loop steps of k_vol_media

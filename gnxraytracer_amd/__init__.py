@@ -441,6 +441,15 @@ def eval_libm(fn, x, x2=None):
     return out
 
 
+def eval_libm_f64(fn, x):
+    """Test hook: the device's double-precision sin / cos / sqrt / tan on float arguments (widened), results as float64."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.zeros(x.shape, dtype=np.float64)
+    _check(lib().gnxr_eval_libm_f64({"sin": 0, "cos": 1, "sqrt": 2, "tan": 3}[fn], x.ctypes.data_as(C.POINTER(C.c_float)), x.size,
+                                    out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out
+
+
 def probe_valu_peak():
     """Measurement hook: VALU issue rate of the device in 1e9 wave64 instructions / s (independent v_fma_f32 chains, 8 waves per SIMD)."""
     v = C.c_double(0.0)

@@ -130,6 +130,7 @@ PROTOTYPES = {
     "gnxr_framebuffer_save_png": (C.c_int, [C.c_char_p, P(u8), i32, i32]),
     "gnxr_light_grid_table": (C.c_int, [VP, i32, i32, P(f32), i64, P(i64)]),
     "gnxr_eval_libm": (C.c_int, [i32, P(f32), P(f32), i64, P(f32)]),
+    "gnxr_eval_libm_f64": (C.c_int, [i32, P(f32), i64, P(C.c_double)]),
     "gnxr_builder_create": (C.c_int, [P(VP)]),
     "gnxr_builder_set_camera_medium": (C.c_int, [VP, i32]),
     "gnxr_builder_add_sphere": (C.c_int, [VP, P(f32), f32, i32, i32, i32]),

@@ -155,6 +155,8 @@ struct gnxr_scene {
     DevBuf<unsigned char> pflags, pclass;
     DevBuf<unsigned int> tile_counts;
     DevBuf<int> trace_spill;   // global part of k_trace's per-lane traversal stacks
+    DevBuf<unsigned> sort_keys_a, sort_keys_b, sort_items_a, sort_items_b;   // ray binning (GNXR_SORT_RAYS)
+    DevBuf<unsigned char> sort_tmp;
     DevBuf<float4> vol_n1, vol_f, vol_Li, vol_Tr, vol_Ld, vol_mres;   // VolPath light-estimate records (vol_kernel.hip.h)
     DevBuf<int4> vol_vs;
     DevBuf<unsigned char> vol_state;
@@ -568,6 +570,23 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
         auto launch_trace = [&](TraceWork w, int n_sh, int n_mis) {
             long long total = (long long)w.n_closest + 2ll * w.n_nee;
             if (total <= 0) return;
+            w.order = nullptr;
+            static const int sort_rays = getenv("GNXR_SORT_RAYS") ? atoi(getenv("GNXR_SORT_RAYS")) : 0;   // experiment: bin the rays of a launch by kind / octant / origin cell
+            if (sort_rays > 0 && total >= (1 << 16)) {
+                if (s->sort_keys_a.alloc(3 * cap) || s->sort_keys_b.alloc(3 * cap) || s->sort_items_a.alloc(3 * cap) || s->sort_items_b.alloc(3 * cap)) return;
+                const Box3 &wb = s->cs.world_bound;
+                const float3 lo = make_float3(wb.lo.x, wb.lo.y, wb.lo.z);
+                const float3 scale = make_float3(32.f / std::max(1e-20f, wb.hi.x - wb.lo.x), 32.f / std::max(1e-20f, wb.hi.y - wb.lo.y), 32.f / std::max(1e-20f, wb.hi.z - wb.lo.z));
+                if (timing) timer.begin(1, stream);
+                hipLaunchKernelGGL(k_trace_keys, dim3(grid_for(total)), dim3(kBlock), 0, stream, pa, w, lo, scale, s->sort_keys_a.p, s->sort_items_a.p);
+                size_t bytes = 0;
+                const int b0 = sort_rays >= 2 ? 0 : 15, b1 = kTraceKeyBits;   // 1: kind + octant only; 2: + origin cell
+                (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, s->sort_keys_a.p, s->sort_keys_b.p, s->sort_items_a.p, s->sort_items_b.p, (int)total, b0, b1, stream);
+                if (s->sort_tmp.alloc(bytes)) return;
+                (void)hipcub::DeviceRadixSort::SortPairs(s->sort_tmp.p, bytes, s->sort_keys_a.p, s->sort_keys_b.p, s->sort_items_a.p, s->sort_items_b.p, (int)total, b0, b1, stream);
+                if (timing) timer.end(stream);
+                w.order = s->sort_items_b.p;
+            }
             (void)hipMemsetAsync(&dctr->cursor, 0, sizeof(unsigned int), stream);
             // LDS traversal stack: one column per lane, depth from the BVH (binary walk: depth + 1; 4-wide walk: stack4_need)
             const bool wide = s->wide_ok && !counting;
@@ -936,6 +955,20 @@ int gnxr_eval_libm(int32_t fn, const float *x, const float *x2, int64_t n, float
     hipLaunchKernelGGL(k_libm_probe, dim3(grid_for(n)), dim3(kBlock), 0, 0, (int)fn, (const float *)dx.p, (const float *)(x2 ? dx2.p : nullptr), (long long)n, dout.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return GNXR_OK;
+}
+
+int gnxr_eval_libm_f64(int32_t fn, const float *x, int64_t n, double *out) {
+    if (!x || !out || n < 0 || fn < 0 || fn > 3) { set_error("bad argument"); return GNXR_ERR_INVALID; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (n == 0) return GNXR_OK;
+    DevBuf<float> dx;
+    DevBuf<double> dout;
+    if ((rc = dx.upload(x, (size_t)n)) || (rc = dout.alloc((size_t)n))) return rc;
+    hipLaunchKernelGGL(k_libm_probe_f64, dim3(grid_for(n)), dim3(kBlock), 0, 0, (int)fn, (const float *)dx.p, (long long)n, dout.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     return GNXR_OK;
 }
 

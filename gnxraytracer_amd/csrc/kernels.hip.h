@@ -714,6 +714,15 @@ static __global__ void k_libm_probe(int fn, const float *x, const float *x2, lon
     }
 }
 
+// test hook: the double-precision libm calls of the path (device_bsdf.h: sincos / sqrt, device_math.h: tan)
+static __global__ void k_libm_probe_f64(int fn, const float *x, long long n, double *out) {
+    for (long long i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const double v = (double)x[i];
+        if (fn <= 1) { double sv, cv; sincos(v, &sv, &cv); out[i] = fn == 0 ? sv : cv; }
+        else out[i] = fn == 2 ? sqrt(v) : tan(v);
+    }
+}
+
 // FrameBuffer::update_f_u_c, ui/FrameBuffer.h:127-149
 static __global__ void k_framebuffer_update(float *mean, const float *frame, long long nvals, int frame_count, unsigned char *rgba8) {
     for (long long i = blockIdx.x * blockDim.x + threadIdx.x; i < nvals; i += (long long)gridDim.x * blockDim.x) {

@@ -367,6 +367,10 @@ int gnxr_light_grid_table(gnxr_scene *s, int32_t strategy, int32_t on_host, floa
  * media/GridDensityMedium.cpp:41,67, media/HomogeneousMedium.cpp:13,24, core/Medium.cpp:187, core/Geometry.h:1436-1443);
  * the device restates glibc 2.35's algorithms so the results carry glibc's bits. */
 int gnxr_eval_libm(int32_t fn, const float *x, const float *x2, int64_t n, float *out);
+/* The double-precision libm calls of the path, on float arguments widened to double, results as doubles.  fn: 0 sin, 1 cos (the pair
+ * the device evaluates for `r * cos(phi)`, `r * sin(phi)` at core/MicroFacet.cpp:220-223, where the unqualified calls bind to the
+ * double versions), 2 sqrt (MicroFacet.cpp:220, DisneyMaterial.cpp:236), 3 tan (MicroFacet.cpp:190-191, 297). */
+int gnxr_eval_libm_f64(int32_t fn, const float *x, int64_t n, double *out);
 
 /* -- output stage (FrameBuffer::update_f_u_c, ui/FrameBuffer.h:127-149) ------------------ */
 /* Folds one Render() result into the running mean of `frame_count` previous frames and

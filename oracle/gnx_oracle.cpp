@@ -267,4 +267,27 @@ int gnxo_light_le(gnxo_scene *s, int light, const gnxr_ray *rays, int64_t n, flo
     return 0;
 }
 
+// FrameBuffer::update_f_u_c (ui/FrameBuffer.h:127-149) for every pixel and channel 0..2, as SamplerIntegrator::Render calls it
+// (core/Integrator.cpp:307-310), plus set_uc(i, j, 3, 255): running mean over `frame_count` (= curRenderCount) Render() calls, tone map
+// 1 - expf(-x / (1 - 0.75)), implicit float -> unsigned char conversion.  `mean` is the fbuffer plane (RGBA, updated in place).
+int gnxo_framebuffer_update(float *mean, const float *frame, int32_t width, int32_t height, int32_t frame_count, uint8_t *rgba8) {
+    if (!mean || !frame || !rgba8 || width <= 0 || height <= 0 || frame_count <= 0) return -1;
+    const int curRenderCount = frame_count, channals = 4;
+    for (int h = 0; h < height; ++h)
+        for (int w = 0; w < width; ++w) {
+            for (int shifting = 0; shifting < 3; ++shifting) {
+                const float dat = frame[(w + h * width) * channals + shifting];
+                int offset = (w + h * width) * channals + shifting;
+                float weight = (1.0f / (float)curRenderCount);
+                float fValue = weight * dat + (1.0f - weight) * mean[offset];
+                mean[offset] = fValue;
+                float exposure = 0.75;
+                float temp_c = 1.0f - expf(-mean[offset] * 1.0f / (1 - exposure));
+                rgba8[offset] = (unsigned char)(temp_c * 255);
+            }
+            rgba8[(w + h * width) * channals + 3] = 255;
+        }
+    return 0;
+}
+
 }  // extern "C"

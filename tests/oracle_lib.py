@@ -45,6 +45,7 @@ def olib():
         L.gnxo_bsdf_probe.argtypes = [VP, P(_abi.Ray), P(f32), P(f32), i64, C.c_int, P(f32)]
         L.gnxo_light_probe.argtypes = [VP, C.c_int, C.c_int, P(f32), P(f32), P(f32), P(f32), i64, P(f32)]
         L.gnxo_light_le.argtypes = [VP, C.c_int, P(_abi.Ray), i64, P(f32)]
+        L.gnxo_framebuffer_update.argtypes = [P(f32), P(f32), i32, i32, i32, P(u8)]
         _olib = L
     return _olib
 
@@ -127,6 +128,16 @@ class OracleScene:
         out = np.zeros((len(rays), 3), np.float32)
         olib().gnxo_light_le(self._h, light, rays.ctypes.data_as(C.POINTER(_abi.Ray)), len(rays), _fp(out))
         return out
+
+
+def oracle_framebuffer_update(running_mean, frame, frame_count):
+    """FrameBuffer::update_f_u_c restated (oracle/gnx_oracle.cpp): updates running_mean in place, returns the RGBA8 plane."""
+    h, w = frame.shape[:2]
+    frame = np.ascontiguousarray(frame, np.float32)
+    rgba8 = np.zeros((h, w, 4), np.uint8)
+    rc = olib().gnxo_framebuffer_update(_fp(running_mean), _fp(frame), w, h, int(frame_count), rgba8.ctypes.data_as(C.POINTER(C.c_uint8)))
+    assert rc == 0
+    return rgba8
 
 
 def oracle_halton(width, height, px, py, s, dim):

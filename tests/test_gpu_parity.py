@@ -243,8 +243,7 @@ def test_cfg4_at_full_resolution_against_oracle(gpu):
         acc += part
         rays += s["rays_closest"] + s["rays_any"]
     assert (acc.view(np.uint32) == img.view(np.uint32)).all() and rays == st["rays_closest"] + st["rays_any"]
-    # escaped camera rays see the map: the sky part of the image is lit by Le alone
-    assert img[..., :3].max() > 1.0 and np.isfinite(img).all()
+    assert np.isfinite(img).all() and img[..., :3].min() >= 0 and img[..., :3].max() * (1024 / 2) > 1.0   # (two of 1024 samples, divided by 1024)
 
 
 def test_dragon_scene_against_oracle(gpu):
@@ -548,18 +547,24 @@ def test_edge_cases(gpu):
 
 
 def test_framebuffer_update_matches_ui_framebuffer(gpu):
-    """FrameBuffer::update_f_u_c (ui/FrameBuffer.h:127-149): running mean over Render() calls + 1-exp(-4x)."""
+    """FrameBuffer::update_f_u_c (ui/FrameBuffer.h:127-149): running mean over Render() calls + 1 - expf(-4x) -> uint8, against the
+    oracle's restatement of that function, BYTE for byte (the device's expf carries glibc's bits), over five folded frames whose
+    values span the tone curve (0, denormal-small, around every uint8 step, saturating)."""
     rng = np.random.default_rng(3)
-    f1, f2 = (rng.random((9, 13, 4)).astype(np.float32) * 2 for _ in range(2))
-    mean = np.zeros_like(f1)
-    u1 = gpu.framebuffer_update(mean, f1, 1)
-    assert biteq(mean[..., :3], f1[..., :3])
-    u2 = gpu.framebuffer_update(mean, f2, 2)
-    w = np.float32(0.5)
-    expect = w * f2 + (np.float32(1) - w) * f1
-    assert biteq(mean[..., :3], expect[..., :3])
-    tm = (1.0 - np.exp(-expect.astype(np.float64) / 0.25)) * 255
-    assert np.abs(u2[..., :3].astype(np.float64) - np.floor(tm[..., :3])).max() <= 1 and (u2[..., 3] == 255).all()
+    H, W = 37, 53
+    mean_d = np.zeros((H, W, 4), np.float32)
+    mean_o = np.zeros((H, W, 4), np.float32)
+    for k in range(1, 6):
+        f = (rng.random((H, W, 4)) ** 3 * (4.0 if k % 2 else 0.2)).astype(np.float32)
+        f[0, :8, :3] = [[0.0], [1e-30], [1e-8], [0.25 * np.log(2.0)], [10.0], [1e30], [0.001], [88.0]]   # edge values (the mean of non-negative frames stays >= 0)
+        u_d = gpu.framebuffer_update(mean_d, f, k)
+        u_o = ol.oracle_framebuffer_update(mean_o, f, k)
+        assert biteq(mean_d[..., :3], mean_o[..., :3])
+        assert (u_d == u_o).all() and (u_d[..., 3] == 255).all()
+    assert len(np.unique(u_d[..., :3])) > 200   # the comparison covered the whole tone curve
+    # and the closed form agrees to within the rounding of expf (sanity of the restatement itself)
+    tm = (1.0 - np.exp(-mean_o[..., :3].astype(np.float64) / 0.25)) * 255
+    assert np.abs(u_o[..., :3].astype(np.float64) - np.floor(tm)).max() <= 1
 
 
 def test_c_caller_renders_the_default_scene(gpu, tmp_path):
