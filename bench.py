@@ -210,39 +210,47 @@ def load_profile_json(name, args, sps, world):
 
 
 def roofline(kernel, secs, launches, units, unit_name, bytes_per_unit, byte_terms, args, sps, world, valu_peak_ginst, extra):
-    """Two ceilings for the dominant kernel, each a fraction <= 1 of a stated peak; `bound` names the higher one.
-    hbm : ALGORITHMIC bytes per unit (counted on the walk that is timed) x units per launch / HIP-event launch time vs 8 TB/s;
-          beside it the bytes the PMC counters saw (`traffic`, separate FETCH_SIZE / WRITE_SIZE passes, profiles/).
+    """Two ceilings for the dominant kernel, each a fraction of a stated peak; `bound` names the one the kernel sits closer to.
+    hbm : bytes that actually reached HBM per launch (PMC: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes, profiles/) over the
+          HIP-event launch time vs 8 TB/s.  The ALGORITHMIC byte rate (SURVEY 8d's model, counted on the walk that is timed) stands
+          beside it: the 11 MB of nodes and triangles are served by L2 / Infinity Cache, so that rate is a cache-level figure and may
+          exceed the HBM peak -- it is reported as `algorithmic_GBps`, never as a fraction of HBM.
     valu: VALU wave-instructions per unit (SQ_INSTS_VALU of a kept --pmc pass) x units / time vs the issue rate a saturating
           v_fma_f32 loop reaches on this device (measured in this run by gnxr_probe_valu_peak)."""
     avg_s = secs / launches
     upl = units / launches
-    hbm_alg = upl * bytes_per_unit / avg_s / 1e9
+    alg = upl * bytes_per_unit / avg_s / 1e9
+    one = unit_name[:-1]
     r = {"kernel": kernel, "launches": launches, "avg_launch_ms": avg_s * 1e3, unit_name + "_per_launch": upl,
-         "bytes_per_" + unit_name[:-1]: bytes_per_unit, "byte_model": byte_terms}
+         "bytes_per_" + one: bytes_per_unit, "byte_model": byte_terms, "algorithmic_bytes_per_launch": upl * bytes_per_unit}
     r.update(extra)
-    hbm = {"achieved": hbm_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_alg / HBM_PEAK_GBS}
+    hbm = {"achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "algorithmic_GBps": alg}
     traffic = None
     tj = load_profile_json("traffic_latest.json", args, sps, world)
     if tj and kernel in tj:
         traffic = tj[kernel].get("hbm_bytes_per_launch")
-        hbm["traffic_source"] = {"file": "profiles/traffic_latest.json", "commit": tj.get("_measured_on", {}).get("commit"),
-                                 "raw_bytes_per_launch": tj[kernel].get("hbm_bytes_per_launch_uncorrected")}
-        hbm["hbm_frac_measured"] = traffic / avg_s / 1e9 / HBM_PEAK_GBS   # FETCH x 2 (gfx950 correction) + WRITE, over the HIP-event time
+        meas = traffic / avg_s / 1e9
+        hbm.update({"achieved": meas, "frac": meas / HBM_PEAK_GBS, "algorithmic_over_measured": upl * bytes_per_unit / traffic,
+                    "traffic_source": {"file": "profiles/traffic_latest.json", "commit": tj.get("_measured_on", {}).get("commit"),
+                                       "raw_bytes_per_launch": tj[kernel].get("hbm_bytes_per_launch_uncorrected"),
+                                       "correction": "FETCH_SIZE x 2 (gfx950, MI355X_MICROARCH.md) + WRITE_SIZE"}})
     valu = None
     pj = load_profile_json("pmc_latest.json", args, sps, world)
     if pj and kernel in pj and valu_peak_ginst:
         k = pj[kernel]
-        per_unit = k["valu_insts_per_launch"] / upl
         ach = k["valu_insts_per_launch"] / avg_s / 1e9
         valu = {"achieved": ach, "peak": valu_peak_ginst, "unit": "G wave-instr/s", "frac": ach / valu_peak_ginst,
-                "wave_insts_per_" + unit_name[:-1]: per_unit, "lane_util": k.get("lane_util"), "valu_busy_pmc": k.get("valu_busy"),
+                "wave_insts_per_" + one: k["valu_insts_per_launch"] / upl, "lane_util": k.get("lane_util"), "valu_busy_pmc": k.get("valu_busy"),
                 "wait_frac": k.get("wait_frac"), "waves_per_simd": k.get("waves_per_simd"),
                 "source": {"file": "profiles/pmc_latest.json", "commit": pj.get("_measured_on", {}).get("commit")},
                 "peak_source": "gnxr_probe_valu_peak in this run: independent v_fma_f32 chains, 8 waves per SIMD on every CU"}
-    pick = valu if (valu and valu["frac"] >= hbm["frac"]) else hbm
-    r.update({"bound": "valu" if pick is valu else "hbm", "achieved": pick["achieved"], "peak": pick["peak"], "unit": pick["unit"],
-              "frac": pick["frac"], "traffic": traffic, "hbm": hbm, "valu": valu})
+    cands = [(c["frac"], n, c) for n, c in (("valu", valu), ("hbm", hbm)) if c and c["frac"] is not None]
+    if cands:
+        _, name, pick = max(cands, key=lambda t: t[0])
+        r.update({"bound": name, "achieved": pick["achieved"], "peak": pick["peak"], "unit": pick["unit"], "frac": pick["frac"]})
+    else:   # no counter file for this launch size: nothing measured to price against
+        r.update({"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None})
+    r.update({"traffic": traffic, "hbm": hbm, "valu": valu})
     return r
 
 

@@ -61,6 +61,13 @@ def init(device_id=0):
     _check(lib().gnxr_init(int(device_id)))
 
 
+def init_devices(device_ids):
+    """One process, several devices: scenes created afterwards are replicated on all of them and Render() shards the image rows
+    over them (gnxr_init_devices)."""
+    ids = (C.c_int32 * len(device_ids))(*[int(d) for d in device_ids])
+    _check(lib().gnxr_init_devices(len(device_ids), ids))
+
+
 class SceneBuilder:
     """Mirror of the scene-authoring free functions in ui/ModelList.cpp / ui/MaterialList.cpp."""
 

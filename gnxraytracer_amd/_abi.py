@@ -115,6 +115,7 @@ PROTOTYPES = {
     "gnxr_init": (C.c_int, [C.c_int]),
     "gnxr_shutdown": (None, []),
     "gnxr_last_error": (C.c_char_p, []),
+    "gnxr_init_devices": (C.c_int, [i32, P(i32)]),
     "gnxr_set_profiling": (C.c_int, [C.c_int]),
     "gnxr_probe_valu_peak": (C.c_int, [P(C.c_double)]),
     "gnxr_scene_create": (C.c_int, [P(SceneDesc), P(VP)]),

@@ -6,13 +6,17 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include <hipcub/hipcub.hpp>
 
 #include "host_scene.h"
 #include "kernels.hip.h"
+#include "trace4_kernel.hip.h"
 #include "kernel_instances.h"
 
 using namespace gnxr;
@@ -46,9 +50,10 @@ int hip_status(hipError_t e) {
 }
 
 int g_device = -1;
+std::vector<int> g_devices;        // gnxr_init_devices: every scene is replicated on these and renders shard their rows over them
 int g_num_cus = 256;
 int g_profiling = 0;
-int g_trace_blocks_per_cu = 6;   // GNXR_TRACE_BLOCKS_PER_CU overrides (tuning)
+int g_trace_blocks_per_cu = 5;   // persistent blocks of the traversal kernel per CU (5 waves per SIMD at its 96 VGPRs, 32 KB of LDS each); GNXR_TRACE_BLOCKS_PER_CU overrides (tuning)
 
 // Per-kernel timing with HIP events on the render stream.  Events are recycled from a pool and resolved
 // after the stream has been synchronised.
@@ -170,6 +175,8 @@ struct gnxr_scene {
     bool wide_ok = true;   // 4-wide traversal usable (leaf sizes / triangle count fit the reference encoding)
     std::recursive_mutex render_mutex;   // one render in flight per handle; gnxr_render holds it around its staging buffer too
     int device = 0;                      // the HIP device the tables live on
+    std::vector<std::unique_ptr<gnxr_scene>> replicas;   // the same scene on the other devices of gnxr_init_devices (element 0 of that list is this one)
+    DevBuf<float4> shard_out;            // a replica's full-size output plane; its rows are peer-copied into the primary's image
 
     int bind() const { HIP_TRY(hipSetDevice(device)); return GNXR_OK; }
     ~gnxr_scene() { if (h_counters) (void)hipHostFree(h_counters); }
@@ -343,33 +350,53 @@ int gnxr_init(int device_id) {
     if (device_id < 0 || device_id >= n) { set_error("device %d out of range (%d visible)", device_id, n); return GNXR_ERR_INVALID; }
     HIP_TRY(hipSetDevice(device_id));
     g_device = -1;
+    g_devices.assign(1, device_id);
     return ensure_device();
 }
-void gnxr_shutdown(void) { g_device = -1; }
+int gnxr_init_devices(int32_t n_devices, const int32_t *device_ids) {
+    if (n_devices <= 0 || n_devices > 64 || !device_ids) { set_error("bad device list"); return GNXR_ERR_INVALID; }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { set_error("no HIP device available; libgnxr has no CPU fallback"); return GNXR_ERR_NO_DEVICE; }
+    for (int i = 0; i < n_devices; ++i)
+        if (device_ids[i] < 0 || device_ids[i] >= n) { set_error("device %d out of range (%d visible)", device_ids[i], n); return GNXR_ERR_INVALID; }
+    int rc = gnxr_init(device_ids[0]);
+    if (rc) return rc;
+    g_devices.assign(device_ids, device_ids + n_devices);
+    // peer access between the primary and the others (assembling the image); a refusal is not fatal: copies then stage through the host
+    for (int i = 1; i < n_devices; ++i) {
+        if (device_ids[i] == device_ids[0]) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, device_ids[0], device_ids[i]) == hipSuccess && can) {
+            (void)hipSetDevice(device_ids[0]); (void)hipDeviceEnablePeerAccess(device_ids[i], 0);
+            (void)hipSetDevice(device_ids[i]); (void)hipDeviceEnablePeerAccess(device_ids[0], 0);
+        }
+    }
+    (void)hipGetLastError();   // "peer access already enabled" is fine
+    HIP_TRY(hipSetDevice(device_ids[0]));
+    return GNXR_OK;
+}
+void gnxr_shutdown(void) { g_device = -1; g_devices.clear(); }
 int gnxr_set_profiling(int flags) { g_profiling = flags; return GNXR_OK; }
 #ifdef GX_TRACE_STATS
 // development builds only (-DGX_TRACE_STATS): wave-level occupancy statistics of k_trace
-int gnxr_debug_trace_stats(unsigned long long *out16, int reset) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_trace_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return GNXR_ERR_INVALID;
-    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_stats), z, sizeof(z)); }
+int gnxr_debug_trace_stats(unsigned long long *out16, int reset) {   // 24 slots
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_trace_stats), 24 * sizeof(unsigned long long)) != hipSuccess) return GNXR_ERR_INVALID;
+    if (reset) { unsigned long long z[24] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_stats), z, sizeof(z)); }
     return GNXR_OK;
 }
 #endif
 
-int gnxr_scene_create(const gnxr_scene_desc *desc, gnxr_scene **out) {
-    if (!desc || !out) { set_error("null argument"); return GNXR_ERR_INVALID; }
-    int rc = ensure_device();
-    if (rc) return rc;
-    gnxr_scene *s = new (std::nothrow) gnxr_scene();
-    if (!s) return GNXR_ERR_OOM;
-    s->device = g_device;
-    if (!compile_scene(desc, &s->cs, device_morton_sort)) { delete s; return GNXR_ERR_INVALID; }
+// device side of gnxr_scene_create: everything compile_scene produced goes to the scene's device
+static int upload_scene(gnxr_scene *s) {
     CompiledScene &cs = s->cs;
-    if (cs.bvh_max_depth + 1 > 64) { set_error("BVH depth %d exceeds the 64-entry traversal stack (BVHAccel.cpp:661)", cs.bvh_max_depth); delete s; return GNXR_ERR_UNSUPPORTED; }
+    int rc = s->bind();
+    if (rc) return rc;
+    if (cs.bvh_max_depth + 1 > 64) { set_error("BVH depth %d exceeds the 64-entry traversal stack (BVHAccel.cpp:661)", cs.bvh_max_depth); return GNXR_ERR_UNSUPPORTED; }
     s->stack_size = cs.bvh_max_depth + 1 <= 32 ? 32 : 64;
     s->wide_ok = cs.tris.size() < (1u << 24) && cs.stack4_need + 1 <= 128 && getenv("GNXR_BINARY_BVH") == nullptr;
     for (const DNode &n : cs.nodes) if ((n.meta & 0xffffu) > 127) s->wide_ok = false;
-#define UP(field) if ((rc = s->field.upload(cs.field)) != GNXR_OK) { delete s; return rc; }
+#define UP(field) if ((rc = s->field.upload(cs.field)) != GNXR_OK) return rc;
     UP(nodes) UP(nodes4) UP(tris) UP(leaf_boxes) UP(lights) UP(perms) UP(primes) UP(prime_sums) UP(prime_magic)
     UP(dmedia) UP(grid_density) UP(tri_media) UP(spheres) UP(textures) UP(tex_texels) UP(ewa_lut) UP(tri_uv) UP(tri_n) UP(tri_s)
     UP(env_texels) UP(env_cond_func) UP(env_cond_cdf) UP(env_cond_int) UP(env_marg_func) UP(env_marg_cdf)
@@ -383,15 +410,38 @@ int gnxr_scene_create(const gnxr_scene_desc *desc, gnxr_scene **out) {
             memset(&up[0], 0, sizeof(DMaterial));
             memcpy(&up[0], &tt, sizeof(tt));
             std::copy(src.begin(), src.end(), up.begin() + 1);
-            if ((rc = (k == 0 ? s->materials : s->materials_single).upload(up)) != GNXR_OK) { delete s; return rc; }
+            if ((rc = (k == 0 ? s->materials : s->materials_single).upload(up)) != GNXR_OK) return rc;
         }
     }
-    if ((rc = s->infinite.upload(cs.infinite_lights)) != GNXR_OK) { delete s; return rc; }
-    if ((rc = s->counters.alloc(1)) != GNXR_OK) { delete s; return rc; }
-    if (hipHostMalloc((void **)&s->h_counters, sizeof(Counters)) != hipSuccess) { set_error("hipHostMalloc failed"); delete s; return GNXR_ERR_OOM; }
+    if ((rc = s->infinite.upload(cs.infinite_lights)) != GNXR_OK) return rc;
+    if ((rc = s->counters.alloc(1)) != GNXR_OK) return rc;
+    if (hipHostMalloc((void **)&s->h_counters, sizeof(Counters)) != hipSuccess) { set_error("hipHostMalloc failed"); return GNXR_ERR_OOM; }
+    return GNXR_OK;
+}
+
+int gnxr_scene_create(const gnxr_scene_desc *desc, gnxr_scene **out) {
+    if (!desc || !out) { set_error("null argument"); return GNXR_ERR_INVALID; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    gnxr_scene *s = new (std::nothrow) gnxr_scene();
+    if (!s) return GNXR_ERR_OOM;
+    s->device = g_device;
+    if (!compile_scene(desc, &s->cs, device_morton_sort)) { delete s; return GNXR_ERR_INVALID; }
+    if ((rc = upload_scene(s)) != GNXR_OK) { delete s; return rc; }
+    // gnxr_init_devices: the same tables on every other device of the list (the host-side compilation is shared)
+    for (size_t i = 1; i < g_devices.size(); ++i) {
+        std::unique_ptr<gnxr_scene> r(new (std::nothrow) gnxr_scene());
+        if (!r) { delete s; return GNXR_ERR_OOM; }
+        r->device = g_devices[i];
+        r->cs = s->cs;
+        if ((rc = upload_scene(r.get())) != GNXR_OK) { delete s; (void)hipSetDevice(g_device); return rc; }
+        s->replicas.push_back(std::move(r));
+    }
+    if ((rc = s->bind()) != GNXR_OK) { delete s; return rc; }
+    const CompiledScene &cs = s->cs;
     if (getenv("GNXR_VERBOSE"))
-        fprintf(stderr, "[gnxr] scene: %zu tris, %zu nodes (depth %d), %zu 4-wide nodes (stack %d), wide=%d\n", cs.tris.size(), cs.nodes.size(), cs.bvh_max_depth,
-                cs.nodes4.size(), cs.stack4_need, (int)s->wide_ok);
+        fprintf(stderr, "[gnxr] scene: %zu tris, %zu nodes (depth %d), %zu 4-wide nodes (stack %d), wide=%d, %zu device(s)\n", cs.tris.size(), cs.nodes.size(), cs.bvh_max_depth,
+                cs.nodes4.size(), cs.stack4_need, (int)s->wide_ok, 1 + s->replicas.size());
     *out = s;
     return GNXR_OK;
 }
@@ -412,7 +462,8 @@ static int count_local_rows(const gnxr_render_params *p) {
     return rows;
 }
 
-int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba_out, void *hip_stream, gnxr_stats *stats) {
+// One device: the wavefront loop over the rows `pin` assigns to this shard, on the device the scene's tables live on.
+static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba_out, void *hip_stream, gnxr_stats *stats) {
     if (!s || !pin || !d_rgba_out) { set_error("null argument"); return GNXR_ERR_INVALID; }
     gnxr_render_params p = *pin;
     if (p.shard_count <= 0) p.shard_count = 1;
@@ -590,12 +641,18 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
             (void)hipMemsetAsync(&dctr->cursor, 0, sizeof(unsigned int), stream);
             // LDS traversal stack: one column per lane, depth from the BVH (binary walk: depth + 1; 4-wide walk: stack4_need)
             const bool wide = s->wide_ok && !counting;
-            int entries = wide ? s->cs.stack4_need + 1 : s->cs.bvh_max_depth + 2;
-            // k_trace needs ~80 VGPRs -> 6 waves per SIMD = 6 blocks of 4 waves per CU; keep the LDS part of the stack small
-            // enough for that (160 KB / 6 blocks / 1 KB per level = 26 levels), deeper levels spill to global memory
+            const int entries = wide ? s->cs.stack4_need + 1 : s->cs.bvh_max_depth + 2;
+            // 5 blocks of 4 waves per CU is what k_trace4's 96 VGPRs allow (5 waves per SIMD); the LDS of a block -- stack levels plus, for
+            // the 4-wide kernel, the set-up ray records and the node cache -- must fit 5 times into the 160 KB; deeper levels spill to
+            // global memory (LDS levels are worth more than a bigger node cache: profiles/README.md, r02 A/B table)
             const int per_cu = g_trace_blocks_per_cu;
-            int lds_entries = std::min(entries, std::max(4, (int)((160 * 1024) / per_cu / (kBlock * sizeof(int))) - 1));
-            size_t lds = (size_t)lds_entries * kBlock * sizeof(int);
+            // besides the stack: the set-up ray records, the top-of-tree node cache and the order table
+            const size_t fixed_b = wide ? (size_t)(kRayRecDwords + (spheres ? 1 : 0)) * kRqStride * sizeof(int) + (size_t)kTopCache * 128 + 128 : 0;
+            static const int lds_levels_cap = getenv("GNXR_TRACE_LDS_LEVELS") ? std::max(2, atoi(getenv("GNXR_TRACE_LDS_LEVELS"))) : 64;   // tuning knob
+            const int lds_entries = std::min(std::min(entries, lds_levels_cap), std::max(2, (int)(((160 * 1024) / per_cu - 1024 - fixed_b) / (kBlock * sizeof(int)))));
+            const bool spill_needed = entries > lds_entries;
+            const size_t lds = (size_t)lds_entries * kBlock * sizeof(int) + fixed_b;
+            const int n_top = (int)std::min<size_t>(kTopCache, s->cs.root4 >= 0 ? s->cs.nodes4.size() : 0);
             // persistent waves: enough blocks to fill the chip, never more than the work needs
             int blocks = (int)std::min<long long>((long long)g_num_cus * per_cu, (total + kBlock - 1) / kBlock);
             if (timing) timer.begin(0, stream);
@@ -605,13 +662,18 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
             static const int chunk_max = getenv("GNXR_TRACE_CHUNK") ? std::max(64, atoi(getenv("GNXR_TRACE_CHUNK")) / 64 * 64) : kTraceChunk;   // tuning knob
             const int chunk = (int)std::min<long long>(chunk_max, std::max<long long>(64, ((total + waves - 1) / waves + 63) / 64 * 64));
 #define GX_TRACE(C, W, S) hipLaunchKernelGGL((k_trace<C, W, S>), dim3(blocks), dim3(kBlock), lds, stream, sc, pa, w, &dctr->cursor, dctr, lds_entries, s->trace_spill.p, chunk)
-            if (spheres) {
-                if (counting) GX_TRACE(true, false, true); else if (wide && count_wide) GX_TRACE(true, true, true); else if (wide) GX_TRACE(false, true, true);
-                else if (count_wide) GX_TRACE(true, false, true); else GX_TRACE(false, false, true);
-            } else {
-                if (counting) GX_TRACE(true, false, false); else if (wide && count_wide) GX_TRACE(true, true, false); else if (wide) GX_TRACE(false, true, false);
-                else if (count_wide) GX_TRACE(true, false, false); else GX_TRACE(false, false, false);
+#define GX_TRACE4(C, S, P) hipLaunchKernelGGL((k_trace4<C, S, P>), dim3(blocks), dim3(kBlock), lds, stream, sc, pa, w, &dctr->cursor, dctr, lds_entries, s->trace_spill.p, chunk, n_top)
+#define GX_TRACE4_CS(C, S) do { if (spill_needed) GX_TRACE4(C, S, true); else GX_TRACE4(C, S, false); } while (0)
+            if (wide) {   // the 4-wide walk (trace4_kernel.hip.h); count_wide: its counting variant
+                if (spheres) { if (count_wide) GX_TRACE4_CS(true, true); else GX_TRACE4_CS(false, true); }
+                else { if (count_wide) GX_TRACE4_CS(true, false); else GX_TRACE4_CS(false, false); }
+            } else {      // the reference's binary tree: counting runs on BVHAccel's own walk, and scenes the 4-wide encoding cannot hold
+                const bool cnt = counting || count_wide;
+                if (spheres) { if (cnt) GX_TRACE(true, false, true); else GX_TRACE(false, false, true); }
+                else { if (cnt) GX_TRACE(true, false, false); else GX_TRACE(false, false, false); }
             }
+#undef GX_TRACE4_CS
+#undef GX_TRACE4
 #undef GX_TRACE
             if (timing) timer.end(stream);
             rays_closest += (unsigned long long)w.n_closest + (unsigned long long)n_mis;
@@ -808,6 +870,76 @@ int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgb
     return GNXR_OK;
 }
 
+// Several devices behind one handle (gnxr_init_devices): the rows of this render are dealt round-robin over the devices, each
+// device renders its rows concurrently (one host thread and one stream per device, nothing exchanged during rendering) into a
+// full-size plane of its own, and the rows are then copied into the caller's image on the primary device (peer copies over xGMI,
+// one strided 2D copy per device).  A single device takes the direct path.
+static int render_sharded(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba_out, void *hip_stream, gnxr_stats *stats) {
+    if (!s || !pin || !d_rgba_out) { set_error("null argument"); return GNXR_ERR_INVALID; }
+    const int nd = 1 + (int)s->replicas.size();
+    if (nd == 1) return render_one(s, pin, d_rgba_out, hip_stream, stats);
+    gnxr_render_params base = *pin;
+    if (base.shard_count <= 0) base.shard_count = 1;
+    if (base.shard_rows <= 0) base.shard_rows = 1;
+    if (base.shard_rows != 1) { set_error("multi-device rendering deals single rows: shard_rows must be 1"); return GNXR_ERR_UNSUPPORTED; }
+    if (base.width <= 0 || base.height <= 0 || base.shard_index < 0 || base.shard_index >= base.shard_count) { set_error("invalid render parameters"); return GNXR_ERR_INVALID; }
+    std::lock_guard<std::recursive_mutex> lock(s->render_mutex);
+    const size_t npx = (size_t)base.width * base.height;
+    std::vector<int> rcs(nd, GNXR_OK);
+    std::vector<std::string> errs(nd);
+    std::vector<gnxr_stats> sts(nd);
+    hipStream_t caller = (hipStream_t)hip_stream;
+    int rc = s->bind();
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(caller));   // the image must be safe to write from the other devices' streams
+    auto worker = [&](int i) {
+        gnxr_scene *r = i == 0 ? s : s->replicas[i - 1].get();
+        gnxr_render_params p = base;   // rows y == shard_index (mod shard_count) of the caller, every nd-th of them
+        p.shard_index = base.shard_index + base.shard_count * i;
+        p.shard_count = base.shard_count * nd;
+        int rc_ = r->bind();
+        void *dst = d_rgba_out;
+        if (rc_ == GNXR_OK && i > 0) { rc_ = r->shard_out.alloc(npx); dst = r->shard_out.p; }
+        if (rc_ == GNXR_OK) rc_ = render_one(r, &p, dst, i == 0 ? hip_stream : nullptr, &sts[i]);
+        if (rc_ == GNXR_OK && i > 0) {
+            // rows p.shard_index, + p.shard_count, ...: one strided copy into the primary's image (UVA: the runtime routes it over the peer link)
+            const int first = p.shard_index, step = p.shard_count;
+            const int rows = first < base.height ? (base.height - first + step - 1) / step : 0;
+            const size_t rowb = (size_t)base.width * sizeof(float4);
+            if (rows > 0) {
+                hipError_t e = hipMemcpy2DAsync((char *)d_rgba_out + (size_t)first * rowb, rowb * step, (const char *)dst + (size_t)first * rowb, rowb * step, rowb, rows,
+                                                hipMemcpyDeviceToDevice, nullptr);
+                if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+                if (e != hipSuccess) { set_error("peer copy from device %d failed: %s", r->device, hipGetErrorString(e)); rc_ = hip_status(e); }
+            }
+        }
+        rcs[i] = rc_;
+        if (rc_ != GNXR_OK) errs[i] = get_error();
+    };
+    std::vector<std::thread> pool;
+    for (int i = 1; i < nd; ++i) pool.emplace_back(worker, i);
+    worker(0);
+    for (auto &t : pool) t.join();
+    (void)s->bind();
+    for (int i = 0; i < nd; ++i) if (rcs[i] != GNXR_OK) { set_error("device %d: %s", i == 0 ? s->device : s->replicas[i - 1]->device, errs[i].c_str()); return rcs[i]; }
+    if (stats) {
+        *stats = sts[0];
+        for (int i = 1; i < nd; ++i) {
+            const gnxr_stats &t = sts[i];
+            stats->rays_closest += t.rays_closest; stats->rays_any += t.rays_any; stats->camera_samples += t.camera_samples;
+            stats->nodes_visited += t.nodes_visited; stats->tris_tested += t.tris_tested; stats->kernel_launches += t.kernel_launches;
+            stats->rays_closest_nee += t.rays_closest_nee; stats->media_segments += t.media_segments; stats->media_steps += t.media_steps; stats->leaf_retests += t.leaf_retests;
+            stats->seconds_render = std::max(stats->seconds_render, t.seconds_render); stats->seconds_total = std::max(stats->seconds_total, t.seconds_total);
+            stats->passes = std::max(stats->passes, t.passes);
+        }
+    }
+    return GNXR_OK;
+}
+
+int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba_out, void *hip_stream, gnxr_stats *stats) {
+    return render_sharded(s, pin, d_rgba_out, hip_stream, stats);
+}
+
 int gnxr_render(gnxr_scene *s, const gnxr_render_params *p, float *rgba_out, gnxr_stats *stats) {
     if (!s || !p || !rgba_out) { set_error("null argument"); return GNXR_ERR_INVALID; }
     if (p->width <= 0 || p->height <= 0) { set_error("invalid image size"); return GNXR_ERR_INVALID; }
@@ -817,7 +949,7 @@ int gnxr_render(gnxr_scene *s, const gnxr_render_params *p, float *rgba_out, gnx
     int rc = s->out.alloc(npx);
     if (rc) return rc;
     HIP_TRY(hipMemset(s->out.p, 0, npx * sizeof(float4)));
-    rc = gnxr_render_device(s, p, s->out.p, nullptr, stats);
+    rc = render_sharded(s, p, s->out.p, nullptr, stats);
     if (rc) return rc;
     // copy back only the rows this shard owns
     int sc = p->shard_count > 0 ? p->shard_count : 1, sr = p->shard_rows > 0 ? p->shard_rows : 1;

@@ -31,6 +31,7 @@ struct DNode4 {
 };
 static_assert(sizeof(DNode4) == 128, "DNode4 must be 128 bytes");
 constexpr int32_t kNode4Empty = 0x7ffffffe;
+constexpr int kTopNodesMax = 1024;   // DNode4[0 .. kTopNodesMax) are the top of the tree in breadth-first order (scene_compile.cpp); the traversal kernel caches a prefix of them in LDS
 constexpr int32_t kRefDone = 0x7fffffff;
 
 // Triangle in BVH-leaf order: three dwordx4.  .w lanes carry the ids the shading stage needs.

@@ -927,6 +927,31 @@ bool compile_scene(const gnxr_scene_desc *d, CompiledScene *cs, MortonSortFn mor
     cs->stack4_need = 1;
     cs->root4 = collapse(cs->nodes, 0, cs->nodes4, 0, &cs->stack4_need);
     if (cs->nodes4.empty()) cs->nodes4.push_back(DNode4());
+    else if (cs->root4 >= 0) {
+        // Renumber the 4-wide nodes: the top of the tree in breadth-first order (indices [0, kTopNodes): what the traversal kernel keeps in
+        // LDS), everything below in the depth-first order `collapse` produced (subtrees stay compact in memory).  Node numbers are only
+        // addresses: the child slots, their boxes and the visiting-order tables are untouched, so the walk is the same walk.
+        const size_t n = cs->nodes4.size();
+        std::vector<int32_t> order;
+        order.reserve(n);
+        std::vector<char> placed(n, 0);
+        std::vector<int32_t> frontier{cs->root4};
+        for (size_t head = 0; head < frontier.size() && order.size() < (size_t)kTopNodesMax; ++head) {
+            const int32_t o = frontier[head];
+            order.push_back(o); placed[o] = 1;
+            for (int k = 0; k < 4; ++k) if (cs->nodes4[o].child[k] >= 0 && cs->nodes4[o].child[k] != kNode4Empty) frontier.push_back(cs->nodes4[o].child[k]);
+        }
+        for (size_t o = 0; o < n; ++o) if (!placed[o]) order.push_back((int32_t)o);
+        std::vector<int32_t> new_of(n);
+        for (size_t i = 0; i < n; ++i) new_of[order[i]] = (int32_t)i;
+        std::vector<DNode4> re(n);
+        for (size_t i = 0; i < n; ++i) {
+            re[i] = cs->nodes4[order[i]];
+            for (int k = 0; k < 4; ++k) if (re[i].child[k] >= 0 && re[i].child[k] != kNode4Empty) re[i].child[k] = new_of[re[i].child[k]];
+        }
+        cs->nodes4.swap(re);
+        cs->root4 = new_of[cs->root4];
+    }
     // bounds of every leaf of the binary tree, addressed by the leaf's first triangle: BVHAccel::Intersect tests a leaf's OWN box when
     // it pops the node (BVHAccel.cpp:665), the 4-wide walk re-tests it against the tMax of that moment (trace_kernel.hip.h, phase B)
     cs->leaf_boxes.assign((size_t)d->n_triangles * 8, 0.f);

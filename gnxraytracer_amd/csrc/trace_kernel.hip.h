@@ -130,7 +130,7 @@ GX_DEV int bvh4_step(const float4 *__restrict__ n4, int node, V3 ro, V3 invDir, 
 }
 
 #ifdef GX_TRACE_STATS
-static __device__ unsigned long long g_trace_stats[16];
+static __device__ unsigned long long g_trace_stats[24];
 #define GX_STAT(i, v) do { if (lane == 0) st_[i] += (unsigned long long)(v); } while (0)
 #else
 #define GX_STAT(i, v) do {} while (0)
@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
     int cur = -1, toVisit = 0, leafOff = 0, leafN = 0, hitLeaf = -1, expect = -1;
     uint32_t cntNodes = 0, cntTris = 0, cntRetests = 0;
 #ifdef GX_TRACE_STATS
-    unsigned long long st_[16] = {0};
+    unsigned long long st_[24] = {0};
 #endif
 
     while (true) {
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
         }
     }
 #ifdef GX_TRACE_STATS
-    if (lane == 0) for (int i = 0; i < 16; ++i) if (st_[i]) atomicAdd(&g_trace_stats[i], st_[i]);
+    if (lane == 0) for (int i = 0; i < 24; ++i) if (st_[i]) atomicAdd(&g_trace_stats[i], st_[i]);
 #endif
     if (COUNT) {
         atomicAdd(&ctr->nodes, (unsigned long long)cntNodes);

@@ -301,6 +301,14 @@ typedef struct gnxr_scene gnxr_scene;
 int gnxr_abi_version(void);
 int gnxr_abi_sizeof(int which);        /* sizeof of the structs above in declaration order (binding self-check) */
 int gnxr_init(int device_id);          /* binds the calling process to one HIP device    */
+/* One process, several devices (`gnxr_init(int n_devices, const int *device_ids)`): scenes created afterwards are
+ * replicated on every listed device and gnxr_render / gnxr_render_device deal the image rows round-robin over them, render the
+ * shards concurrently (one host thread + stream per device, no exchange during rendering) and assemble the FrameBuffer on
+ * device_ids[0] with one strided peer copy per device -- what the reference's single `integrator->Render(scene)` call
+ * (ui/RenderThread.cpp:175, core/Integrator.h:17-23) needs to use a whole node.  Results are bit-identical to one device's
+ * (pixels are independent).  The same id may be listed more than once (two shards sharing a device: how this path is tested on
+ * a one-GPU box).  Batched trace calls and probes run on device_ids[0].  gnxr_init(d) == gnxr_init_devices(1, &d).            */
+int gnxr_init_devices(int32_t n_devices, const int32_t *device_ids);
 void gnxr_shutdown(void);
 const char *gnxr_last_error(void);
 /* Measurement switches (process-wide).  bit 0: bracket every traversal kernel launch with HIP events on

@@ -1,24 +1,41 @@
-"""A/B timing of library builds on the headline workload (dev tool): python tests/dev_ab.py lib1.so lib2.so ..."""
+"""A/B timing of library builds / tuning knobs on the headline workload (dev tool).
+usage: python tests/dev_ab.py [--spp N] [--workload cfg3|cfg4] variant ...      variant = name[:lib.so][:ENV=VAL,ENV=VAL]
+Each variant runs in its own process (GNXR_LIB selects the build, the environment carries the knobs); prints one JSON line each."""
 import os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np, torch
     import gnxraytracer_amd as gx, scenes
+    spp, workload = int(sys.argv[2]), sys.argv[3]
     gx.init(0)
-    b = scenes.dragon_cornell(100000, "glass+metal")
+    b = scenes.dragon_cornell(100000, "glass+metal") if workload == "cfg3" else scenes.dragon_cornell(100000, "zoo", env=scenes.synthetic_env_path(1000, 500))
     scene = gx.Scene(b); integ = gx.PathIntegrator(8, 1.0, "spatial")
     out = torch.zeros((1080, 1920, 4), device="cuda")
     gx.lib().gnxr_set_profiling(1)
     best = None
     for rep in range(4):
-        st = integ.RenderDevice(scene, out.data_ptr(), 1920, 1080, 1024, spp_begin=8 * rep, spp_end=8 * rep + 8, samples_per_pass=8)
+        st = integ.RenderDevice(scene, out.data_ptr(), 1920, 1080, 1024, spp_begin=spp * rep, spp_end=spp * rep + spp, samples_per_pass=spp)
         if rep and (best is None or st["seconds_render"] < best["seconds_render"]): best = st
     rays = best["rays_closest"] + best["rays_any"]
-    print(json.dumps({"lib": os.environ.get("GNXR_LIB", "default"), "ms": best["seconds_render"] * 1e3, "Mrays/s": rays / best["seconds_render"] / 1e6,
-                      "trace_ms": best["seconds_closest"] * 1e3, "shade_ms": best["seconds_shade"] * 1e3, "combine_ms": best["seconds_nee"] * 1e3, "checksum": float(out.sum().item())}))
+    print(json.dumps({"variant": os.environ.get("GNXR_AB_NAME", "default"), "ms": round(best["seconds_render"] * 1e3, 3), "Mrays/s": round(rays / best["seconds_render"] / 1e6, 1),
+                      "trace_ms": round(best["seconds_closest"] * 1e3, 3), "shade_ms": round(best["seconds_shade"] * 1e3, 3), "combine_ms": round(best["seconds_nee"] * 1e3, 3),
+                      "checksum": float(out.double().sum().item())}))
 else:
-    for lib in sys.argv[1:]:
-        env = dict(os.environ, GNXR_LIB=os.path.abspath(lib))
-        r = subprocess.run([sys.executable, __file__, "--child"], env=env, capture_output=True, text=True)
-        print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ("FAILED " + lib + " " + r.stderr[-500:]), flush=True)
+    args = sys.argv[1:]
+    spp, workload = 32, "cfg3"
+    while args and args[0].startswith("--"):
+        if args[0] == "--spp": spp = int(args[1])
+        if args[0] == "--workload": workload = args[1]
+        args = args[2:]
+    for v in args:
+        parts = v.split(":")
+        env = dict(os.environ, GNXR_AB_NAME=parts[0])
+        for p in parts[1:]:
+            if "=" in p:
+                for kv in p.split(","):
+                    k, val = kv.split("="); env[k] = val
+            elif p:
+                env["GNXR_LIB"] = os.path.abspath(p)
+        r = subprocess.run([sys.executable, __file__, "--child", str(spp), workload], env=env, capture_output=True, text=True)
+        print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ("FAILED " + v + " " + r.stderr[-800:]), flush=True)
