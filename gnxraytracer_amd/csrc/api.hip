@@ -137,6 +137,7 @@ struct gnxr_scene {
     DevBuf<DNode4> nodes4;
     DevBuf<DTri> tris;
     DevBuf<float> leaf_boxes;
+    DevBuf<uint8_t> tri_class;
     DevBuf<DSphere> spheres;
     DevBuf<DMaterial> materials, materials_single;
     DevBuf<DTexture> textures;
@@ -188,6 +189,7 @@ struct gnxr_scene {
         d.root4 = cs.root4;
         d.tris = tris.p;
         d.leaf_box = reinterpret_cast<const float4 *>(leaf_boxes.p);
+        d.tri_class = tri_class.p;
         d.spheres = spheres.p;
         d.n_spheres = cs.n_spheres;
         d.materials = materials.p + 1;   // [0] carries the texture tables
@@ -397,7 +399,7 @@ static int upload_scene(gnxr_scene *s) {
     s->wide_ok = cs.tris.size() < (1u << 24) && cs.stack4_need + 1 <= 128 && getenv("GNXR_BINARY_BVH") == nullptr;
     for (const DNode &n : cs.nodes) if ((n.meta & 0xffffu) > 127) s->wide_ok = false;
 #define UP(field) if ((rc = s->field.upload(cs.field)) != GNXR_OK) return rc;
-    UP(nodes) UP(nodes4) UP(tris) UP(leaf_boxes) UP(lights) UP(perms) UP(primes) UP(prime_sums) UP(prime_magic)
+    UP(nodes) UP(nodes4) UP(tris) UP(leaf_boxes) UP(tri_class) UP(lights) UP(perms) UP(primes) UP(prime_sums) UP(prime_magic)
     UP(dmedia) UP(grid_density) UP(tri_media) UP(spheres) UP(textures) UP(tex_texels) UP(ewa_lut) UP(tri_uv) UP(tri_n) UP(tri_s)
     UP(env_texels) UP(env_cond_func) UP(env_cond_cdf) UP(env_cond_int) UP(env_marg_func) UP(env_marg_cdf)
 #undef UP
@@ -605,8 +607,11 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
     int class_mask = 0;
     for (const DMaterial &m : s->cs.materials) class_mask |= 1 << m.shade_class;
     const bool textured = (class_mask & 8) != 0;
-    bool area_only = true;
-    for (const gnxr_light &l : s->cs.desc_lights) if (l.type != GNXR_LIGHT_AREA_TRI) area_only = false;
+    bool area_only = true, area_env_only = true;
+    for (const gnxr_light &l : s->cs.desc_lights) {
+        if (l.type != GNXR_LIGHT_AREA_TRI) area_only = false;
+        if (l.type != GNXR_LIGHT_AREA_TRI && l.type != GNXR_LIGHT_INFINITE) area_env_only = false;
+    }
     KernelTimer timer;
     Counters *dctr = s->counters.p;
     for (int s0 = p.spp_begin; s0 < p.spp_end; s0 += k) {
@@ -807,6 +812,13 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
                     if (class_mask & 2) GX_SHADE(LM_GLOSSY, LT_AREA, 1);
                     if (class_mask & 4) GX_SHADE(LM_ALL, LT_AREA, 2);
                     if (class_mask & 8) GX_SHADE_TEX(LT_AREA);
+                } else if (area_env_only && !spheres && !(class_mask & 8)) {
+                    // BASELINE config 4's light set (area lights + one InfiniteAreaLight): without the delta-light and sky-box code
+#define GX_SHADE_AE(LMV, C) hipLaunchKernelGGL((k_shade<LMV, LT_AREA | LT_ENV, false>), g, b, 0, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C])
+                    GX_SHADE_AE(LM_DIFFUSE, 0);
+                    if (class_mask & 2) GX_SHADE_AE(LM_GLOSSY, 1);
+                    if (class_mask & 4) GX_SHADE_AE(LM_ALL, 2);
+#undef GX_SHADE_AE
                 } else {
                     GX_SHADE(LM_DIFFUSE, LT_ALL, 0);
                     if (class_mask & 2) GX_SHADE(LM_GLOSSY, LT_ALL, 1);

@@ -50,6 +50,7 @@ struct CompiledScene {
     int stack4_need = 1;                 // worst-case traversal stack entries for nodes4
     std::vector<DTri> tris;              // leaf order
     std::vector<float> leaf_boxes;       // 8 floats per leaf-order triangle, valid at the first triangle of each leaf: the leaf's LinearBVHNode bounds (lo.xyz hi.x | hi.yz 0 0)
+    std::vector<uint8_t> tri_class;      // per leaf-order triangle: DMaterial::shade_class of its material (0 for null materials): what k_trace writes into pclass
     std::vector<int32_t> leaf_of_prim;   // authoring index -> leaf index
     int bvh_max_depth = 0;
     Box3 world_bound;

@@ -58,6 +58,7 @@ struct DScene {
     const float4 *nodes4;   // DNode4[] as 8 float4 each
     int root4;
     const DTri *tris;
+    const unsigned char *tri_class;   // shade class of each leaf-order triangle's material (CompiledScene::tri_class)
     const float4 *leaf_box;   // 2 float4 per leaf-order triangle: bounds of the leaf that starts there (CompiledScene::leaf_boxes)
     const DSphere *spheres;   // tested before the BVH; hit code -2 - index
     int n_spheres;

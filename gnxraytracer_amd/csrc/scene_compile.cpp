@@ -1048,6 +1048,11 @@ bool compile_scene(const gnxr_scene_desc *d, CompiledScene *cs, MortonSortFn mor
             t.material = attr_copy[t.material];
         }
     }
+    cs->tri_class.assign(d->n_triangles, 0);
+    for (int li = 0; li < d->n_triangles; ++li) {
+        const int m = cs->tris[li].material;
+        if (m >= 0) cs->tri_class[li] = (uint8_t)cs->materials[m].shade_class;
+    }
     // ---- lights
     cs->lights.resize(std::max(1, d->n_lights));
     memset(cs->lights.data(), 0, sizeof(DLight) * cs->lights.size());

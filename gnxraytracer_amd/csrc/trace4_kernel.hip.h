@@ -393,8 +393,8 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
                 pa.hit[path] = hitLeaf;
                 int cls = 0;   // null materials (and misses that still have to collect an infinite light) use the code of class 0
                 if (SPH ? hitLeaf != -1 : hitLeaf >= 0) {
-                    int mat = (!SPH || hitLeaf >= 0) ? tris[hitLeaf].material : sc.spheres[-2 - hitLeaf].material;
-                    if (mat >= 0) cls = sc.materials[mat].shade_class;
+                    if (!SPH || hitLeaf >= 0) cls = sc.tri_class[hitLeaf];   // one byte instead of the triangle -> material -> class chain
+                    else { const int mat = sc.spheres[-2 - hitLeaf].material; if (mat >= 0) cls = sc.materials[mat].shade_class; }
                 } else if (sc.lt.n_infinite == 0) {
                     // a ray that escapes a scene without infinite lights adds nothing and ends its path (PathIntegrator.cpp:101-113):
                     // no shading class (4 is binned nowhere), so it does not take a lane in a k_shade wave

@@ -34,10 +34,33 @@ __global__ void __launch_bounds__(256) k_gather(const float4 *__restrict__ tab, 
             const float4 *p = tab + (size_t)(rec & 127u) * 8;
             float4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4], f = p[5], g = p[6], h = p[7];
             acc += a.x + b.y + c.z + d.w + e.x + f.y + g.z + h.w;
+        } else if (mode == 9) {
+            acc += 1.f;
         } else if (mode == 4) {   // own 64-byte record (4 dwordx4): half a line
             const float4 *p = tab + (size_t)rec * 8 + ((idx >> 4) & 1u) * 4;
             float4 a = p[0], b = p[1], c = p[2], d = p[3];
             acc += a.x + b.y + c.z + d.w;
+        } else if (mode == 6) {   // 8 random dword gathers inside a 32 KB window (L1 hits): the Halton permutation-table pattern
+            const float *p = reinterpret_cast<const float *>(tab);
+            unsigned j = idx >> 8;
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { s += p[(j >> r) & 8191u]; j = j * 747796405u + 2891336453u; }
+            acc += s;
+        } else if (mode == 7) {   // 8 random ushort gathers inside a 32 KB window
+            const unsigned short *p = reinterpret_cast<const unsigned short *>(tab);
+            unsigned j = idx >> 8;
+            unsigned s = 0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { s += p[(j >> r) & 16383u]; j = j * 747796405u + 2891336453u; }
+            acc += (float)s;
+        } else if (mode == 8) {   // 8 dword loads of the SAME address for all lanes (uniform table read through the vector path)
+            const float *p = reinterpret_cast<const float *>(tab);
+            unsigned j = __shfl(idx >> 8, 0);
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { s += p[(j >> r) & 8191u]; j = j * 747796405u + 2891336453u; }
+            acc += s;
         } else {                  // two 64-byte halves of two different records (8 dwordx4, 2 lines)
             const float4 *p = tab + (size_t)rec * 8, *q = tab + (size_t)((rec * 7919u) % nrec) * 8 + 4;
             float4 a = p[0], b = p[1], c = p[2], d = p[3], e = q[0], f = q[1], g = q[2], h = q[3];
@@ -55,7 +78,7 @@ int main(int argc, char **argv) {
     int per_cu = argc > 2 ? atoi(argv[2]) : 5;
     int blocks = 256 * per_cu; hipMalloc(&out, blocks * 256 * 4);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    for (int mode = 0; mode < 6; ++mode) {
+    for (int mode = 0; mode < 10; ++mode) {
         int iters = 2000;
         for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(a); hipLaunchKernelGGL(k_gather, dim3(blocks), dim3(256), 0, 0, tab, nrec, iters, mode, out); hipEventRecord(b); hipEventSynchronize(b);
