@@ -148,6 +148,7 @@ struct gnxr_scene {
     DevBuf<int32_t> primes, prime_sums;
     DevBuf<uint32_t> prime_magic;
     DevBuf<float> env_texels, env_cond_func, env_cond_cdf, env_cond_int, env_marg_func, env_marg_cdf;
+    DevBuf<uint16_t> env_marg_guide, env_cond_guide;
     DevBuf<float> grid_table;
     DevBuf<DMedium> dmedia;
     DevBuf<float> grid_density;
@@ -204,6 +205,7 @@ struct gnxr_scene {
         d.lt.env_texels = env_texels.p;
         d.lt.env_cond_func = env_cond_func.p; d.lt.env_cond_cdf = env_cond_cdf.p; d.lt.env_cond_int = env_cond_int.p;
         d.lt.env_marg_func = env_marg_func.p; d.lt.env_marg_cdf = env_marg_cdf.p;
+        d.lt.env_marg_guide = env_marg_guide.p; d.lt.env_cond_guide = env_cond_guide.p;
         d.st.perms = perms.p; d.st.primes = primes.p; d.st.prime_sums = prime_sums.p; d.st.prime_magic = prime_magic.p;
         d.st.h = make_halton(W, H);
         return d;
@@ -380,6 +382,14 @@ int gnxr_init_devices(int32_t n_devices, const int32_t *device_ids) {
 }
 void gnxr_shutdown(void) { g_device = -1; g_devices.clear(); }
 int gnxr_set_profiling(int flags) { g_profiling = flags; return GNXR_OK; }
+#ifdef GX_SHADE_STATS
+// development builds only (-DGX_SHADE_STATS): wave-time per section of k_shade
+int gnxr_debug_shade_stats(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_shade_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return GNXR_ERR_INVALID;
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_shade_stats), z, sizeof(z)); }
+    return GNXR_OK;
+}
+#endif
 #ifdef GX_TRACE_STATS
 // development builds only (-DGX_TRACE_STATS): wave-level occupancy statistics of k_trace
 int gnxr_debug_trace_stats(unsigned long long *out16, int reset) {   // 24 slots
@@ -401,7 +411,7 @@ static int upload_scene(gnxr_scene *s) {
 #define UP(field) if ((rc = s->field.upload(cs.field)) != GNXR_OK) return rc;
     UP(nodes) UP(nodes4) UP(tris) UP(leaf_boxes) UP(tri_class) UP(lights) UP(perms) UP(primes) UP(prime_sums) UP(prime_magic)
     UP(dmedia) UP(grid_density) UP(tri_media) UP(spheres) UP(textures) UP(tex_texels) UP(ewa_lut) UP(tri_uv) UP(tri_n) UP(tri_s)
-    UP(env_texels) UP(env_cond_func) UP(env_cond_cdf) UP(env_cond_int) UP(env_marg_func) UP(env_marg_cdf)
+    UP(env_texels) UP(env_cond_func) UP(env_cond_cdf) UP(env_cond_int) UP(env_marg_func) UP(env_marg_cdf) UP(env_marg_guide) UP(env_cond_guide)
 #undef UP
     {   // materials, preceded by one record that carries the texture tables (tex_tables(), device_texture.h)
         DTexTables tt;

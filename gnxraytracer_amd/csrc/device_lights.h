@@ -25,6 +25,7 @@ struct DLightTables {
     DEnv env;
     const float *env_texels;
     const float *env_cond_func, *env_cond_cdf, *env_cond_int, *env_marg_func, *env_marg_cdf;
+    const uint16_t *env_marg_guide, *env_cond_guide;   // FindInterval guide tables (scene_compile.cpp build_env)
 };
 
 struct LightSample {
@@ -51,8 +52,20 @@ GX_DEV int find_interval(const float *cdf, int size, float u) {  // GNXRayTracer
     }
     return min(max(first - 1, 0), size - 2);
 }
-GX_DEV float dist1d_sample_continuous(const float *func, const float *cdf, int n, float funcInt, float u, float *pdf, int *off) {
-    int offset = find_interval(cdf, n + 1, u);
+// the same search started from a guide table: guide[b] = number of cdf entries <= b / G, so for u in bucket b the partition point lies in
+// [guide[b], guide[b + 1]] and the bisection (same predicate) runs over those few entries only
+GX_DEV int find_interval_guided(const float *cdf, int size, float u, const uint16_t *guide, int G) {
+    const int b = min(max((int)(u * (float)G), 0), G - 1);
+    int first = guide[b], len = (int)guide[b + 1] - first;
+    while (len > 0) {
+        int half = len >> 1, middle = first + half;
+        if (cdf[middle] <= u) { first = middle + 1; len -= half + 1; }
+        else len = half;
+    }
+    return min(max(first - 1, 0), size - 2);
+}
+GX_DEV float dist1d_sample_continuous(const float *func, const float *cdf, int n, float funcInt, float u, float *pdf, int *off, const uint16_t *guide = nullptr, int G = 0) {
+    int offset = guide ? find_interval_guided(cdf, n + 1, u, guide, G) : find_interval(cdf, n + 1, u);
     *off = offset;
     float du = u - cdf[offset];
     if ((cdf[offset + 1] - cdf[offset]) > 0) du /= (cdf[offset + 1] - cdf[offset]);
@@ -145,8 +158,9 @@ GX_DEV LightSample light_sample(const DLightTables &t, int li, V3 refP, float u0
         const DEnv &e = t.env;
         float pdfs0, pdfs1;
         int v, dummy;
-        float d1 = dist1d_sample_continuous(t.env_marg_func, t.env_marg_cdf, e.dh, e.marg_func_int, u1, &pdfs1, &v);
-        float d0 = dist1d_sample_continuous(t.env_cond_func + (size_t)v * e.dw, t.env_cond_cdf + (size_t)v * (e.dw + 1), e.dw, t.env_cond_int[v], u0, &pdfs0, &dummy);
+        float d1 = dist1d_sample_continuous(t.env_marg_func, t.env_marg_cdf, e.dh, e.marg_func_int, u1, &pdfs1, &v, t.env_marg_guide, kEnvGuideMarg);
+        float d0 = dist1d_sample_continuous(t.env_cond_func + (size_t)v * e.dw, t.env_cond_cdf + (size_t)v * (e.dw + 1), e.dw, t.env_cond_int[v], u0, &pdfs0, &dummy,
+                                            t.env_cond_guide + (size_t)v * (kEnvGuideCond + 1), kEnvGuideCond);
         float mapPdf = pdfs0 * pdfs1;
         if (mapPdf == 0) return s;
         float theta = d1 * GX_PI, phi = d0 * 2 * GX_PI;

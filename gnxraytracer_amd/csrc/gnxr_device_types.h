@@ -119,6 +119,7 @@ struct DCamera {
     int32_t ortho;    // OrthographicCamera (camera/Orthographic.cpp) instead of PerspectiveCamera
 };
 
+constexpr int kEnvGuideMarg = 1024, kEnvGuideCond = 512;   // buckets of the FindInterval guide tables (powers of two: u * G is exact)
 struct DEnv {         // InfiniteAreaLight tables
     int32_t w, h;     // Lmap level-0 size
     int32_t dw, dh;   // distribution size (2w, 2h)

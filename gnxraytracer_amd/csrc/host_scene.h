@@ -76,6 +76,7 @@ struct CompiledScene {
     float env_power_lookup[3] = {0, 0, 0};   // Lmap->Lookup((.5,.5), .5), for InfiniteAreaLight::Power
     std::vector<float> env_cond_func, env_cond_cdf, env_cond_int;   // Distribution2D conditional rows
     std::vector<float> env_marg_func, env_marg_cdf;
+    std::vector<uint16_t> env_marg_guide, env_cond_guide;   // FindInterval guide tables (kEnvGuideMarg + 1 entries; per row kEnvGuideCond + 1)
     // media
     std::vector<gnxr_medium> media;
     std::vector<DMedium> dmedia;

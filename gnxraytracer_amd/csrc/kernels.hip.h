@@ -322,12 +322,24 @@ GX_DEV Spec nee_record_Ld(const PathArrays &pa, size_t rec, float *xw) {
 #endif
 // TEX: the queue holds hits on image-textured materials (shade class 3): Kd / Ks are looked up per hit, unfiltered -- PathIntegrator
 // slices the camera RayDifferential (`Ray ray(r)`, PathIntegrator.cpp:67), so ComputeDifferentials always takes its zero branch.
+#ifdef GX_SHADE_STATS
+// development builds only: wave-time (s_memtime ticks) per section of k_shade, summed over all waves
+static __device__ unsigned long long g_shade_stats[16];
+#define GX_STICK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) sst_[i] += t_ - stick_; stick_ = t_; } while (0)
+#else
+#define GX_STICK(i) do {} while (0)
+#endif
 template <uint32_t LM, int LT, bool SPH, bool TEX = false>
 __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRender r, PathArrays pa, const int *__restrict__ queue, const unsigned int *n_dev) {
     const int n = (int)*n_dev;
+#ifdef GX_SHADE_STATS
+    unsigned long long sst_[16] = {0};
+    unsigned long long stick_ = __builtin_amdgcn_s_memtime();
+#endif
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         bool survive = false, wantNee = false, wantShadow = false, wantMis = false;
         int path = -1;
+        GX_STICK(9);
         {
             path = queue[i];
             uint2 m = pa.meta[path];
@@ -366,6 +378,7 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
                     found = sp.valid;
                 }
             }
+            GX_STICK(0);   // state + triangle loads, tri_test, surface_point
             // PathIntegrator.cpp:101-111: emitted light at the vertex / from the environment
             if (bounces == 0 || specularBounce) {
                 if (found) {
@@ -374,6 +387,7 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
                     for (int k = 0; k < sc.lt.n_infinite; ++k) L = L + beta * light_Le<LT>(sc.lt, sc.lt.infinite[k], ro, rd);
                 }
             }
+            GX_STICK(1);   // Le
             if (found && bounces < r.max_depth) {
                 if (triMat < 0) {
                     // null material: skip the boundary, PathIntegrator.cpp:121-126 (bounces-- ; continue)
@@ -400,10 +414,12 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
                     if (mat->n_nonspecular > 0 && sc.lt.n_lights > 0) {
                         float lightPdfSel;
                         int lightNum = light_select(sc.lt, sp.p, ss.get1d(), &lightPdfSel);
+                        GX_STICK(2);   // light selection (1 Halton value + grid lookup)
                         if (lightPdfSel != 0) {
                             float ul0, ul1, us0, us1;
                             ss.get2d(&ul0, &ul1);
                             ss.get2d(&us0, &us1);
+                            GX_STICK(3);   // 4 Halton values
                             // ---- EstimateDirect, Integrator.cpp:93-210 (handleMedia = false, specular = false): the arithmetic of
                             // estimate_direct_record above, kept in line here (the factored call cost k_shade 3.5 % on cfg 3)
                             const int bsdfFlags = BSDF_ALL & ~BSDF_SPECULAR;
@@ -412,6 +428,7 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
                             Spec X(0.f), Y(0.f);
                             int expect = -1;
                             LightSample ls = light_sample<LT>(sc.lt, lightNum, sp.p, ul0, ul1);
+                            GX_STICK(4);   // light_sample
                             float scatteringPdf = 0;
                             if (ls.pdf > 0 && !ls.Li.is_black()) {
                                 Spec f = bsdf.f(woN, ls.wi, bsdfFlags) * absdot(ls.wi, sp.ns);
@@ -424,11 +441,13 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
                                     nflags |= 1;
                                 }
                             }
+                            GX_STICK(5);   // BSDF f / pdf towards the light sample, shadow ray
                             if (!light_is_delta<LT>(sc.lt.lights[lightNum])) {
                                 int sampledType;
                                 Spec f = bsdf.sample_f(woN, &wi2, us0, us1, &scatteringPdf, bsdfFlags, &sampledType);
                                 f = f * absdot(wi2, sp.ns);
                                 bool sampledSpecular = (sampledType & BSDF_SPECULAR) != 0;
+                                GX_STICK(6);   // BSDF sample_f of the MIS half
                                 if (!f.is_black() && scatteringPdf > 0) {
                                     float weight = 1;
                                     bool skip = false;
@@ -457,6 +476,7 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
                                     }
                                 }
                             }
+                            GX_STICK(7);   // light_pdf + MIS record
                             if (nflags) {
                                 pa.sh_o[path] = make_float4(so.x, so.y, so.z, 1 - GX_SHADOW_EPS);
                                 pa.sh_d[path] = make_float4(sd.x, sd.y, sd.z, __int_as_float(nflags));
@@ -473,6 +493,7 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
                             }
                         }
                     }
+                    GX_STICK(8);   // NEE record stores
                     // ---- BSDF sampling for the next path vertex, PathIntegrator.cpp:144-163
                     V3 wo = -rd, wi;
                     float pdf, u0, u1;
@@ -504,10 +525,14 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
                     }
                 }
             }
+            GX_STICK(10);  // continuation: 2 Halton values, BSDF sample_f, Russian roulette, state stores
             pa.L[path] = make_float4(L.r, L.g, L.b, 0.f);
         }
         pa.pflags[path] = (unsigned char)((survive ? 1 : 0) | (wantNee ? 2 : 0) | (wantShadow ? 4 : 0) | (wantMis ? 8 : 0));
     }
+#ifdef GX_SHADE_STATS
+    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 16; ++k) if (sst_[k]) atomicAdd(&g_shade_stats[k], sst_[k]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

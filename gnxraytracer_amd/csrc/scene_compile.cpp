@@ -771,6 +771,16 @@ static void build_env(const gnxr_scene_desc *d, const gnxr_light &l, bool flip_y
     cs->env_marg_func = cs->env_cond_int;
     cs->env_marg_cdf.resize(H2 + 1);
     dist1d(cs->env_marg_func.data(), H2, cs->env_marg_cdf.data(), &e.marg_func_int);
+    // Guide tables for FindInterval (GNXRayTracer.h:336-349) over the marginal and conditional cdfs: for bucket b of [0, 1) the entry is
+    // the number of cdf values <= b / G, so the answer for any u of the bucket lies between two neighbouring entries and the device
+    // bisects a handful of values instead of 1025 / 2049 (same predicate, same result -- the partition point is unique).
+    auto upper = [](const float *cdf, int size, float u) { int n = 0, len = size; while (len > 0) { int half = len >> 1; if (cdf[n + half] <= u) { n += half + 1; len -= half + 1; } else len = half; } return n; };
+    cs->env_marg_guide.resize(kEnvGuideMarg + 1);
+    for (int b = 0; b <= kEnvGuideMarg; ++b) cs->env_marg_guide[b] = b == kEnvGuideMarg ? (uint16_t)(H2 + 1) : (uint16_t)upper(cs->env_marg_cdf.data(), H2 + 1, (float)b / kEnvGuideMarg);
+    cs->env_cond_guide.resize((size_t)H2 * (kEnvGuideCond + 1));
+    for (int v = 0; v < H2; ++v)
+        for (int b = 0; b <= kEnvGuideCond; ++b)
+            cs->env_cond_guide[(size_t)v * (kEnvGuideCond + 1) + b] = b == kEnvGuideCond ? (uint16_t)(W2 + 1) : (uint16_t)upper(&cs->env_cond_cdf[(size_t)v * (W2 + 1)], W2 + 1, (float)b / kEnvGuideCond);
     // Preprocess: scene.WorldBound().BoundingSphere (InfiniteAreaLight.h:23-26)
     Vec3 c = (cs->world_bound.lo + cs->world_bound.hi) / 2;
     e.world_center[0] = c.x; e.world_center[1] = c.y; e.world_center[2] = c.z;
