@@ -209,14 +209,17 @@ def load_profile_json(name, args, sps, world):
     return tj
 
 
-def roofline(kernel, secs, launches, units, unit_name, bytes_per_unit, byte_terms, args, sps, world, valu_peak_ginst, extra):
-    """Two ceilings for the dominant kernel, each a fraction of a stated peak; `bound` names the one the kernel sits closer to.
-    hbm : bytes that actually reached HBM per launch (PMC: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes, profiles/) over the
-          HIP-event launch time vs 8 TB/s.  The ALGORITHMIC byte rate (SURVEY 8d's model, counted on the walk that is timed) stands
-          beside it: the 11 MB of nodes and triangles are served by L2 / Infinity Cache, so that rate is a cache-level figure and may
-          exceed the HBM peak -- it is reported as `algorithmic_GBps`, never as a fraction of HBM.
-    valu: VALU wave-instructions per unit (SQ_INSTS_VALU of a kept --pmc pass) x units / time vs the issue rate a saturating
-          v_fma_f32 loop reaches on this device (measured in this run by gnxr_probe_valu_peak)."""
+def roofline(kernel, secs, launches, units, unit_name, bytes_per_unit, byte_terms, args, sps, world, peaks, gathers_per_unit, extra):
+    """Three ceilings for the dominant kernel, each a fraction of a stated peak; `bound` names the one the kernel sits closest to.
+    hbm   : bytes that actually reached HBM per launch (PMC: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes, profiles/) over
+            the HIP-event launch time vs 8 TB/s.  The ALGORITHMIC byte rate (SURVEY 8d's model, counted on the walk that is timed)
+            stands beside it: nodes and triangles are served by LDS / L2 / Infinity Cache, so that rate is a cache-level figure and may
+            exceed the HBM peak -- it is reported as `algorithmic_GBps`, never as a fraction of HBM.
+    valu  : VALU wave-instructions per unit (SQ_INSTS_VALU of a kept --pmc pass) x units / time vs the issue rate a saturating
+            v_fma_f32 loop reaches on this device (gnxr_probe_valu_peak, measured in this run).
+    gather: per-lane vector-memory loads per unit (counted: 8 per node visit that reads memory, 3 per triangle, 2 per leaf re-test,
+            3 per ray for its record) x units / time vs the rate at which the device takes per-lane 16-byte gathers
+            (gnxr_probe_gather_peak, measured in this run: ~1.1 lanes per clock per CU, hit or miss, at any occupancy)."""
     avg_s = secs / launches
     upl = units / launches
     alg = upl * bytes_per_unit / avg_s / 1e9
@@ -236,21 +239,26 @@ def roofline(kernel, secs, launches, units, unit_name, bytes_per_unit, byte_term
                                        "correction": "FETCH_SIZE x 2 (gfx950, MI355X_MICROARCH.md) + WRITE_SIZE"}})
     valu = None
     pj = load_profile_json("pmc_latest.json", args, sps, world)
-    if pj and kernel in pj and valu_peak_ginst:
+    if pj and kernel in pj and peaks.get("valu"):
         k = pj[kernel]
         ach = k["valu_insts_per_launch"] / avg_s / 1e9
-        valu = {"achieved": ach, "peak": valu_peak_ginst, "unit": "G wave-instr/s", "frac": ach / valu_peak_ginst,
+        valu = {"achieved": ach, "peak": peaks["valu"], "unit": "G wave-instr/s", "frac": ach / peaks["valu"],
                 "wave_insts_per_" + one: k["valu_insts_per_launch"] / upl, "lane_util": k.get("lane_util"), "valu_busy_pmc": k.get("valu_busy"),
                 "wait_frac": k.get("wait_frac"), "waves_per_simd": k.get("waves_per_simd"),
                 "source": {"file": "profiles/pmc_latest.json", "commit": pj.get("_measured_on", {}).get("commit")},
                 "peak_source": "gnxr_probe_valu_peak in this run: independent v_fma_f32 chains, 8 waves per SIMD on every CU"}
-    cands = [(c["frac"], n, c) for n, c in (("valu", valu), ("hbm", hbm)) if c and c["frac"] is not None]
+    gather = None
+    if gathers_per_unit and peaks.get("gather"):
+        ach = upl * gathers_per_unit / avg_s / 1e9
+        gather = {"achieved": ach, "peak": peaks["gather"], "unit": "G lane-loads/s", "frac": ach / peaks["gather"], "lane_loads_per_" + one: gathers_per_unit,
+                  "peak_source": "gnxr_probe_gather_peak in this run: 8 dwordx4 of a random 128-byte record per lane, 8 MB table, 5 blocks per CU"}
+    cands = [(c["frac"], n, c) for n, c in (("valu", valu), ("gather", gather), ("hbm", hbm)) if c and c["frac"] is not None]
     if cands:
         _, name, pick = max(cands, key=lambda t: t[0])
         r.update({"bound": name, "achieved": pick["achieved"], "peak": pick["peak"], "unit": pick["unit"], "frac": pick["frac"]})
-    else:   # no counter file for this launch size: nothing measured to price against
+    else:   # no counter file for this launch size and no probe: nothing measured to price against
         r.update({"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None})
-    r.update({"traffic": traffic, "hbm": hbm, "valu": valu})
+    r.update({"traffic": traffic, "hbm": hbm, "valu": valu, "gather": gather})
     return r
 
 
@@ -446,8 +454,8 @@ def main():
 
     # ---- roofline of the dominant kernel (rank 0's launches, HIP events on the render stream)
     if not args.no_kernel_timing and tot["launches_closest"] > 0:
-        note("roofline: VALU issue probe + counting pass")
-        valu_peak = gx.probe_valu_peak()   # G wave-instructions / s a saturating v_fma_f32 loop reaches on this device, now
+        note("roofline: VALU issue and gather-rate probes + counting pass")
+        peaks = {"valu": gx.probe_valu_peak(), "gather": gx.probe_gather_peak()}   # what this device reaches on each, now
         # untimed counting pass of one sample per pixel: the WIDE (4-wide, speculative) walk that the timed kernel performs,
         # and the tracking-loop steps of k_vol_media
         gx.lib().gnxr_set_profiling(4)
@@ -456,7 +464,7 @@ def main():
         torch.cuda.synchronize()
         nr = stc["rays_closest"] + stc["rays_any"]
         n4, n_tris = stc["nodes_visited"] / nr, stc["tris_tested"] / nr
-        kernel_seconds = {"k_trace": tot["seconds_closest"], ("k_vol_media" if args.workload == "cfg5" else "k_nee_combine"): tot["seconds_nee"],
+        kernel_seconds = {"k_trace4": tot["seconds_closest"], ("k_vol_media" if args.workload == "cfg5" else "k_nee_combine"): tot["seconds_nee"],
                           ("k_vol_step+compaction" if args.workload == "cfg5" else "k_shade+compaction"): tot["seconds_shade"]}
         if args.workload == "cfg5" and tot["launches_nee"] > 0 and tot["seconds_nee"] >= tot["seconds_closest"]:
             # k_vol_media dominates cfg 5: unit = one medium segment (Medium::Sample / Medium::Tr of the ray in flight).
@@ -464,18 +472,22 @@ def main():
             # (two Halton draws per step read the permutation table: 2 B x digits, L2-resident, not charged)
             steps = stc["media_steps"] / max(1, stc["media_segments"])
             b_seg = 64.0 + 32.0 * steps
+            # per-lane loads: 8 density values per step + the permutation-table digits of its two Halton values (~2 x 5) + 4 per segment
             result["roofline"] = roofline("k_vol_media", tot["seconds_nee"], tot["launches_nee"], tot["media_segments"], "segments", b_seg,
-                                          "64 B per segment (ray, state, result) + 32 B per tracking step (8 density loads)", args, sps, world, valu_peak,
-                                          {"tracking_steps_per_segment": steps, "kernel_seconds": kernel_seconds})
+                                          "64 B per segment (ray, state, result) + 32 B per tracking step (8 density loads)", args, sps, world, peaks,
+                                          4.0 + 18.0 * steps, {"tracking_steps_per_segment": steps, "kernel_seconds": kernel_seconds})
         else:
-            n_re = stc["leaf_retests"] / nr
+            n_re, n_mem = stc["leaf_retests"] / nr, stc["nodes_from_memory"] / nr
             b_ray = 136.0 + 128.0 * n4 + 48.0 * n_tris + 32.0 * n_re   # SURVEY 8(d) with the node term of the tree that is walked: 128-B DNode4
-            result["roofline"] = roofline("k_trace", tot["seconds_closest"], tot["launches_closest"], rays, "rays", b_ray,
+            result["roofline"] = roofline("k_trace4", tot["seconds_closest"], tot["launches_closest"], rays, "rays", b_ray,
                                           "136 B records + 128 B x 4-wide nodes visited (speculative visits included) + 48 B x triangles tested + "
-                                          "32 B x leaf boxes re-tested, counted by k_trace<COUNT, WIDE> on the timed walk", args, sps, world, valu_peak,
-                                          {"nodes4_per_ray": n4, "tris_per_ray": n_tris, "leaf_retests_per_ray": n_re, "kernel_seconds": kernel_seconds})
-        result["roofline"]["note"] = ("the 11 MB of BVH + triangles live in L2 / Infinity Cache, so the algorithmic byte model over-states what "
-                                      "reaches HBM (see hbm.hbm_frac_measured); the kernel is bound by VALU issue at partial lane utilisation")
+                                          "32 B x leaf boxes re-tested, counted by k_trace4<COUNT> on the timed walk", args, sps, world, peaks,
+                                          8.0 * n_mem + 3.0 * n_tris + 2.0 * n_re + 3.0,
+                                          {"nodes4_per_ray": n4, "nodes4_from_memory_per_ray": n_mem, "tris_per_ray": n_tris, "leaf_retests_per_ray": n_re,
+                                           "kernel_seconds": kernel_seconds})
+        result["roofline"]["note"] = ("nodes and triangles (11 MB) are served by LDS (the top 64 nodes: half of all visits), L2 and Infinity Cache, so the "
+                                      "algorithmic byte model over-states what reaches HBM; the walk is a dependent chain per ray (load a node, test four "
+                                      "boxes, pick the next) and sits below all three ceilings -- DESIGN.md section 4 has the measurements that rule each one out")
     if args.save_image and rank == 0:
         np.save(args.save_image, acc.cpu().numpy())
     if world == 1 and not args.no_cpu_baseline:

@@ -464,6 +464,13 @@ def probe_valu_peak():
     return v.value
 
 
+def probe_gather_peak():
+    """Measurement hook: per-lane 16-byte gather rate of the device in 1e9 lane-loads / s (8 dwordx4 of a random 128-byte record per lane)."""
+    v = C.c_double(0.0)
+    _check(lib().gnxr_probe_gather_peak(C.byref(v)))
+    return v.value
+
+
 def framebuffer_update(running_mean, frame, frame_count):
     """FrameBuffer::update_f_u_c (ui/FrameBuffer.h:127-149): running mean + 1-exp(-4x) tone map to RGBA8."""
     h, w = frame.shape[:2]

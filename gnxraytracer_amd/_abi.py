@@ -93,7 +93,7 @@ class Stats(C.Structure):
         ("kernel_launches", u32), ("passes", u32),
         ("seconds_closest", C.c_double), ("seconds_nee", C.c_double), ("seconds_shade", C.c_double),
         ("launches_closest", u32), ("launches_nee", u32), ("rays_closest_nee", u64),
-        ("media_segments", u64), ("media_steps", u64), ("leaf_retests", u64),
+        ("media_segments", u64), ("media_steps", u64), ("leaf_retests", u64), ("nodes_from_memory", u64),
     ]
 
 
@@ -118,6 +118,7 @@ PROTOTYPES = {
     "gnxr_init_devices": (C.c_int, [i32, P(i32)]),
     "gnxr_set_profiling": (C.c_int, [C.c_int]),
     "gnxr_probe_valu_peak": (C.c_int, [P(C.c_double)]),
+    "gnxr_probe_gather_peak": (C.c_int, [P(C.c_double)]),
     "gnxr_scene_create": (C.c_int, [P(SceneDesc), P(VP)]),
     "gnxr_scene_destroy": (None, [VP]),
     "gnxr_scene_info": (C.c_int, [VP, P(i32), P(i32), P(i32)]),

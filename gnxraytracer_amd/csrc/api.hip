@@ -316,9 +316,52 @@ __global__ void __launch_bounds__(256) k_valu_peak(float *out, int iters, float 
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = ((x0 + x1) + (x2 + x3)) + ((x4 + x5) + (x6 + x7));
 }
+// Gather-rate probe: every lane reads the 8 dwordx4 of its own pseudo-random 128-byte record (a BVH node visit without the arithmetic),
+// the next record depends on what was read (a traversal's dependent chain).
+__global__ void __launch_bounds__(256) k_gather_peak(const float4 *__restrict__ tab, unsigned nrec, int iters, float *out) {
+    unsigned idx = (blockIdx.x * 256u + threadIdx.x) * 2654435761u;
+    float acc = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        idx = idx * 1664525u + 1013904223u;
+        const float4 *p = tab + (size_t)((idx >> 8) % nrec) * 8;
+        const float4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4], f = p[5], g = p[6], h = p[7];
+        acc += a.x + b.y + c.z + d.w + e.x + f.y + g.z + h.w;
+        idx ^= __float_as_uint(acc) & 1u;
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
 }  // namespace
 
 extern "C" {
+
+int gnxr_probe_gather_peak(double *giga_lane_loads_per_s) {
+    if (!giga_lane_loads_per_s) { set_error("null argument"); return GNXR_ERR_INVALID; }
+    int rc = ensure_device();
+    if (rc) return rc;
+    const unsigned nrec = 8u * 1024 * 1024 / 128;
+    const int blocks = g_num_cus * 5, iters = 1000;
+    DevBuf<float4> tab;
+    DevBuf<float> out;
+    if ((rc = tab.alloc((size_t)nrec * 8)) != GNXR_OK || (rc = out.alloc((size_t)blocks * 256)) != GNXR_OK) return rc;
+    HIP_TRY(hipMemset(tab.p, 0, (size_t)nrec * 128));
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    double best = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(a, 0);
+        hipLaunchKernelGGL(k_gather_peak, dim3(blocks), dim3(256), 0, 0, (const float4 *)tab.p, nrec, iters, out.p);
+        (void)hipEventRecord(b, 0);
+        if (hipEventSynchronize(b) != hipSuccess) break;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, a, b) == hipSuccess && ms > 0) best = std::max(best, (double)blocks * 256 * (double)iters * 8 / (ms * 1e-3) / 1e9);
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    HIP_TRY(hipGetLastError());
+    *giga_lane_loads_per_s = best;
+    return GNXR_OK;
+}
 
 int gnxr_probe_valu_peak(double *giga_wave_insts_per_s) {
     if (!giga_wave_insts_per_s) { set_error("null argument"); return GNXR_ERR_INVALID; }
@@ -888,6 +931,7 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
         stats->media_segments = media_segments;
         stats->media_steps = s->h_counters->media_steps;
         stats->leaf_retests = s->h_counters->retests;
+        stats->nodes_from_memory = s->h_counters->nodes_global;
     }
     return GNXR_OK;
 }
@@ -951,6 +995,7 @@ static int render_sharded(gnxr_scene *s, const gnxr_render_params *pin, void *d_
             stats->rays_closest += t.rays_closest; stats->rays_any += t.rays_any; stats->camera_samples += t.camera_samples;
             stats->nodes_visited += t.nodes_visited; stats->tris_tested += t.tris_tested; stats->kernel_launches += t.kernel_launches;
             stats->rays_closest_nee += t.rays_closest_nee; stats->media_segments += t.media_segments; stats->media_steps += t.media_steps; stats->leaf_retests += t.leaf_retests;
+            stats->nodes_from_memory += t.nodes_from_memory;
             stats->seconds_render = std::max(stats->seconds_render, t.seconds_render); stats->seconds_total = std::max(stats->seconds_total, t.seconds_total);
             stats->passes = std::max(stats->passes, t.passes);
         }

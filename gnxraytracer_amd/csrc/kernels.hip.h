@@ -51,6 +51,7 @@ struct Counters {
     unsigned long long whitted_mis;                 // MIS closest-hit rays queued by k_whitted_step (DirectLighting); follows whitted_shadow
     unsigned long long media_steps;                 // tracking-loop iterations of k_vol_media<COUNT>
     unsigned long long retests;                     // k_trace<COUNT, WIDE>: leaf boxes re-tested against a shrunken tMax (32 B each)
+    unsigned long long nodes_global;                // k_trace4<COUNT>: node visits served from global memory (the others come from the LDS copy of the top of the tree)
 };
 
 struct DScene {

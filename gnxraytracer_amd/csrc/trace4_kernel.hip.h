@@ -112,7 +112,7 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
     unsigned oNX = 0, oNY = 16, oNZ = 32;   // byte offset of the near plane of each axis inside a DNode4 (far = 48 | 80 | 112 - near ... see below)
     unsigned ordShift = 0;                  // bit offset of this octant's byte in the node's 64-bit order table
     int cur = -1, toVisit = 0, leafOff = 0, leafN = 0, hitLeaf = -1;
-    uint32_t cntNodes = 0, cntTris = 0, cntRetests = 0;
+    uint32_t cntNodes = 0, cntTris = 0, cntRetests = 0, cntNodesGlobal = 0;
 #ifdef GX_TRACE_STATS
     unsigned long long st_[24] = {0};
 #endif
@@ -272,6 +272,7 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
                     const f4v t7 = L[7 * kTopCache];
                     tb = make_uint2(__float_as_uint(t7.x), __float_as_uint(t7.y));
                 } else {
+                    if (COUNT) cntNodesGlobal++;
                     const unsigned off = (unsigned)cur << 7;
 #define GX_LD4(o) (*reinterpret_cast<const f4v *>(nb + (unsigned)(off + (o))))
                     nX = GX_LD4(oNX); fX = GX_LD4(48u - oNX); nY = GX_LD4(oNY); fY = GX_LD4(80u - oNY); nZ = GX_LD4(oNZ); fZ = GX_LD4(112u - oNZ);
@@ -419,6 +420,7 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
         atomicAdd(&ctr->nodes, (unsigned long long)cntNodes);
         atomicAdd(&ctr->tris, (unsigned long long)cntTris);
         atomicAdd(&ctr->retests, (unsigned long long)cntRetests);
+        atomicAdd(&ctr->nodes_global, (unsigned long long)cntNodesGlobal);
     }
 }
 

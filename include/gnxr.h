@@ -286,6 +286,7 @@ typedef struct gnxr_stats {
     uint64_t media_segments;    /* VolPath: ray segments handed to the tracking kernel (Medium::Sample / Medium::Tr calls on rays inside a medium) */
     uint64_t media_steps;       /* VolPath: tracking-loop iterations of those segments (filled by the counting run, profiling bit 2) */
     uint64_t leaf_retests;      /* counting run, bit 2: leaf boxes re-tested against a shrunken tMax by the 4-wide walk (32 B each)  */
+    uint64_t nodes_from_memory; /* counting run, bit 2: 4-wide node visits that read global memory (the rest hit the kernel's LDS copy of the top of the tree) */
 } gnxr_stats;
 
 typedef struct gnxr_ray { float o[3]; float tmax; float d[3]; float _pad; } gnxr_ray;
@@ -323,6 +324,11 @@ int gnxr_set_profiling(int flags);
  * independent v_fma_f32 chains with 8 waves on every SIMD -- the ceiling bench.py prices the traversal kernel's
  * instruction stream against.                                                                                */
 int gnxr_probe_valu_peak(double *giga_wave_insts_per_s);
+/* Measurement hook: the rate at which this device takes per-lane 16-byte gathers (every lane reads the 8 dwordx4 of its own random
+ * 128-byte record of an 8 MB table: the access pattern of a BVH node visit), in 1e9 lane-loads per second.  On MI355X this rate
+ * (~690 G/s = 1.1 lanes per clock per CU) is the same for L1-resident and L2-resident tables and at 1 to 8 blocks per CU
+ * (tools/probes/gather_probe.hip): it is a ceiling of the vector-memory path, beside HBM bandwidth and VALU issue.              */
+int gnxr_probe_gather_peak(double *giga_lane_loads_per_s);
 
 /* -- scene (replaces `Scene(make_shared<BVHAccel>(prims,1), lights)`, RenderThread.cpp:155) */
 int gnxr_scene_create(const gnxr_scene_desc *desc, gnxr_scene **out);
