@@ -218,6 +218,13 @@ class SceneBuilder:
             d = density.ctypes.data_as(C.POINTER(C.c_float))
         return _check(lib().gnxr_builder_add_medium(self._h, C.byref(medium), d))
 
+    def add_volume_file(self, path, g=0.0, sigma_scale=1.0, medium_to_world=None):
+        """GridDensityMedium from a `.volume` file (Resources/density_render.70.volume's format); returns the medium index."""
+        m = None
+        if medium_to_world is not None:
+            m = np.ascontiguousarray(medium_to_world, dtype=np.float32).reshape(16).ctypes.data_as(C.POINTER(C.c_float))
+        return _check(lib().gnxr_builder_add_volume_file(self._h, os.fsencode(path), float(g), float(sigma_scale), m))
+
     def add_image_texture(self, image, su=1.0, sv=1.0, du=0.0, dv=0.0, trilinear=False, max_aniso=8.0, wrap="repeat", scale=1.0, gamma=False):
         """ImageTexture<RGBSpectrum, Spectrum>(UVMapping2D(su, sv, du, dv), file, doTrilinear, maxAniso, wrap, scale, gamma)
         (textures/ImageTexture.h; the defaults are those of getSmileFacePlasticMaterial, ui/MaterialList.cpp:31-46).  `image` is

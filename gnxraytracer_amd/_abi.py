@@ -152,6 +152,7 @@ PROTOTYPES = {
     "gnxr_builder_add_inf_light": (C.c_int, [VP, C.c_char_p]),
     "gnxr_builder_add_inf_light_data": (C.c_int, [VP, P(f32), i32, i32, P(f32), P(f32)]),
     "gnxr_builder_add_medium": (C.c_int, [VP, P(Medium), P(f32)]),
+    "gnxr_builder_add_volume_file": (C.c_int, [VP, C.c_char_p, f32, f32, P(f32)]),
     "gnxr_builder_add_emissive_mesh": (C.c_int, [VP, P(f32), i32, P(i32), i32, P(f32), i32, P(f32), i32]),
     "gnxr_builder_add_spot_light": (C.c_int, [VP]),
     "gnxr_builder_add_dist_light": (C.c_int, [VP]),

@@ -621,6 +621,44 @@ int gnxr_builder_add_medium(gnxr_builder *b, const gnxr_medium *m, const float *
     return (int)b->b.media.size() - 1;
 }
 
+// GridDensityMedium from a `.volume` text file -- the format of the reference's Resources/density_render.70.volume (which nothing in
+// the reference loads: GridDensityMedium is never instantiated, ui/RenderThread.cpp:21 only includes its header): tokens
+// `nx N ny N nz N`, `p0 x y z`, `p1 x y z`, `sigma_a r g b`, `sigma_s r g b`, then nx * ny * nz densities, x fastest
+// (density[(z * ny + y) * nx + x], media/GridDensityMedium.h:34-38), any whitespace / CRLF.
+int gnxr_builder_add_volume_file(gnxr_builder *b, const char *path, float g, float sigma_scale, const float *medium_to_world16) {
+    if (!b || !path) return GNXR_ERR_INVALID;
+    FILE *fp = fopen(path, "rb");
+    if (!fp) { set_error("cannot open %s", path); return GNXR_ERR_IO; }
+    auto fail = [&](const char *what) { fclose(fp); set_error("%s: %s", path, what); return (int)GNXR_ERR_IO; };
+    char key[32];
+    int n[3] = {0, 0, 0};
+    float p0[3], p1[3], sa[3], ss[3];
+    const char *dims[3] = {"nx", "ny", "nz"};
+    for (int i = 0; i < 3; ++i)
+        if (fscanf(fp, "%31s %d", key, &n[i]) != 2 || strcmp(key, dims[i]) != 0 || n[i] <= 0) return fail("bad .volume header (nx / ny / nz)");
+    struct { const char *name; float *v; } rows[4] = {{"p0", p0}, {"p1", p1}, {"sigma_a", sa}, {"sigma_s", ss}};
+    for (auto &r : rows)
+        if (fscanf(fp, "%31s %f %f %f", key, &r.v[0], &r.v[1], &r.v[2]) != 4 || strcmp(key, r.name) != 0) return fail("bad .volume header (p0 / p1 / sigma_a / sigma_s)");
+    const size_t count = (size_t)n[0] * n[1] * n[2];
+    if (count >= (1ull << 31)) return fail("density grid too large");
+    std::vector<float> dens(count);
+    for (size_t i = 0; i < count; ++i)
+        if (fscanf(fp, "%f", &dens[i]) != 1) return fail("truncated density data");
+    fclose(fp);
+    gnxr_medium m;
+    memset(&m, 0, sizeof(m));
+    m.type = GNXR_MEDIUM_GRID;
+    m.nx = n[0]; m.ny = n[1]; m.nz = n[2];
+    for (int c = 0; c < 3; ++c) { m.sigma_a[c] = sa[c] * sigma_scale; m.sigma_s[c] = ss[c] * sigma_scale; }
+    m.g = g;
+    if (medium_to_world16) memcpy(m.medium_to_world, medium_to_world16, 64);
+    else {   // the file's own placement: Translate(p0) * Scale(p1 - p0) maps the unit cube of the grid onto [p0, p1]
+        const float mm[16] = {p1[0] - p0[0], 0, 0, p0[0], 0, p1[1] - p0[1], 0, p0[1], 0, 0, p1[2] - p0[2], p0[2], 0, 0, 0, 1};
+        memcpy(m.medium_to_world, mm, 64);
+    }
+    return gnxr_builder_add_medium(b, &m, dens.data());
+}
+
 // ImageTexture(UVMapping2D, filename, doTrilinear, maxAniso, wrapMode, scale, gamma), textures/ImageTexture.cpp:40-48
 int gnxr_builder_add_texture_data(gnxr_builder *b, const gnxr_texture *t, const float *rgb, int32_t w, int32_t h) {
     if (!b || !t || !rgb || w <= 0 || h <= 0) return GNXR_ERR_INVALID;

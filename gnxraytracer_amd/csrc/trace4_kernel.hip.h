@@ -295,6 +295,21 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
         const float x = fminf(fminf(tfx.C, tfy.C), tfz.C);                                \
         hitMask |= (e <= x && e < tMax && x > 0.f) ? (BIT) : 0u;                          \
     }
+#elif GX_T4_PACKED == 2
+                    // two children at a time (packed fp32 on .xy, then on .zw): half the live temporaries of the four-at-once form
+                    typedef float f2v __attribute__((ext_vector_type(2)));
+#define GX_SLAB2(H, C0, C1, B0, B1)                                                                            \
+    {                                                                                                          \
+        const f2v tnx = (nX.H - ro.x) * inv.x, tny = (nY.H - ro.y) * inv.y, tnz = (nZ.H - ro.z) * inv.z;        \
+        const f2v tfx = ((fX.H - ro.x) * inv.x) * k, tfy = ((fY.H - ro.y) * inv.y) * k, tfz = ((fZ.H - ro.z) * inv.z) * k; \
+        const float e0 = fmaxf(fmaxf(tnx.x, tny.x), tnz.x), x0 = fminf(fminf(tfx.x, tfy.x), tfz.x);             \
+        const float e1 = fmaxf(fmaxf(tnx.y, tny.y), tnz.y), x1 = fminf(fminf(tfx.y, tfy.y), tfz.y);             \
+        hitMask |= (e0 <= x0 && e0 < tMax && x0 > 0.f) ? (B0) : 0u;                                             \
+        hitMask |= (e1 <= x1 && e1 < tMax && x1 > 0.f) ? (B1) : 0u;                                             \
+    }
+                    GX_SLAB2(xy, x, y, 1u, 2u) GX_SLAB2(zw, z, w, 4u, 8u)
+#undef GX_SLAB2
+#define GX_SLAB3(C, BIT)
 #else
 #define GX_SLAB3(C, BIT)                                                                                       \
     {                                                                                                          \

@@ -424,6 +424,11 @@ int gnxr_builder_add_inf_light(gnxr_builder *b, const char *hdr_path);          
 int gnxr_builder_add_inf_light_data(gnxr_builder *b, const float *rgb, int32_t w, int32_t h,
                                     const float *light_to_world16, const float power[3]);
 int gnxr_builder_add_medium(gnxr_builder *b, const gnxr_medium *m, const float *density);
+/* GridDensityMedium from a `.volume` text file (the format of the reference's Resources/density_render.70.volume: `nx N ny N nz N`,
+ * `p0 x y z`, `p1 x y z`, `sigma_a r g b`, `sigma_s r g b`, then nx*ny*nz densities): sigma_a / sigma_s of the header times
+ * sigma_scale, Henyey-Greenstein g, MediumToWorld = medium_to_world16 or, when NULL, Translate(p0) * Scale(p1 - p0) of the header.
+ * Returns the medium index.                                                                                                      */
+int gnxr_builder_add_volume_file(gnxr_builder *b, const char *path, float g, float sigma_scale, const float *medium_to_world16);
 /* ImageTexture: `t` carries the mapping / filter parameters (width, height, texel_offset are filled in); returns the texture
  * index.  _file decodes a Radiance .hdr like stbi_loadf; other formats (the reference's awesomeface.jpg) must be decoded by the
  * caller and passed as texels. */

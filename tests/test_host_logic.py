@@ -218,3 +218,34 @@ def test_radiance_writer_round_trips_through_the_builder(gx, tmp_path):
     assert (px[True].view(np.uint32) == px[False].view(np.uint32)).all()
     m = img.max(axis=2, keepdims=True)
     assert (np.abs(px[True] - img) <= m / 128 + 1e-30).all() and (px[True][-1] == 0).all()
+
+
+def test_volume_file_reader(gx, tmp_path):
+    """gnxr_builder_add_volume_file: the `.volume` text format of Resources/density_render.70.volume (CRLF line ends, header rows
+    nx/ny/nz, p0, p1, sigma_a, sigma_s, then the densities x-fastest) -> a GRID medium placed by the header's own box."""
+    d = scenes.synthetic_density(7, 5, 3)   # [nz, ny, nx]
+    nz, ny, nx = d.shape
+    p = tmp_path / "smoke.volume"
+    with open(p, "w", newline="") as f:
+        f.write(f"nx {nx} ny {ny} nz {nz}\r\np0 0.010000 0.020000 0.030000 \r\np1 1.990000 1.500000 0.790000 \r\nsigma_a 10 10 10\r\nsigma_s 90 80 70\r\n")
+        f.write(" ".join(repr(float(v)) for v in d.reshape(-1)) + " \r\n")
+    b = gx.SceneBuilder()
+    w = b.MatteMaterial((0.5, 0.5, 0.5))
+    b.AddCornell(w, w, w)
+    m = b.add_volume_file(str(p), g=0.3, sigma_scale=0.5)
+    desc = b.desc()
+    md = desc.media[m]
+    assert (md.type, md.nx, md.ny, md.nz) == (gx._abi.MEDIUM_GRID, nx, ny, nz) and md.g == np.float32(0.3)
+    assert list(md.sigma_a) == [5.0, 5.0, 5.0] and list(md.sigma_s) == [45.0, 40.0, 35.0]
+    m2w = np.array(list(md.medium_to_world), np.float32).reshape(4, 4)
+    p0, p1 = np.float32([0.01, 0.02, 0.03]), np.float32([1.99, 1.5, 0.79])
+    assert (np.diag(m2w)[:3] == p1 - p0).all() and (m2w[:3, 3] == p0).all() and m2w[3, 3] == 1
+    got = np.ctypeslib.as_array(desc.grid_density, shape=(nx * ny * nz,))
+    assert (got.view(np.uint32) == d.reshape(-1).view(np.uint32)).all()
+    m3 = b.add_volume_file(str(p), medium_to_world=np.eye(4))     # explicit placement, second grid appended behind the first
+    assert b.desc().media[m3].density_offset == nx * ny * nz and b.desc().media[m3].medium_to_world[0] == 1.0
+    for bad in ("nx 2 ny 2\n", "nx 2 ny 2 nz 2\np0 0 0 0\np1 1 1 1\nsigma_a 1 1 1\nsigma_s 1 1 1\n1 2 3\n"):
+        q = tmp_path / "bad.volume"
+        q.write_text(bad)
+        with pytest.raises(gx.GnxrError):
+            b.add_volume_file(str(q))

@@ -71,3 +71,18 @@ def test_oracle_equals_reference_classes_under_the_reference_hdr(gx, strategy):
     assert (int(cnt[0]), int(cnt[1])) == (ost["rays_closest"], ost["rays_any"])
     assert (oimg[..., :3].view(np.uint32) == rimg[..., :3].view(np.uint32)).all()
     assert oimg[..., :3].max() > 0.5   # the environment actually lights the scene
+
+
+@needs_ref
+def test_volume_reader_on_the_reference_density_file(gx):
+    """Resources/density_render.70.volume (100 x 100 x 40, CRLF) through gnxr_builder_add_volume_file: header and all 400 000
+    densities equal the committed data fixture tests/golden/density_70.npz (which cfg 5's goldens were rendered from)."""
+    g = np.load(os.path.join(GOLDEN, "density_70.npz"))
+    b = gx.SceneBuilder()
+    m = b.add_volume_file(os.path.join(RES, "density_render.70.volume"))
+    d = b.desc()
+    md = d.media[m]
+    assert (md.nx, md.ny, md.nz) == (int(g["nx"]), int(g["ny"]), int(g["nz"])) == (100, 100, 40)
+    assert list(md.sigma_a) == [10.0] * 3 and list(md.sigma_s) == [90.0] * 3
+    got = np.ctypeslib.as_array(d.grid_density, shape=(100 * 100 * 40,))
+    assert (got.view(np.uint32) == g["density"].reshape(-1).astype(np.float32).view(np.uint32)).all()
