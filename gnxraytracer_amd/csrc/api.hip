@@ -622,7 +622,7 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
         if ((rc = s->trace_spill.alloc((size_t)g_num_cus * g_trace_blocks_per_cu * kBlock * (size_t)entries)) != GNXR_OK) return rc;
     }
     if ((rc = s->accum.alloc(r.npix)) != GNXR_OK) return rc;
-    const int max_tiles = (int)((cap + kCompactBlock - 1) / kCompactBlock);
+    const int max_tiles = (int)((cap + kCompactTile - 1) / kCompactTile);
     if ((rc = s->tile_counts.alloc((size_t)4 * max_tiles)) != GNXR_OK) return rc;
     PathArrays pa;
     pa.ray_o = s->ray_o.p; pa.ray_d = s->ray_d.p; pa.beta = s->beta.p; pa.L = s->L.p; pa.meta = s->meta.p; pa.hit = s->hit.p; pa.pflags = s->pflags.p; pa.pclass = s->pclass.p;
@@ -741,7 +741,7 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
         };
         // stream compaction (compact_kernel.hip.h): count -> scan -> scatter, no global atomics
         auto compact = [&](int mode, const int *qin, int nin, const unsigned char *keys, int nout, int nscatter, unsigned int *totals, int *o0, int *o1, int *o2, int *o3 = nullptr) {
-            int tiles = (nin + kCompactBlock - 1) / kCompactBlock;
+            int tiles = (nin + kCompactTile - 1) / kCompactTile;
             int g = std::min(tiles, g_num_cus * 8);
             if (mode == COMPACT_FLAGS) hipLaunchKernelGGL((k_compact_count<COMPACT_FLAGS, 4>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles);
             else if (nout == 4) hipLaunchKernelGGL((k_compact_count<COMPACT_CLASS, 4>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles);
@@ -850,15 +850,21 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
             {
                 int *qc[4] = {s->queue_c0.p, s->queue_c1.p, s->queue_c2.p, s->queue_c3.p};
                 dim3 g(grid_for(n)), b(kBlock);
+                // the Halton tables of the first dimensions go to LDS (device_sampler.h LdsSampler): 64 dimensions (the camera sample + 6 path vertices:
+                // 18.8 KB per block; deeper vertices read global memory).  A/B on cfg 3: shade -3 % at 64 / 88 dimensions, +4 % at 112 (occupancy)
+                static const int shade_lds_dims = getenv("GNXR_SHADE_LDS_DIMS") ? std::max(0, std::min(128, atoi(getenv("GNXR_SHADE_LDS_DIMS")))) : 64;   // tuning knob
+                const int sdims = std::min<int>(shade_lds_dims, (int)s->cs.prime_sums.size() - 1);
+                const int snperm = sdims > 0 ? s->cs.prime_sums[sdims] : 0;
+                const size_t slds = sdims > 0 ? ((((size_t)snperm * 2 + 15) & ~(size_t)15) + (size_t)sdims * 16) : 0;
 #define GX_SHADE(LMV, LTV, C)                                                                                                                        \
     do {                                                                                                                                             \
-        if (spheres) hipLaunchKernelGGL((k_shade<LMV, LTV, true>), g, b, 0, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C]); \
-        else hipLaunchKernelGGL((k_shade<LMV, LTV, false>), g, b, 0, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C]);       \
+        if (spheres) hipLaunchKernelGGL((k_shade<LMV, LTV, true>), g, b, slds, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C], sdims, snperm); \
+        else hipLaunchKernelGGL((k_shade<LMV, LTV, false>), g, b, slds, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C], sdims, snperm);       \
     } while (0)
 #define GX_SHADE_TEX(LTV)                                                                                                                            \
     do {                                                                                                                                             \
-        if (spheres) hipLaunchKernelGGL((k_shade<LM_ALL, LTV, true, true>), g, b, 0, stream, sc, r, pa, (const int *)qc[3], (const unsigned int *)&dctr->q_class[3]); \
-        else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, 0, stream, sc, r, pa, (const int *)qc[3], (const unsigned int *)&dctr->q_class[3]);       \
+        if (spheres) hipLaunchKernelGGL((k_shade<LM_ALL, LTV, true, true>), g, b, slds, stream, sc, r, pa, (const int *)qc[3], (const unsigned int *)&dctr->q_class[3], sdims, snperm); \
+        else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, slds, stream, sc, r, pa, (const int *)qc[3], (const unsigned int *)&dctr->q_class[3], sdims, snperm);       \
     } while (0)
                 if (area_only) {
                     GX_SHADE(LM_DIFFUSE, LT_AREA, 0);
@@ -867,7 +873,7 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
                     if (class_mask & 8) GX_SHADE_TEX(LT_AREA);
                 } else if (area_env_only && !spheres && !(class_mask & 8)) {
                     // BASELINE config 4's light set (area lights + one InfiniteAreaLight): without the delta-light and sky-box code
-#define GX_SHADE_AE(LMV, C) hipLaunchKernelGGL((k_shade<LMV, LT_AREA | LT_ENV, false>), g, b, 0, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C])
+#define GX_SHADE_AE(LMV, C) hipLaunchKernelGGL((k_shade<LMV, LT_AREA | LT_ENV, false>), g, b, slds, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C], sdims, snperm)
                     GX_SHADE_AE(LM_DIFFUSE, 0);
                     if (class_mask & 2) GX_SHADE_AE(LM_GLOSSY, 1);
                     if (class_mask & 4) GX_SHADE_AE(LM_ALL, 2);

@@ -331,8 +331,12 @@ static __device__ unsigned long long g_shade_stats[16];
 #define GX_STICK(i) do {} while (0)
 #endif
 template <uint32_t LM, int LT, bool SPH, bool TEX = false>
-__global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRender r, PathArrays pa, const int *__restrict__ queue, const unsigned int *n_dev) {
+__global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRender r, PathArrays pa, const int *__restrict__ queue, const unsigned int *n_dev, int lds_dims, int lds_nperm) {
+    extern __shared__ int shade_smem[];   // the Halton tables of dimensions [0, lds_dims): device_sampler.h LdsSampler
     const int n = (int)*n_dev;
+    if (blockIdx.x * blockDim.x >= (unsigned)n) return;   // this block has no item: skip the table fill
+    const LdsSampler lsam = lds_sampler_fill(sc.st, lds_dims, lds_nperm, shade_smem, threadIdx.x, kBlock);
+    __syncthreads();
 #ifdef GX_SHADE_STATS
     unsigned long long sst_[16] = {0};
     unsigned long long stick_ = __builtin_amdgcn_s_memtime();
@@ -409,7 +413,7 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
                     }
                     Bsdf<LM> bsdf;
                     bsdf.mat = mat; bsdf.ns = sp.ns; bsdf.ng = sp.n; bsdf.ss = sp.ss; bsdf.ts = sp.ts;
-                    SampleStream ss(sc.st, index, dim);
+                    SampleStream ss(sc.st, index, dim, lsam);
                     V3 woN = normalize(-rd);  // Interaction::wo
                     // ---- UniformSampleOneLight, Integrator.cpp:57-79
                     if (mat->n_nonspecular > 0 && sc.lt.n_lights > 0) {
