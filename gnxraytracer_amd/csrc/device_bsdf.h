@@ -126,8 +126,7 @@ GX_DEV void tr_sample11(float cosTheta, float U1, float U2, float *slope_x, floa
         // unqualified sqrt/cos/sin bind to the double versions in the reference (MicroFacet.cpp:220-223)
         float r = (float)sqrt((double)(U1 / (1 - U1)));
         float phi = (float)(6.28318530718 * (double)U2);
-        double sphi, cphi;
-        sincos((double)phi, &sphi, &cphi);
+        const double sphi = gx_sin_d((double)phi), cphi = gx_cos_d((double)phi);   // glibc's __sin / __cos, restated (device_math.h)
         *slope_x = (float)((double)r * cphi);
         *slope_y = (float)((double)r * sphi);
         return;

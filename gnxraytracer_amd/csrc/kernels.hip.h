@@ -749,7 +749,7 @@ static __global__ void k_libm_probe(int fn, const float *x, const float *x2, lon
 static __global__ void k_libm_probe_f64(int fn, const float *x, long long n, double *out) {
     for (long long i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const double v = (double)x[i];
-        if (fn <= 1) { double sv, cv; sincos(v, &sv, &cv); out[i] = fn == 0 ? sv : cv; }
+        if (fn <= 1) out[i] = fn == 0 ? gx_sin_d(v) : gx_cos_d(v);
         else out[i] = fn == 2 ? sqrt(v) : tan(v);
     }
 }

@@ -267,6 +267,18 @@ int gnxo_light_le(gnxo_scene *s, int light, const gnxr_ray *rays, int64_t n, flo
     return 0;
 }
 
+// The host's double-precision libm on float arguments widened to double (what `cos(phi)` / `sin(phi)` / `sqrt(..)` at
+// core/MicroFacet.cpp:220-223 evaluate): the checker for the device's restatement of glibc's __sin / __cos.  fn: 0 sin, 1 cos, 2 sqrt, 3 tan.
+int gnxo_libm_f64(int32_t fn, const float *x, int64_t n, double *out) {
+    if (!x || !out || n < 0 || fn < 0 || fn > 3) return -1;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        const double v = (double)x[i];
+        out[i] = fn == 0 ? sin(v) : fn == 1 ? cos(v) : fn == 2 ? sqrt(v) : tan(v);
+    }
+    return 0;
+}
+
 // FrameBuffer::update_f_u_c (ui/FrameBuffer.h:127-149) for every pixel and channel 0..2, as SamplerIntegrator::Render calls it
 // (core/Integrator.cpp:307-310), plus set_uc(i, j, 3, 255): running mean over `frame_count` (= curRenderCount) Render() calls, tone map
 // 1 - expf(-x / (1 - 0.75)), implicit float -> unsigned char conversion.  `mean` is the fbuffer plane (RGBA, updated in place).

@@ -46,6 +46,7 @@ def olib():
         L.gnxo_light_probe.argtypes = [VP, C.c_int, C.c_int, P(f32), P(f32), P(f32), P(f32), i64, P(f32)]
         L.gnxo_light_le.argtypes = [VP, C.c_int, P(_abi.Ray), i64, P(f32)]
         L.gnxo_framebuffer_update.argtypes = [P(f32), P(f32), i32, i32, i32, P(u8)]
+        L.gnxo_libm_f64.argtypes = [i32, P(f32), i64, P(C.c_double)]
         _olib = L
     return _olib
 
@@ -138,6 +139,15 @@ def oracle_framebuffer_update(running_mean, frame, frame_count):
     rc = olib().gnxo_framebuffer_update(_fp(running_mean), _fp(frame), w, h, int(frame_count), rgba8.ctypes.data_as(C.POINTER(C.c_uint8)))
     assert rc == 0
     return rgba8
+
+
+def host_libm_f64(fn, x):
+    """sin / cos / sqrt / tan of the host's libm (double) on float32 arguments widened to double, all cores."""
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.zeros(x.shape, np.float64)
+    rc = olib().gnxo_libm_f64({"sin": 0, "cos": 1, "sqrt": 2, "tan": 3}[fn], _fp(x), x.size, out.ctypes.data_as(C.POINTER(C.c_double)))
+    assert rc == 0
+    return out
 
 
 def oracle_halton(width, height, px, py, s, dim):
