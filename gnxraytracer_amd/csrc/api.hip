@@ -147,7 +147,7 @@ struct gnxr_scene {
     DevBuf<uint16_t> perms;
     DevBuf<int32_t> primes, prime_sums;
     DevBuf<uint32_t> prime_magic;
-    DevBuf<float> env_texels, env_cond_func, env_cond_cdf, env_cond_int, env_marg_func, env_marg_cdf;
+    DevBuf<float> env_texels4, env_cond_func, env_cond_cdf, env_cond_int, env_marg_func, env_marg_cdf;
     DevBuf<uint16_t> env_marg_guide, env_cond_guide;
     DevBuf<float> grid_table;
     DevBuf<DMedium> dmedia;
@@ -202,7 +202,7 @@ struct gnxr_scene {
         d.lt.grid_table = grid_table.p;
         d.lt.has_env = cs.has_env ? 1 : 0;
         d.lt.env = cs.env;
-        d.lt.env_texels = env_texels.p;
+        d.lt.env_texels = reinterpret_cast<const float4 *>(env_texels4.p);
         d.lt.env_cond_func = env_cond_func.p; d.lt.env_cond_cdf = env_cond_cdf.p; d.lt.env_cond_int = env_cond_int.p;
         d.lt.env_marg_func = env_marg_func.p; d.lt.env_marg_cdf = env_marg_cdf.p;
         d.lt.env_marg_guide = env_marg_guide.p; d.lt.env_cond_guide = env_cond_guide.p;
@@ -454,7 +454,7 @@ static int upload_scene(gnxr_scene *s) {
 #define UP(field) if ((rc = s->field.upload(cs.field)) != GNXR_OK) return rc;
     UP(nodes) UP(nodes4) UP(tris) UP(leaf_boxes) UP(tri_class) UP(lights) UP(perms) UP(primes) UP(prime_sums) UP(prime_magic)
     UP(dmedia) UP(grid_density) UP(tri_media) UP(spheres) UP(textures) UP(tex_texels) UP(ewa_lut) UP(tri_uv) UP(tri_n) UP(tri_s)
-    UP(env_texels) UP(env_cond_func) UP(env_cond_cdf) UP(env_cond_int) UP(env_marg_func) UP(env_marg_cdf) UP(env_marg_guide) UP(env_cond_guide)
+    UP(env_texels4) UP(env_cond_func) UP(env_cond_cdf) UP(env_cond_int) UP(env_marg_func) UP(env_marg_cdf) UP(env_marg_guide) UP(env_cond_guide)
 #undef UP
     {   // materials, preceded by one record that carries the texture tables (tex_tables(), device_texture.h)
         DTexTables tt;

@@ -23,7 +23,7 @@ struct DLightTables {
     // env
     int has_env;
     DEnv env;
-    const float *env_texels;
+    const float4 *env_texels;   // level-0 texels of the environment map, rgb_ (one dwordx4 each)
     const float *env_cond_func, *env_cond_cdf, *env_cond_int, *env_marg_func, *env_marg_cdf;
     const uint16_t *env_marg_guide, *env_cond_guide;   // FindInterval guide tables (scene_compile.cpp build_env)
 };
@@ -79,10 +79,10 @@ GX_DEV Spec env_lookup(const DLightTables &t, float s_, float t_) {  // MIPMap::
     float s = s_ * rx - 0.5f, tt = t_ * ry - 0.5f;
     int s0 = (int)floorf(s), t0 = (int)floorf(tt);
     float ds = s - s0, dt = tt - t0;
-    const float *tex = t.env_texels;
+    const float4 *tex = t.env_texels;
     int sa = modi(s0, rx), sb = modi(s0 + 1, rx), ta = modi(t0, ry), tb = modi(t0 + 1, ry);
-    Spec c00 = spec3(tex + ((size_t)ta * rx + sa) * 3), c01 = spec3(tex + ((size_t)tb * rx + sa) * 3);
-    Spec c10 = spec3(tex + ((size_t)ta * rx + sb) * 3), c11 = spec3(tex + ((size_t)tb * rx + sb) * 3);
+    const float4 q00 = tex[(size_t)ta * rx + sa], q01 = tex[(size_t)tb * rx + sa], q10 = tex[(size_t)ta * rx + sb], q11 = tex[(size_t)tb * rx + sb];
+    Spec c00(q00.x, q00.y, q00.z), c01(q01.x, q01.y, q01.z), c10(q10.x, q10.y, q10.z), c11(q11.x, q11.y, q11.z);
     return (1 - ds) * (1 - dt) * c00 + (1 - ds) * dt * c01 + ds * (1 - dt) * c10 + ds * dt * c11;
 }
 GX_DEV float spherical_theta(V3 v) { return gx_acos(clampf(v.z, -1, 1)); }

@@ -73,6 +73,7 @@ struct CompiledScene {
     bool has_env = false;
     DEnv env;
     std::vector<float> env_texels;       // Lmap level 0, rgb
+    std::vector<float> env_texels4;      // the same as float4 (rgb_) per texel: one dwordx4 per texel of the bilinear lookup on the device
     float env_power_lookup[3] = {0, 0, 0};   // Lmap->Lookup((.5,.5), .5), for InfiniteAreaLight::Power
     std::vector<float> env_cond_func, env_cond_cdf, env_cond_int;   // Distribution2D conditional rows
     std::vector<float> env_marg_func, env_marg_cdf;

@@ -695,6 +695,8 @@ static void build_env(const gnxr_scene_desc *d, const gnxr_light &l, bool flip_y
         rx = px; ry = py;
     }
     cs->env_texels = tex;
+    cs->env_texels4.resize(tex.size() / 3 * 4);
+    for (size_t i = 0; i < tex.size() / 3; ++i) { cs->env_texels4[4 * i] = tex[3 * i]; cs->env_texels4[4 * i + 1] = tex[3 * i + 1]; cs->env_texels4[4 * i + 2] = tex[3 * i + 2]; cs->env_texels4[4 * i + 3] = 0.f; }
     // InfiniteAreaLight::Power = Pi r^2 Lmap->Lookup((.5, .5), .5) (InfiniteAreaLight.cpp:84-89): the only consumer of the upper
     // MIP levels (MIPMap.h:147-170 box-filter pyramid, :225-242 Lookup, :244-256 triangle).  Only the "power" light
     // strategy reads it.
