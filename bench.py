@@ -62,8 +62,10 @@ def parse(argv=None):
         d = ap.parse_args([])
         if args.width == d.width and args.height == d.height: args.width, args.height = 512, 512
         if args.spp == d.spp: args.spp = 256
-        if args.spp_per_step == d.spp_per_step: args.spp_per_step = 128
-        if args.steps == d.steps: args.steps = args.spp // args.spp_per_step
+        # one pass holds all 256 samples of every pixel (67 M paths, 24 GB): VolPath has one ray in flight per path, so a pass runs ~60
+        # rounds whose tail is thin; the thicker the rounds the better (64 / 128 / 256 spp per pass: 0.425 / 0.364 / 0.336 s)
+        if args.spp_per_step == d.spp_per_step: args.spp_per_step = 256
+        if args.steps == d.steps: args.steps = max(1, args.spp // args.spp_per_step)
     return args
 
 

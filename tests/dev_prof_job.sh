@@ -20,7 +20,7 @@ python bench.py --workload cfg5 > $O/bench_cfg5.json 2> $O/bench_cfg5.err; echo 
 fi
 if has stats; then
 for W in cfg3 cfg4 cfg5; do
-  S=4; if [ $W = cfg5 ]; then S=2; fi
+  S=4; if [ $W = cfg5 ]; then S=1; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$W -- python3 bench.py --workload $W --steps $S --warmup 1 --no-cpu-baseline > $O/stats_$W.log 2>&1
   echo "stats $W done"
 done
@@ -28,12 +28,12 @@ find $O -name "*kernel_stats.csv" | head
 fi
 if has pmc; then
 SQ="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_WAIT_ANY"
-for W in cfg3 cfg5; do
+for W in cfg3 cfg4 cfg5; do
   rocprofv3 --kernel-trace --pmc $SQ -d $O/pmc_sq_$W --output-format csv -- python3 bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/pmc_sq_$W.log 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch_$W --output-format csv -- python3 bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/fetch_$W.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write_$W --output-format csv -- python3 bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/write_$W.log 2>&1
   python tests/dev_traffic.py $O/fetch_$W $O/write_$W $O/traffic_$W.json
-  X=""; if [ $W = cfg5 ]; then X="--width 512 --height 512"; fi
+  X=""; if [ $W = cfg5 ]; then X="--width 512 --height 512 --spp-per-step 256"; fi
   python tests/dev_pmc_json.py $O/pmc_sq_$W $O/pmc_$W.json --workload $W $X --traffic $O/traffic_$W.json
   echo "pmc $W done"
 done

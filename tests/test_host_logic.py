@@ -182,7 +182,7 @@ def test_bench_launch_plan():
     with pytest.raises(SystemExit):
         a("--gpus", "0")
     c5 = a("--workload", "cfg5")
-    assert (c5.width, c5.height, c5.spp, c5.steps) == (512, 512, 256, 2)
+    assert (c5.width, c5.height, c5.spp, c5.spp_per_step, c5.steps) == (512, 512, 256, 256, 1)
     assert a("--workload", "cfg4").workload == "cfg4" and a().workload == "cfg3"
 
 
