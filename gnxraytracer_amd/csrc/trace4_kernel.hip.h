@@ -100,6 +100,9 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
         return (!SPILL || n < lds_entries) ? stk[n * kBlock] : spl[(n - lds_entries) * spillStride];
     };
 
+#ifndef GX_T4_REFILL_IN_A
+#define GX_T4_REFILL_IN_A 0   // measured: 48.2 vs 37.9 ms (profiles/README.md) -- the extra code in the node loop costs more than the lanes it keeps on
+#endif
     unsigned poolBase = 0, poolCount = 0;   // wave-uniform: the chunk of work items this wave owns
     bool exhausted = false;                 // wave-uniform: the global cursor ran past `total`
     unsigned rqHead = 0, rqCount = 0;       // wave-uniform: set-up rays waiting in LDS
@@ -117,6 +120,46 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
     unsigned long long st_[24] = {0};
 #endif
 
+    // take record `slot` of this wave's ready queue into the lane
+    auto take_ray = [&](unsigned slot) {
+        const lds_float *q = (const lds_float *)(rq + slot);
+        ro = V3(q[0 * kRqStride], q[1 * kRqStride], q[2 * kRqStride]); tMax = q[3 * kRqStride];
+        inv = V3(q[4 * kRqStride], q[5 * kRqStride], q[6 * kRqStride]); Sx = q[7 * kRqStride];
+        Sy = q[8 * kRqStride];
+        pk = __float_as_int(q[9 * kRqStride]);
+        path = __float_as_int(q[10 * kRqStride]);
+        hitLeaf = SPH ? rq[slot + 11 * kRqStride] : -1;
+        const int neg0 = inv.x < 0, neg1 = inv.y < 0, neg2 = inv.z < 0;
+        oNX = neg0 ? 48u : 0u; oNY = neg1 ? 64u : 16u; oNZ = neg2 ? 80u : 32u;   // lox 0 loy 16 loz 32 hix 48 hiy 64 hiz 80
+        ordShift = 8u * (unsigned)(neg0 | (neg1 << 1) | (neg2 << 2));
+        cur = ((pk >> 4) & 1) ? -1 : sc.root4; toVisit = 0; leafN = 0;
+        live = true;
+    };
+    // write the result of the lane's finished ray
+    auto retire_ray = [&]() {
+        const int kind = pk & 3;
+        if (kind == 0) {
+            pa.hit[path] = hitLeaf;
+            int cls = 0;   // null materials (and misses that still have to collect an infinite light) use the code of class 0
+            if (SPH ? hitLeaf != -1 : hitLeaf >= 0) {
+                if (!SPH || hitLeaf >= 0) cls = sc.tri_class[hitLeaf];   // one byte instead of the triangle -> material -> class chain
+                else { const int mat = sc.spheres[-2 - hitLeaf].material; if (mat >= 0) cls = sc.materials[mat].shade_class; }
+            } else if (sc.lt.n_infinite == 0) {
+                // a ray that escapes a scene without infinite lights adds nothing and ends its path (PathIntegrator.cpp:101-113):
+                // no shading class (4 is binned nowhere), so it does not take a lane in a k_shade wave
+                cls = 4;
+                pa.pflags[path] = 0;
+            }
+            pa.pclass[path] = (unsigned char)cls;
+        }
+        else if (kind == 1) reinterpret_cast<float *>(&pa.sh_o[path])[3] = hitLeaf == -1 ? 1.f : 0.f;
+        else {
+            const int expect = __float_as_int(pa.mis_o[path].w);   // the leaf triangle the light sample expects (-1: nothing), written by k_shade
+            bool ok = (expect >= 0) ? (hitLeaf == expect) : (hitLeaf == -1);
+            reinterpret_cast<float *>(&pa.mis_o[path])[3] = ok ? 1.f : 0.f;
+        }
+        live = false;
+    };
 #ifdef GX_TRACE_STATS
 #define GX_TICK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); GX_STAT(i, t_ - tick_); tick_ = t_; } while (0)
     unsigned long long tick_ = __builtin_amdgcn_s_memtime();
@@ -210,20 +253,7 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
             }
             if (rqCount > 0) {
                 const unsigned rank = (unsigned)__popcll(needMask & ((1ull << lane) - 1ull));
-                if (need && rank < rqCount) {
-                    const lds_float *q = (const lds_float *)(rq + rqHead + rank);
-                    ro = V3(q[0 * kRqStride], q[1 * kRqStride], q[2 * kRqStride]); tMax = q[3 * kRqStride];
-                    inv = V3(q[4 * kRqStride], q[5 * kRqStride], q[6 * kRqStride]); Sx = q[7 * kRqStride];
-                    Sy = q[8 * kRqStride];
-                    pk = __float_as_int(q[9 * kRqStride]);
-                    path = __float_as_int(q[10 * kRqStride]);
-                    hitLeaf = SPH ? rq[rqHead + rank + 11 * kRqStride] : -1;
-                    const int neg0 = inv.x < 0, neg1 = inv.y < 0, neg2 = inv.z < 0;
-                    oNX = neg0 ? 48u : 0u; oNY = neg1 ? 64u : 16u; oNZ = neg2 ? 80u : 32u;   // lox 0 loy 16 loz 32 hix 48 hiy 64 hiz 80
-                    ordShift = 8u * (unsigned)(neg0 | (neg1 << 1) | (neg2 << 2));
-                    cur = ((pk >> 4) & 1) ? -1 : sc.root4; toVisit = 0; leafN = 0;
-                    live = true;
-                }
+                if (need && rank < rqCount) take_ray(rqHead + rank);
                 const unsigned t = min(rqCount, (unsigned)__popcll(needMask));
                 rqHead += t; rqCount -= t;
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");       // all reads of the queue precede the next batch's writes
@@ -237,9 +267,26 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
         }
 
         // ---------------- phase A: interior traversal until at most half of the live lanes still look for a leaf ----------------
-        const int nLive = __popcll(liveMask);
+        int nLive = __popcll(liveMask);
         GX_STAT(9, nLive);
         while (true) {
+#if GX_T4_REFILL_IN_A
+            // a lane whose ray has ended does not wait for phase C: it writes its result and takes the next set-up ray from the wave's
+            // queue right here (a pop is a dozen ds_reads), so the node steps below run with more lanes on
+            {
+                const bool fin = live && cur == -1 && leafN == 0;
+                const unsigned long long finMask = __ballot(fin);
+                if (finMask != 0 && rqCount > 0) {
+                    if (fin) retire_ray();
+                    const unsigned rank = (unsigned)__popcll(finMask & ((1ull << lane) - 1ull));
+                    if (fin && rank < rqCount) take_ray(rqHead + rank);
+                    const unsigned t = min(rqCount, (unsigned)__popcll(finMask));
+                    rqHead += t; rqCount -= t;
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                    nLive = __popcll(__ballot(live));
+                }
+            }
+#endif
             if (live && leafN == 0 && cur < -1) {   // the next reference is a leaf: stage it, pre-pop its successor
                 const int lr = ~cur;
                 leafOff = lr & 0xffffff; leafN = (lr >> 24) & 0x7f;
@@ -403,30 +450,7 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
         }
         GX_TICK(13);
         // ---------------- phase C: retire finished rays ----------------
-        if (live && cur == -1 && leafN == 0) {
-            const int kind = pk & 3;
-            if (kind == 0) {
-                pa.hit[path] = hitLeaf;
-                int cls = 0;   // null materials (and misses that still have to collect an infinite light) use the code of class 0
-                if (SPH ? hitLeaf != -1 : hitLeaf >= 0) {
-                    if (!SPH || hitLeaf >= 0) cls = sc.tri_class[hitLeaf];   // one byte instead of the triangle -> material -> class chain
-                    else { const int mat = sc.spheres[-2 - hitLeaf].material; if (mat >= 0) cls = sc.materials[mat].shade_class; }
-                } else if (sc.lt.n_infinite == 0) {
-                    // a ray that escapes a scene without infinite lights adds nothing and ends its path (PathIntegrator.cpp:101-113):
-                    // no shading class (4 is binned nowhere), so it does not take a lane in a k_shade wave
-                    cls = 4;
-                    pa.pflags[path] = 0;
-                }
-                pa.pclass[path] = (unsigned char)cls;
-            }
-            else if (kind == 1) reinterpret_cast<float *>(&pa.sh_o[path])[3] = hitLeaf == -1 ? 1.f : 0.f;
-            else {
-                const int expect = __float_as_int(pa.mis_o[path].w);   // the leaf triangle the light sample expects (-1: nothing), written by k_shade
-                bool ok = (expect >= 0) ? (hitLeaf == expect) : (hitLeaf == -1);
-                reinterpret_cast<float *>(&pa.mis_o[path])[3] = ok ? 1.f : 0.f;
-            }
-            live = false;
-        }
+        if (live && cur == -1 && leafN == 0) retire_ray();
     }
 #ifdef GX_TRACE_STATS
     if (lane == 0) for (int i = 0; i < 24; ++i) if (st_[i]) atomicAdd(&g_trace_stats[i], st_[i]);
