@@ -85,6 +85,38 @@ GX_DEV bool tri_test(V3 p0, V3 p1, V3 p2, V3 ro, V3 rd, float tMax, TriHit *h) {
     return tri_test_sheared(p0, p1, p2, ro, rs, tMax, h);
 }
 
+// (t, b0, b1, b2) of a hit the traversal has already accepted: the value-producing operations of tri_test_sheared in the same order
+// (Triangle.cpp:91-135, 149-155), without the rejection tests and the error bound (Triangle.cpp:129-148, 156-168), which can only say
+// "hit" again for the ray, tMax and triangle the traversal accepted.
+GX_DEV void tri_hit_recompute(V3 p0, V3 p1, V3 p2, V3 ro, V3 rd, TriHit *h) {
+    const RayShear rs = ray_shear(rd);
+    V3 p0t = permute3(p0 - ro, rs.kz), p1t = permute3(p1 - ro, rs.kz), p2t = permute3(p2 - ro, rs.kz);
+    const float Sx = rs.Sx, Sy = rs.Sy, Sz = rs.Sz;
+    p0t.x += Sx * p0t.z; p0t.y += Sy * p0t.z;
+    p1t.x += Sx * p1t.z; p1t.y += Sy * p1t.z;
+    p2t.x += Sx * p2t.z; p2t.y += Sy * p2t.z;
+    float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+    float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+    float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+    if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {  // Triangle.cpp:117-128
+        double p2txp1ty = (double)p2t.x * (double)p1t.y;
+        double p2typ1tx = (double)p2t.y * (double)p1t.x;
+        e0 = (float)(p2typ1tx - p2txp1ty);
+        double p0txp2ty = (double)p0t.x * (double)p2t.y;
+        double p0typ2tx = (double)p0t.y * (double)p2t.x;
+        e1 = (float)(p0typ2tx - p0txp2ty);
+        double p1txp0ty = (double)p1t.x * (double)p0t.y;
+        double p1typ0tx = (double)p1t.y * (double)p0t.x;
+        e2 = (float)(p1typ0tx - p1txp0ty);
+    }
+    const float det = e0 + e1 + e2;
+    p0t.z *= Sz; p1t.z *= Sz; p2t.z *= Sz;
+    const float tScaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+    const float invDet = 1 / det;
+    h->b0 = e0 * invDet; h->b1 = e1 * invDet; h->b2 = e2 * invDet;
+    h->t = tScaled * invDet;
+}
+
 GX_DEV void load_tri(const DTri *tris, int leaf, V3 *p0, V3 *p1, V3 *p2) {
     const float4 *q = reinterpret_cast<const float4 *>(tris + leaf);
     float4 a = q[0], b = q[1], c = q[2];

@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
                 float4 a = q[0], b = q[1], c = q[2];
                 p0 = V3(a.x, a.y, a.z); p1 = V3(b.x, b.y, b.z); p2 = V3(c.x, c.y, c.z);
                 triMat = __float_as_int(b.w); triLight = __float_as_int(c.w);
-                found = tri_test(p0, p1, p2, ro, rd, o4.w, &h);  // same arithmetic as the traversal: always true here
+                tri_hit_recompute(p0, p1, p2, ro, rd, &h);   // the traversal accepted this triangle for this ray: same arithmetic, same (t, b0, b1, b2)
                 if (found) {
                     sp = surface_point(p0, p1, p2, h, triMat >= 0 ? sc.materials[triMat].has_bump != 0 : false);
                     if (TEX) {   // per-corner uvs / shading normals (defaults when the triangle has none: same arithmetic as above)
