@@ -160,6 +160,7 @@ struct gnxr_scene {
     DevBuf<uint2> meta;
     DevBuf<int> hit, queue_a, queue_b, queue_nee, queue_c0, queue_c1, queue_c2, queue_c3;
     DevBuf<unsigned char> pflags, pclass;
+    DevBuf<unsigned int> nee_vis;
     DevBuf<unsigned int> tile_counts;
     DevBuf<int> trace_spill;   // global part of k_trace's per-lane traversal stacks
     DevBuf<unsigned> sort_keys_a, sort_keys_b, sort_items_a, sort_items_b;   // ray binning (GNXR_SORT_RAYS)
@@ -600,7 +601,7 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
         }
     }
 #define AL(f) if ((rc = s->f.alloc(cap)) != GNXR_OK) return rc;
-    AL(ray_o) AL(ray_d) AL(beta) AL(L) AL(sh_o) AL(sh_d) AL(sh_X) AL(mis_o) AL(mis_d) AL(mis_Y) AL(nbeta) AL(meta) AL(hit) AL(queue_a) AL(queue_b) AL(queue_nee) AL(queue_c0) AL(queue_c1) AL(queue_c2) AL(queue_c3) AL(pflags) AL(pclass)
+    AL(ray_o) AL(ray_d) AL(beta) AL(L) AL(sh_o) AL(sh_d) AL(sh_X) AL(mis_o) AL(mis_d) AL(mis_Y) AL(nbeta) AL(meta) AL(hit) AL(queue_a) AL(queue_b) AL(queue_nee) AL(queue_c0) AL(queue_c1) AL(queue_c2) AL(queue_c3) AL(pflags) AL(pclass) AL(nee_vis)
 #undef AL
     if (whitted) {
         const size_t nl = (size_t)std::max(1, n_records), md = (size_t)std::max(1, p.max_depth);
@@ -626,7 +627,7 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
     if ((rc = s->tile_counts.alloc((size_t)4 * max_tiles)) != GNXR_OK) return rc;
     PathArrays pa;
     pa.ray_o = s->ray_o.p; pa.ray_d = s->ray_d.p; pa.beta = s->beta.p; pa.L = s->L.p; pa.meta = s->meta.p; pa.hit = s->hit.p; pa.pflags = s->pflags.p; pa.pclass = s->pclass.p;
-    pa.sh_o = s->sh_o.p; pa.sh_d = s->sh_d.p; pa.sh_X = s->sh_X.p; pa.mis_o = s->mis_o.p; pa.mis_d = s->mis_d.p; pa.mis_Y = s->mis_Y.p; pa.nbeta = s->nbeta.p;
+    pa.sh_o = s->sh_o.p; pa.sh_d = s->sh_d.p; pa.sh_X = s->sh_X.p; pa.mis_o = s->mis_o.p; pa.mis_d = s->mis_d.p; pa.mis_Y = s->mis_Y.p; pa.nbeta = s->nbeta.p; pa.nee_vis = s->nee_vis.p;
     VolArrays va;
     va.vs = s->vol_vs.p; va.sv_o = s->sh_o.p; va.sv_d = s->sh_d.p; va.p1 = s->sh_X.p; va.p1e = s->nbeta.p; va.n1 = s->vol_n1.p; va.f = s->vol_f.p;
     va.Li = s->vol_Li.p; va.Tr = s->vol_Tr.p; va.Ld = s->vol_Ld.p; va.mis_o = s->mis_o.p; va.mis_d = s->mis_d.p; va.mis_Y = s->mis_Y.p; va.mres = s->vol_mres.p; va.state = s->vol_state.p;
@@ -894,10 +895,10 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
             HIP_TRY(hipStreamSynchronize(stream));
             int n_next = (int)s->h_counters->q_next, n_nee = (int)s->h_counters->q_nee;
             int n_sh = (int)s->h_counters->q_shadow, n_mis = (int)s->h_counters->q_mis;
-            launch_trace(TraceWork{q_cur, n_next, s->queue_nee.p, n_nee}, n_sh, n_mis);
+            launch_trace(TraceWork{q_cur, n_next, s->queue_nee.p, n_nee, nullptr, reinterpret_cast<unsigned char *>(s->nee_vis.p)}, n_sh, n_mis);
             if (n_nee > 0) {
                 if (timing) timer.begin(1, stream);
-                hipLaunchKernelGGL(k_nee_combine, dim3(grid_for(n_nee)), dim3(kBlock), 0, stream, pa, (const int *)s->queue_nee.p, n_nee);
+                hipLaunchKernelGGL(k_nee_combine, dim3(grid_for(n_nee)), dim3(kBlock), 0, stream, pa, (const int *)s->queue_nee.p, n_nee, reinterpret_cast<const unsigned char *>(s->nee_vis.p));
                 if (timing) timer.end(stream);
                 ++launches;
             }

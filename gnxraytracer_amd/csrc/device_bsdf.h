@@ -308,9 +308,11 @@ GX_DEV float lobe_pdf(const DLobe &l, V3 wo, V3 wi) {
     return same_hemisphere(wo, wi) ? abs_cos_theta(wi) * GX_INV_PI : 0.f;  // BxDF::Pdf
 }
 
-// *pdf is left untouched on early-outs (the caller zeroes it), as in the reference.
+// *pdf is left untouched on early-outs (the caller zeroes it), as in the reference.  need_f = false: the caller (BSDF::Sample_f for a
+// non-specular lobe, Reflection.cpp:548-556) replaces the returned value by the sum over all matching lobes, so the lobe's own f is not
+// evaluated a first time here.
 template <uint32_t LM>
-GX_DEV Spec lobe_sample(const DLobe &l, V3 wo, V3 *wi, float u0, float u1, float *pdf, int *sampledType) {
+GX_DEV Spec lobe_sample(const DLobe &l, V3 wo, V3 *wi, float u0, float u1, float *pdf, int *sampledType, bool need_f = true) {
     switch (l.kind) {
     case LOBE_SPEC_REFL: if (GX_HAS_LOBE(LOBE_SPEC_REFL)) {  // Reflection.cpp:89-97
         *wi = V3(-wo.x, -wo.y, wo.z);
@@ -363,14 +365,14 @@ GX_DEV Spec lobe_sample(const DLobe &l, V3 wo, V3 *wi, float u0, float u1, float
             if (!refract(wo, wh, eta, wi)) return Spec(0.f);
             *pdf = lobe_pdf<LM>(l, wo, *wi);
         }
-        return lobe_f<LM>(l, wo, *wi);
+        return need_f ? lobe_f<LM>(l, wo, *wi) : Spec(0.f);
     }
     break;
     case LOBE_LAMBERT_TRANS: if (GX_HAS_LOBE(LOBE_LAMBERT_TRANS)) {  // Reflection.cpp:146-155
         *wi = cosine_sample_hemisphere(u0, u1);
         if (wo.z > 0) wi->z *= -1;
         *pdf = lobe_pdf<LM>(l, wo, *wi);
-        return lobe_f<LM>(l, wo, *wi);
+        return need_f ? lobe_f<LM>(l, wo, *wi) : Spec(0.f);
     }
     break;
     case LOBE_DISNEY_CLEARCOAT: if (GX_HAS_LOBE(LOBE_DISNEY_CLEARCOAT)) {  // DisneyMaterial.cpp:255-276
@@ -386,7 +388,7 @@ GX_DEV Spec lobe_sample(const DLobe &l, V3 wo, V3 *wi, float u0, float u1, float
         *wi = reflect(wo, wh);
         if (!same_hemisphere(wo, *wi)) return Spec(0.f);
         *pdf = lobe_pdf<LM>(l, wo, *wi);
-        return lobe_f<LM>(l, wo, *wi);
+        return need_f ? lobe_f<LM>(l, wo, *wi) : Spec(0.f);
     }
     break;
     default: break;
@@ -395,7 +397,7 @@ GX_DEV Spec lobe_sample(const DLobe &l, V3 wo, V3 *wi, float u0, float u1, float
     *wi = cosine_sample_hemisphere(u0, u1);
     if (wo.z < 0) wi->z *= -1;
     *pdf = lobe_pdf<LM>(l, wo, *wi);
-    return lobe_f<LM>(l, wo, *wi);
+    return need_f ? lobe_f<LM>(l, wo, *wi) : Spec(0.f);
 }
 
 // ---- BSDF container, Reflection.h:102-154 + Reflection.cpp:440-563 ----
@@ -464,7 +466,7 @@ struct Bsdf {
         *pdf = 0;
         if (wo.z == 0) return Spec(0.f);
         *sampledType = bx.type;
-        Spec f = lobe_sample<LM>(bx, wo, &wi, ur0, u1, pdf, sampledType);
+        Spec f = lobe_sample<LM>(bx, wo, &wi, ur0, u1, pdf, sampledType, (bx.type & BSDF_SPECULAR) != 0);
         if (*pdf == 0) { *sampledType = 0; return Spec(0.f); }
         *wiW = to_world(wi);
         if (!(bx.type & BSDF_SPECULAR) && matching > 1) {   // the other matching lobes' pdfs, in lobe order; per-lane walk as in sum_f

@@ -40,6 +40,7 @@ struct PathArrays {
     float4 *mis_d;    // MIS ray direction
     float4 *mis_Y;    // f*Li*w/scatteringPdf if the expectation holds
     float4 *nbeta;    // beta at the vertex
+    unsigned int *nee_vis;   // PathIntegrator: per path [0] shadow ray unoccluded, [1] MIS ray found what it expects (bytes written by k_trace), [2] record flags (k_shade)
 };
 
 struct Counters {
@@ -96,8 +97,10 @@ GX_DEV void camera_ray(const DCamera &cam, const DSamplerTables &st, int px, int
     float fx, fy, lx, ly;
     s.get2d(&fx, &fy);
     float pfx = (float)px + fx, pfy = (float)py + fy;
-    (void)s.get1d();  // time
-    s.get2d(&lx, &ly);
+    // CameraSample::time and ::pLens are drawn by every GetCameraSample; their VALUES are read only by a thin-lens camera (time: never --
+    // start == end transform), so a pinhole camera just steps over the three dimensions (3 of the 5 radical inverses of k_raygen)
+    s.dim += 1;  // time
+    if (cam.lens_radius > 0) s.get2d(&lx, &ly); else { s.dim += 2; lx = ly = 0.f; }
     V3 pCamera = xform_point(cam.r2c, V3(pfx, pfy, 0));
     V3 dir = normalize(V3(pCamera.x, pCamera.y, pCamera.z));
     V3 oc(0, 0, 0), dc = dir;
@@ -146,8 +149,8 @@ GX_DEV RayDiff camera_ray_diff(const DCamera &cam, const DSamplerTables &st, int
     SampleStream s(st, index, 0);
     float fx, fy, lx, ly;
     s.get2d(&fx, &fy);
-    (void)s.get1d();
-    s.get2d(&lx, &ly);
+    s.dim += 1;
+    if (cam.lens_radius > 0) s.get2d(&lx, &ly); else { s.dim += 2; lx = ly = 0.f; }
     V3 pCamera = xform_point(cam.r2c, V3((float)px + fx, (float)py + fy, 0));
     V3 dxCamera = xform_point(cam.r2c, V3(1, 0, 0)) - xform_point(cam.r2c, V3(0, 0, 0));
     V3 dyCamera = xform_point(cam.r2c, V3(0, 1, 0)) - xform_point(cam.r2c, V3(0, 0, 0));
@@ -492,6 +495,7 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
                                     pa.mis_Y[path] = make_float4(Y.r, Y.g, Y.b, 0.f);
                                 }
                                 pa.nbeta[path] = make_float4(beta.r, beta.g, beta.b, 0.f);
+                                pa.nee_vis[path] = (unsigned)nflags << 16;
                                 wantNee = true;
                                 wantShadow = (nflags & 1) != 0;
                                 wantMis = (nflags & 2) != 0;

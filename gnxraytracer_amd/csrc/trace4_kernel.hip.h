@@ -109,7 +109,7 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
 
     // per-lane ray state
     bool live = false;
-    int pk = 0, path = -1;   // pk: kind (bits 0-1: 0 continuation, 1 shadow, 2 MIS) | kz << 2 (Triangle.cpp:91) | exact << 5
+    int pk = 0, path = -1;   // pk: kind (bits 0-1: 0 continuation, 1 shadow, 2 MIS) | kz << 2 (Triangle.cpp:91) | done << 4 | exact << 5 | first hit ends the walk << 6
     V3 ro, inv;
     float Sx = 0, Sy = 0, tMax = 0;
     unsigned oNX = 0, oNY = 16, oNZ = 32;   // byte offset of the near plane of each axis inside a DNode4 (far = 48 | 80 | 112 - near ... see below)
@@ -152,11 +152,14 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
             }
             pa.pclass[path] = (unsigned char)cls;
         }
-        else if (kind == 1) reinterpret_cast<float *>(&pa.sh_o[path])[3] = hitLeaf == -1 ? 1.f : 0.f;
-        else {
+        else if (kind == 1) {
+            if (w.vis) w.vis[4 * (size_t)path] = hitLeaf == -1 ? 1 : 0;
+            else reinterpret_cast<float *>(&pa.sh_o[path])[3] = hitLeaf == -1 ? 1.f : 0.f;
+        } else {
             const int expect = __float_as_int(pa.mis_o[path].w);   // the leaf triangle the light sample expects (-1: nothing), written by k_shade
             bool ok = (expect >= 0) ? (hitLeaf == expect) : (hitLeaf == -1);
-            reinterpret_cast<float *>(&pa.mis_o[path])[3] = ok ? 1.f : 0.f;
+            if (w.vis) w.vis[4 * (size_t)path + 1] = ok ? 1 : 0;
+            else reinterpret_cast<float *>(&pa.mis_o[path])[3] = ok ? 1.f : 0.f;
         }
         live = false;
     };
@@ -191,7 +194,7 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
                         unsigned i = poolBase + (unsigned)lane;
                         if (w.order) i = w.order[i];
                         float4 o4, d4;
-                        int kind_ = 0, path_;
+                        int kind_ = 0, path_, any_ = 0;
                         float tMax_;
                         valid = true;
                         if (i < (unsigned)w.n_closest) {
@@ -205,12 +208,15 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
                             path_ = w.q_nee[isShadow ? e : e - (unsigned)w.n_nee];
                             const int nflags = __float_as_int(pa.sh_d[path_].w);
                             if (isShadow) {
-                                kind_ = 1;
+                                kind_ = 1; any_ = 1;
                                 if (nflags & 1) { o4 = pa.sh_o[path_]; d4 = pa.sh_d[path_]; tMax_ = o4.w; }
                                 else valid = false;     // this vertex spawned no shadow ray
                             } else {
                                 kind_ = 2;
-                                if (nflags & 2) { o4 = pa.mis_o[path_]; d4 = pa.mis_d[path_]; tMax_ = GX_INF; }
+                                // a MIS ray that expects to escape (an infinite light was sampled) asks "is there any hit at all": with tMax = inf
+                                // the closest-hit walk and the any-hit walk visit the same nodes up to the first accepted triangle, and that
+                                // triangle already decides the answer
+                                if (nflags & 2) { o4 = pa.mis_o[path_]; d4 = pa.mis_d[path_]; tMax_ = GX_INF; any_ = __float_as_int(o4.w) < 0 ? 1 : 0; }
                                 else valid = false;
                             }
                         }
@@ -223,7 +229,7 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
                                 float tH;
                                 if (sphere_test(sc.spheres[si], o, d, tMax_, &tH)) {
                                     sphHit = -2 - si;
-                                    if (kind_ == 1) { done = 1; break; }
+                                    if (any_) { done = 1; break; }
                                     tMax_ = tH;
                                 }
                             }
@@ -232,7 +238,7 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
                             const int ex = (__builtin_isinf(iv.x) || __builtin_isinf(iv.y) || __builtin_isinf(iv.z)) ? 1 : 0;
                             r0 = make_float4(o.x, o.y, o.z, tMax_);
                             r1 = make_float4(iv.x, iv.y, iv.z, sh.Sx);
-                            r2 = make_float4(sh.Sy, __int_as_float(kind_ | (sh.kz << 2) | (done << 4) | (ex << 5)), __int_as_float(path_), 0.f);
+                            r2 = make_float4(sh.Sy, __int_as_float(kind_ | (sh.kz << 2) | (done << 4) | (ex << 5) | (any_ << 6)), __int_as_float(path_), 0.f);
                         }
                     }
                     const unsigned long long vm = __ballot(valid);
@@ -441,7 +447,7 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
                     TriHit h;
                     if (tri_test_sheared(p0, p1, p2, ro, shear, tMax, &h)) {
                         hitLeaf = leafOff + i;
-                        if ((pk & 3) == 1) { cur = -1; break; }   // IntersectP returns at the first hit
+                        if (pk & 64) { cur = -1; break; }        // IntersectP returns at the first hit (and so may a MIS ray that expects a miss)
                         tMax = h.t;                            // GeometricPrimitive::Intersect shrinks ray.tMax
                     }
                 }

@@ -3,6 +3,7 @@
 //   kind 0  continuation ray      closest hit  -> PathArrays::hit[path]
 //   kind 1  shadow ray            any hit      -> sh_o[path].w  = 1 if unoccluded        (Light.cpp:28-31)
 //   kind 2  MIS ray               closest hit  -> mis_o[path].w = 1 if it found what the light sample expects
+//   (PathIntegrator launches pass TraceWork::vis and get both results as bytes of one word per path instead)
 //                                                                                         (Integrator.cpp:193-203)
 //
 // CDNA4 structure (this is where the time goes, so it is shaped for wave64 rather than for one ray):
@@ -27,6 +28,9 @@ struct TraceWork {
     const int *q_closest; int n_closest;   // path slots (nullptr == identity)
     const int *q_nee; int n_nee;           // paths with an NEE record: two work items each (shadow ray, MIS ray)
     const unsigned *order;                 // nullptr, or a permutation of the work items: position in the launch -> work item (ray binning, k_trace_keys)
+    unsigned char *vis;                    // nullptr: visibility results go to sh_o[path].w / mis_o[path].w (float 1 / 0).  Otherwise 4 bytes per path:
+                                           // [0] shadow ray unoccluded, [1] MIS ray found what the light sample expects (written here), [2] the record's
+                                           // flags (written by k_shade) -- k_nee_combine then reads one word instead of three float4
 };
 
 constexpr int kTraceChunk = 512;   // most rays a wave takes per global atomic (the host shrinks the chunk for thin launches so that every wave gets one)
@@ -346,10 +350,13 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
                 }
                 pa.pclass[path] = (unsigned char)cls;
             }
-            else if (kind == 1) reinterpret_cast<float *>(&pa.sh_o[path])[3] = hitLeaf == -1 ? 1.f : 0.f;
-            else {
+            else if (kind == 1) {
+                if (w.vis) w.vis[4 * (size_t)path] = hitLeaf == -1 ? 1 : 0;
+                else reinterpret_cast<float *>(&pa.sh_o[path])[3] = hitLeaf == -1 ? 1.f : 0.f;
+            } else {
                 bool ok = (expect >= 0) ? (hitLeaf == expect) : (hitLeaf == -1);
-                reinterpret_cast<float *>(&pa.mis_o[path])[3] = ok ? 1.f : 0.f;
+                if (w.vis) w.vis[4 * (size_t)path + 1] = ok ? 1 : 0;
+                else reinterpret_cast<float *>(&pa.mis_o[path])[3] = ok ? 1.f : 0.f;
             }
             item = -1;
         }
@@ -406,18 +413,21 @@ static __global__ void __launch_bounds__(kBlock) k_trace_keys(PathArrays pa, Tra
 }
 
 // L += beta * (EstimateDirect(...) / lightPdf), core/Integrator.cpp:78 + PathIntegrator.cpp:135-141, once the
-// two visibility results of the vertex are known.  Pure streaming.
-static __global__ void __launch_bounds__(kBlock) k_nee_combine(PathArrays pa, const int *__restrict__ queue, int n) {
+// two visibility results of the vertex are known.  Pure streaming: per NEE vertex one word of flags + results (TraceWork::vis), X, Y when
+// the vertex has a MIS ray, beta and L (72 B read, 16 B written; the first version read the three float4 that carried flags and results
+// in their w lanes: 128 B).
+static __global__ void __launch_bounds__(kBlock) k_nee_combine(PathArrays pa, const int *__restrict__ queue, int n, const unsigned char *__restrict__ vis) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         int path = queue[i];
-        float4 sd4 = pa.sh_d[path], X4 = pa.sh_X[path];
-        int flags = __float_as_int(sd4.w);
+        const unsigned v = reinterpret_cast<const unsigned *>(vis)[path];
+        const int flags = (int)((v >> 16) & 0xffu);
+        float4 X4 = pa.sh_X[path];
         Spec Ld(0.f);
-        if ((flags & 1) && pa.sh_o[path].w == 1.f) Ld = Ld + Spec(X4.x, X4.y, X4.z);
-        if (flags & 2) {
+        if ((flags & 1) && (v & 0xffu)) Ld = Ld + Spec(X4.x, X4.y, X4.z);
+        if ((flags & 2) && ((v >> 8) & 0xffu)) {
             float4 Y4 = pa.mis_Y[path];
             Spec Y(Y4.x, Y4.y, Y4.z);
-            if (pa.mis_o[path].w == 1.f && !Y.is_black()) Ld = Ld + Y;
+            if (!Y.is_black()) Ld = Ld + Y;
         }
         float4 nb = pa.nbeta[path], L4 = pa.L[path];
         Spec add = Spec(nb.x, nb.y, nb.z) * (Ld / X4.w);
