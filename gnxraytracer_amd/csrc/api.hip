@@ -192,6 +192,8 @@ struct gnxr_scene {
         d.tris = tris.p;
         d.leaf_box = reinterpret_cast<const float4 *>(leaf_boxes.p);
         d.tri_class = tri_class.p;
+        static const bool no_verts = getenv("GNXR_LEAF_BOX_TABLE") != nullptr;   // experiment switch: always read leaf_boxes
+        d.leaf1_from_verts = (cs.leaf1_from_verts && !no_verts) ? 1 : 0;
         d.spheres = spheres.p;
         d.n_spheres = cs.n_spheres;
         d.materials = materials.p + 1;   // [0] carries the texture tables
@@ -745,6 +747,11 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
             int tiles = (nin + kCompactTile - 1) / kCompactTile;
             int g = std::min(tiles, g_num_cus * 8);
             if (mode == COMPACT_FLAGS) hipLaunchKernelGGL((k_compact_count<COMPACT_FLAGS, 4>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles);
+            else if (mode == COMPACT_HITCLASS) {   // class of the triangle a path hit, looked up and left in `keys` for the scatter pass
+                if (nout == 4) hipLaunchKernelGGL((k_compact_count<COMPACT_HITCLASS, 4>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles, (const int *)s->hit.p, (const unsigned char *)s->tri_class.p, s->pclass.p);
+                else hipLaunchKernelGGL((k_compact_count<COMPACT_HITCLASS, 3>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles, (const int *)s->hit.p, (const unsigned char *)s->tri_class.p, s->pclass.p);
+                mode = COMPACT_CLASS;
+            }
             else if (nout == 4) hipLaunchKernelGGL((k_compact_count<COMPACT_CLASS, 4>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles);
             else hipLaunchKernelGGL((k_compact_count<COMPACT_CLASS, 3>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles);
             hipLaunchKernelGGL(k_compact_scan, dim3(nout), dim3(1024), 0, stream, s->tile_counts.p, tiles, totals);
@@ -847,7 +854,7 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
             if (timing) timer.begin(2, stream);
             // bin the paths by the shade specialisation of the material they hit (pclass written by k_trace)
             const int n_classes = (class_mask & 8) ? 4 : 3;   // image-textured materials have a shade queue of their own
-            compact(COMPACT_CLASS, q_in, n, s->pclass.p, n_classes, n_classes, &dctr->q_class[0], s->queue_c0.p, s->queue_c1.p, s->queue_c2.p, s->queue_c3.p);
+            compact(COMPACT_HITCLASS, q_in, n, s->pclass.p, n_classes, n_classes, &dctr->q_class[0], s->queue_c0.p, s->queue_c1.p, s->queue_c2.p, s->queue_c3.p);
             {
                 int *qc[4] = {s->queue_c0.p, s->queue_c1.p, s->queue_c2.p, s->queue_c3.p};
                 dim3 g(grid_for(n)), b(kBlock);

@@ -15,12 +15,15 @@
 namespace gnxr {
 
 constexpr int kCompactBlock = 256;
-enum CompactMode { COMPACT_FLAGS = 0, COMPACT_CLASS = 1 };
+enum CompactMode { COMPACT_FLAGS = 0, COMPACT_CLASS = 1, COMPACT_HITCLASS = 2 };
 
 template <int MODE>
 GX_DEV unsigned compact_key(const unsigned char *keys, int path) { return keys[path]; }
 template <int MODE>
 GX_DEV bool compact_pred(unsigned key, int o) { return MODE == COMPACT_FLAGS ? ((key >> o) & 1u) != 0 : key == (unsigned)o; }
+//   mode HITCLASS (count pass only): a path whose ray hit a triangle gets its class from tri_class[hit[path]] here, and the pass leaves
+//                 it in keys[path] for the scatter pass (mode CLASS); k_trace writes keys[path] itself only for misses and sphere hits, so
+//                 that its retire step has no dependent gather
 
 // A tile = kCompactTile items = kCompactChunks chunks of one block's width: 8 x fewer tile counts for the single-block scan of pass 2
 // (1 M counts per predicate at 265 M paths took 0.28 ms per scan, 1.7 % of the GPU time of cfg 3; 130 k take 0.04 ms).
@@ -30,7 +33,8 @@ constexpr int kCompactTile = kCompactBlock * kCompactChunks;
 // pass 1: tile_counts[o * nTiles + tile] = number of items of the tile that satisfy predicate o
 template <int MODE, int NOUT>
 __global__ void __launch_bounds__(kCompactBlock) k_compact_count(const int *__restrict__ q_in, int n, const unsigned char *__restrict__ keys, unsigned int *tile_counts,
-                                                                 int nTiles) {
+                                                                 int nTiles, const int *__restrict__ hit = nullptr, const unsigned char *__restrict__ tri_class = nullptr,
+                                                                 unsigned char *keys_out = nullptr) {
     __shared__ unsigned int wsum[NOUT][kCompactBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
@@ -41,7 +45,14 @@ __global__ void __launch_bounds__(kCompactBlock) k_compact_count(const int *__re
             const long long i = (long long)tile * kCompactTile + c * kCompactBlock + threadIdx.x;
             unsigned key = 0xffu;
             const bool valid = i < n;
-            if (valid) key = compact_key<MODE>(keys, q_in ? q_in[i] : (int)i);
+            if (valid) {
+                const int path = q_in ? q_in[i] : (int)i;
+                if (MODE == COMPACT_HITCLASS) {
+                    const int h = hit[path];
+                    if (h >= 0) { key = tri_class[h]; keys_out[path] = (unsigned char)key; }
+                    else key = keys_out[path];   // (the same array as `keys`; read through the pointer that also writes it)
+                } else key = compact_key<MODE>(keys, path);
+            }
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) acc[o] += (unsigned)__popcll(__ballot(valid && compact_pred<MODE>(key, o)));   // wave-uniform
         }

@@ -50,7 +50,8 @@ struct CompiledScene {
     int stack4_need = 1;                 // worst-case traversal stack entries for nodes4
     std::vector<DTri> tris;              // leaf order
     std::vector<float> leaf_boxes;       // 8 floats per leaf-order triangle, valid at the first triangle of each leaf: the leaf's LinearBVHNode bounds (lo.xyz hi.x | hi.yz 0 0)
-    std::vector<uint8_t> tri_class;      // per leaf-order triangle: DMaterial::shade_class of its material (0 for null materials): what k_trace writes into pclass
+    int leaf1_from_verts = 0;            // every one-triangle leaf's bounds == min / max of its triangle's vertices (checked in compile_scene)
+    std::vector<uint8_t> tri_class;      // per leaf-order triangle: DMaterial::shade_class of its material (0 for null materials): the class the binning pass gives a path that hit it
     std::vector<int32_t> leaf_of_prim;   // authoring index -> leaf index
     int bvh_max_depth = 0;
     Box3 world_bound;

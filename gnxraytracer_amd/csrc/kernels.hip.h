@@ -62,6 +62,7 @@ struct DScene {
     const DTri *tris;
     const unsigned char *tri_class;   // shade class of each leaf-order triangle's material (CompiledScene::tri_class)
     const float4 *leaf_box;   // 2 float4 per leaf-order triangle: bounds of the leaf that starts there (CompiledScene::leaf_boxes)
+    int leaf1_from_verts;     // every one-triangle leaf's bounds equal the min / max of its vertices (checked by the scene compiler): no table read for them
     const DSphere *spheres;   // tested before the BVH; hit code -2 - index
     int n_spheres;
     const DMaterial *materials;   // materials[-1] holds the DTexTables of the scene (tex_tables(), device_texture.h)
@@ -344,12 +345,22 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
     unsigned long long sst_[16] = {0};
     unsigned long long stick_ = __builtin_amdgcn_s_memtime();
 #endif
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    // The item's loads form a dependent chain (queue -> path state, hit -> triangle) that two or three waves per SIMD cannot hide, so the
+    // queue entry is fetched two iterations and the hit one iteration ahead (k_trace wrote `hit`; nothing in this kernel changes it): the
+    // state and the triangle of an item are then requested together.
+    const int stride_ = (int)(gridDim.x * blockDim.x);
+    int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    int pathCur_ = i < n ? queue[i] : -1;
+    int leafCur_ = pathCur_ >= 0 ? pa.hit[pathCur_] : -1;
+    int pathNext_ = (long long)i + stride_ < n ? queue[i + stride_] : -1;
+    for (; i < n; i += stride_) {
         bool survive = false, wantNee = false, wantShadow = false, wantMis = false;
         int path = -1;
         GX_STICK(9);
+        const int leafNext_ = pathNext_ >= 0 ? pa.hit[pathNext_] : -1;
+        const int pathNext2_ = (long long)i + 2ll * stride_ < n ? queue[i + 2 * stride_] : -1;
         {
-            path = queue[i];
+            path = pathCur_;
             uint2 m = pa.meta[path];
             uint32_t index = m.x;
             int dim = (int)(m.y & 0xffffu), bounces = (int)((m.y >> 16) & 0xffu);
@@ -358,7 +369,7 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
             V3 ro(o4.x, o4.y, o4.z), rd(d4.x, d4.y, d4.z);
             Spec beta(b4.x, b4.y, b4.z), L(L4.x, L4.y, L4.z);
             float etaScale = b4.w;
-            int leaf = pa.hit[path];
+            int leaf = leafCur_;
             bool found = leaf != -1;
             V3 p0, p1, p2;
             int triMat = -1, triLight = -1;
@@ -538,6 +549,7 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
             pa.L[path] = make_float4(L.r, L.g, L.b, 0.f);
         }
         pa.pflags[path] = (unsigned char)((survive ? 1 : 0) | (wantNee ? 2 : 0) | (wantShadow ? 4 : 0) | (wantMis ? 8 : 0));
+        pathCur_ = pathNext_; leafCur_ = leafNext_; pathNext_ = pathNext2_;
     }
 #ifdef GX_SHADE_STATS
     if ((threadIdx.x & 63) == 0) for (int k = 0; k < 16; ++k) if (sst_[k]) atomicAdd(&g_shade_stats[k], sst_[k]);

@@ -1007,6 +1007,19 @@ bool compile_scene(const gnxr_scene_desc *d, CompiledScene *cs, MortonSortFn mor
         if (t.material >= 0 && d->materials[t.material].type == GNXR_MAT_NONE) t.material = -1;   // no BSDF: medium boundary
         t.p2[0] = p2.x; t.p2[1] = p2.y; t.p2[2] = p2.z; t.light = d->tri_light[prim];
     }
+    // a one-triangle leaf's bounds are Triangle::WorldBound() = Union(Bounds3f(p0, p1), p2) (shape/Triangle.cpp:60-69): the componentwise
+    // min / max of the vertices, no rounding involved.  Checked here for every such leaf so that k_trace4 can rebuild the box from the
+    // vertices it loads anyway; any mismatch (there should be none) sends all leaves back to the leaf_boxes table.
+    cs->leaf1_from_verts = 1;
+    for (const DNode &n : cs->nodes)
+        if ((n.meta & 0xffffu) == 1 && (size_t)n.offset < cs->tris.size()) {
+            const DTri &t = cs->tris[n.offset];
+            const float hi[3] = {n.hi0, n.hi1, n.hi2};
+            for (int a = 0; a < 3; ++a) {
+                const float lo_v = std::min(std::min(t.p0[a], t.p1[a]), t.p2[a]), hi_v = std::max(std::max(t.p0[a], t.p1[a]), t.p2[a]);
+                if (!(lo_v == n.lo[a]) || !(hi_v == hi[a])) cs->leaf1_from_verts = 0;
+            }
+        }
     // ---- materials
     cs->materials.resize(std::max(1, d->n_materials));
     memset(cs->materials.data(), 0, sizeof(DMaterial) * cs->materials.size());

@@ -140,17 +140,19 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
         const int kind = pk & 3;
         if (kind == 0) {
             pa.hit[path] = hitLeaf;
-            int cls = 0;   // null materials (and misses that still have to collect an infinite light) use the code of class 0
-            if (SPH ? hitLeaf != -1 : hitLeaf >= 0) {
-                if (!SPH || hitLeaf >= 0) cls = sc.tri_class[hitLeaf];   // one byte instead of the triangle -> material -> class chain
-                else { const int mat = sc.spheres[-2 - hitLeaf].material; if (mat >= 0) cls = sc.materials[mat].shade_class; }
-            } else if (sc.lt.n_infinite == 0) {
-                // a ray that escapes a scene without infinite lights adds nothing and ends its path (PathIntegrator.cpp:101-113):
-                // no shading class (4 is binned nowhere), so it does not take a lane in a k_shade wave
-                cls = 4;
-                pa.pflags[path] = 0;
+            // The shade class of a triangle hit is looked up from `hit` by the binning pass (k_compact_count<COMPACT_HITCLASS>: tri_class[hit]) --
+            // a dependent gather here would stall the whole wave once per retire.  Only hits without a triangle get their class here.
+            if (hitLeaf < 0) {
+                int cls = 0;   // misses that still have to collect an infinite light use the code of class 0
+                if (SPH && hitLeaf != -1) { const int mat = sc.spheres[-2 - hitLeaf].material; if (mat >= 0) cls = sc.materials[mat].shade_class; }
+                else if (sc.lt.n_infinite == 0) {
+                    // a ray that escapes a scene without infinite lights adds nothing and ends its path (PathIntegrator.cpp:101-113):
+                    // no shading class (4 is binned nowhere), so it does not take a lane in a k_shade wave
+                    cls = 4;
+                    pa.pflags[path] = 0;
+                }
+                pa.pclass[path] = (unsigned char)cls;
             }
-            pa.pclass[path] = (unsigned char)cls;
         }
         else if (kind == 1) {
             if (w.vis) w.vis[4 * (size_t)path] = hitLeaf == -1 ? 1 : 0;
@@ -206,18 +208,25 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
                             const unsigned e = i - (unsigned)w.n_closest;
                             const bool isShadow = e < (unsigned)w.n_nee;
                             path_ = w.q_nee[isShadow ? e : e - (unsigned)w.n_nee];
-                            const int nflags = __float_as_int(pa.sh_d[path_].w);
+                            // PathIntegrator launches (w.vis: one record per path, every record array has an entry for it): the record's flags and
+                            // its ray are loaded together -- one memory round trip after the queue read, not two; a record without the ray has
+                            // stale floats there, which are dropped.  Other integrators size the MIS arrays by what they use: flags first.
+                            const bool together = w.vis != nullptr;
                             if (isShadow) {
                                 kind_ = 1; any_ = 1;
-                                if (nflags & 1) { o4 = pa.sh_o[path_]; d4 = pa.sh_d[path_]; tMax_ = o4.w; }
-                                else valid = false;     // this vertex spawned no shadow ray
+                                o4 = pa.sh_o[path_]; d4 = pa.sh_d[path_]; tMax_ = o4.w;
+                                valid = (__float_as_int(d4.w) & 1) != 0;     // else: this vertex spawned no shadow ray
                             } else {
                                 kind_ = 2;
+                                const int nflags = __float_as_int(pa.sh_d[path_].w);
+                                valid = (nflags & 2) != 0;
+                                if (together || valid) { o4 = pa.mis_o[path_]; d4 = pa.mis_d[path_]; }
+                                else { o4 = make_float4(0, 0, 0, 0); d4 = o4; }
+                                tMax_ = GX_INF;
                                 // a MIS ray that expects to escape (an infinite light was sampled) asks "is there any hit at all": with tMax = inf
                                 // the closest-hit walk and the any-hit walk visit the same nodes up to the first accepted triangle, and that
                                 // triangle already decides the answer
-                                if (nflags & 2) { o4 = pa.mis_o[path_]; d4 = pa.mis_d[path_]; tMax_ = GX_INF; any_ = __float_as_int(o4.w) < 0 ? 1 : 0; }
-                                else valid = false;
+                                any_ = __float_as_int(o4.w) < 0 ? 1 : 0;
                             }
                         }
                         if (valid) {
@@ -426,12 +435,16 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
 #endif
         if (live && leafN > 0) {
             bool visit = true;
-            if (SPH ? hitLeaf != -1 : hitLeaf >= 0) {   // tMax only ever shrinks after a hit: before the first hit the earlier test stands
-                // BVHAccel::Intersect tests a leaf's box when it pops it, i.e. against the CURRENT ray.tMax; the 4-wide step tested it
-                // earlier with an older tMax.  Re-test the leaf's own bounds (the floats of its LinearBVHNode, addressed by its first
-                // triangle) so that exact ties (t == tMax on flat, axis-aligned boxes such as the Cornell walls) resolve as in the reference.
+            // BVHAccel::Intersect tests a leaf's box when it pops it, i.e. against the CURRENT ray.tMax; the 4-wide step tested it earlier with
+            // an older tMax.  tMax only ever shrinks after a hit (before the first hit the earlier test stands), so a ray that has one re-tests
+            // the leaf's own bounds -- exact ties (t == tMax on flat, axis-aligned boxes such as the Cornell walls) then resolve as in the
+            // reference.  The bounds of a one-triangle leaf are the componentwise min / max of its vertices (Triangle::WorldBound, exact),
+            // which this phase loads anyway; only larger leaves read the floats of their LinearBVHNode (leaf_box, addressed by the first triangle).
+            const bool retest = SPH ? hitLeaf != -1 : hitLeaf >= 0;
+            const bool fromVerts = retest && leafN == 1 && sc.leaf1_from_verts;
+            int neg[3] = {inv.x < 0, inv.y < 0, inv.z < 0};
+            if (retest && !fromVerts) {
                 const float4 b0 = sc.leaf_box[2 * (size_t)leafOff], b1 = sc.leaf_box[2 * (size_t)leafOff + 1];
-                int neg[3] = {inv.x < 0, inv.y < 0, inv.z < 0};
                 if (COUNT) cntRetests++;
                 visit = slab_test(b0, b1, ro, inv, neg, tMax);
             }
@@ -444,6 +457,11 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
                     V3 p0, p1, p2;
                     load_tri(tris, leafOff + i, &p0, &p1, &p2);
                     if (COUNT) cntTris++;
+                    if (fromVerts) {
+                        const float4 b0 = make_float4(fminf(fminf(p0.x, p1.x), p2.x), fminf(fminf(p0.y, p1.y), p2.y), fminf(fminf(p0.z, p1.z), p2.z), fmaxf(fmaxf(p0.x, p1.x), p2.x));
+                        const float4 b1 = make_float4(fmaxf(fmaxf(p0.y, p1.y), p2.y), fmaxf(fmaxf(p0.z, p1.z), p2.z), 0.f, 0.f);
+                        if (!slab_test(b0, b1, ro, inv, neg, tMax)) break;
+                    }
                     TriHit h;
                     if (tri_test_sheared(p0, p1, p2, ro, shear, tMax, &h)) {
                         hitLeaf = leafOff + i;

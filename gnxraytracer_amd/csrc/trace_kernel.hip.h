@@ -338,17 +338,17 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
         if (item >= 0 && cur == -1 && leafN == 0) {
             if (kind == 0) {
                 pa.hit[path] = hitLeaf;
-                int cls = 0;   // null materials (and misses that still have to collect an infinite light) use the code of class 0
-                if (SPH ? hitLeaf != -1 : hitLeaf >= 0) {
-                    int mat = (!SPH || hitLeaf >= 0) ? tris[hitLeaf].material : sc.spheres[-2 - hitLeaf].material;
-                    if (mat >= 0) cls = sc.materials[mat].shade_class;
-                } else if (sc.lt.n_infinite == 0) {
-                    // a ray that escapes a scene without infinite lights adds nothing and ends its path (PathIntegrator.cpp:101-113):
-                    // no shading class (4 is binned nowhere), so it does not take a lane in a k_shade wave
-                    cls = 4;
-                    pa.pflags[path] = 0;
+                if (hitLeaf < 0) {   // triangle hits: the binning pass looks the class up from `hit` (k_compact_count<COMPACT_HITCLASS>)
+                    int cls = 0;     // misses that still have to collect an infinite light use the code of class 0
+                    if (SPH && hitLeaf != -1) { const int mat = sc.spheres[-2 - hitLeaf].material; if (mat >= 0) cls = sc.materials[mat].shade_class; }
+                    else if (sc.lt.n_infinite == 0) {
+                        // a ray that escapes a scene without infinite lights adds nothing and ends its path (PathIntegrator.cpp:101-113):
+                        // no shading class (4 is binned nowhere), so it does not take a lane in a k_shade wave
+                        cls = 4;
+                        pa.pflags[path] = 0;
+                    }
+                    pa.pclass[path] = (unsigned char)cls;
                 }
-                pa.pclass[path] = (unsigned char)cls;
             }
             else if (kind == 1) {
                 if (w.vis) w.vis[4 * (size_t)path] = hitLeaf == -1 ? 1 : 0;
