@@ -863,16 +863,20 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
                 static const int shade_lds_dims = getenv("GNXR_SHADE_LDS_DIMS") ? std::max(0, std::min(128, atoi(getenv("GNXR_SHADE_LDS_DIMS")))) : 64;   // tuning knob
                 const int sdims = std::min<int>(shade_lds_dims, (int)s->cs.prime_sums.size() - 1);
                 const int snperm = sdims > 0 ? s->cs.prime_sums[sdims] : 0;
-                const size_t slds = sdims > 0 ? ((((size_t)snperm * 2 + 15) & ~(size_t)15) + (size_t)sdims * 16) : 0;
+                // + the scene's material and light tables when they are small (k_shade: dependent gathers along the BSDF code become LDS reads)
+                static const bool shade_lds_tabs = getenv("GNXR_SHADE_LDS_TABLES") ? atoi(getenv("GNXR_SHADE_LDS_TABLES")) != 0 : true;   // experiment switch
+                const int lmats = (shade_lds_tabs && s->cs.materials.size() <= 12) ? (int)s->cs.materials.size() : 0;
+                const int llights = (shade_lds_tabs && nL > 0 && nL <= 16) ? nL : 0;
+                const size_t slds = (sdims > 0 ? ((((size_t)snperm * 2 + 15) & ~(size_t)15) + (size_t)sdims * 16) : 0) + (size_t)lmats * sizeof(DMaterial) + (size_t)llights * sizeof(DLight);
 #define GX_SHADE(LMV, LTV, C)                                                                                                                        \
     do {                                                                                                                                             \
-        if (spheres) hipLaunchKernelGGL((k_shade<LMV, LTV, true>), g, b, slds, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C], sdims, snperm); \
-        else hipLaunchKernelGGL((k_shade<LMV, LTV, false>), g, b, slds, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C], sdims, snperm);       \
+        if (spheres) hipLaunchKernelGGL((k_shade<LMV, LTV, true>), g, b, slds, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C], sdims, snperm, lmats, llights); \
+        else hipLaunchKernelGGL((k_shade<LMV, LTV, false>), g, b, slds, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C], sdims, snperm, lmats, llights);       \
     } while (0)
 #define GX_SHADE_TEX(LTV)                                                                                                                            \
     do {                                                                                                                                             \
-        if (spheres) hipLaunchKernelGGL((k_shade<LM_ALL, LTV, true, true>), g, b, slds, stream, sc, r, pa, (const int *)qc[3], (const unsigned int *)&dctr->q_class[3], sdims, snperm); \
-        else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, slds, stream, sc, r, pa, (const int *)qc[3], (const unsigned int *)&dctr->q_class[3], sdims, snperm);       \
+        if (spheres) hipLaunchKernelGGL((k_shade<LM_ALL, LTV, true, true>), g, b, slds, stream, sc, r, pa, (const int *)qc[3], (const unsigned int *)&dctr->q_class[3], sdims, snperm, lmats, llights); \
+        else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, slds, stream, sc, r, pa, (const int *)qc[3], (const unsigned int *)&dctr->q_class[3], sdims, snperm, lmats, llights);       \
     } while (0)
                 if (area_only) {
                     GX_SHADE(LM_DIFFUSE, LT_AREA, 0);
@@ -881,7 +885,7 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
                     if (class_mask & 8) GX_SHADE_TEX(LT_AREA);
                 } else if (area_env_only && !spheres && !(class_mask & 8)) {
                     // BASELINE config 4's light set (area lights + one InfiniteAreaLight): without the delta-light and sky-box code
-#define GX_SHADE_AE(LMV, C) hipLaunchKernelGGL((k_shade<LMV, LT_AREA | LT_ENV, false>), g, b, slds, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C], sdims, snperm)
+#define GX_SHADE_AE(LMV, C) hipLaunchKernelGGL((k_shade<LMV, LT_AREA | LT_ENV, false>), g, b, slds, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C], sdims, snperm, lmats, llights)
                     GX_SHADE_AE(LM_DIFFUSE, 0);
                     if (class_mask & 2) GX_SHADE_AE(LM_GLOSSY, 1);
                     if (class_mask & 4) GX_SHADE_AE(LM_ALL, 2);

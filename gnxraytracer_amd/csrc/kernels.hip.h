@@ -335,11 +335,32 @@ static __device__ unsigned long long g_shade_stats[16];
 #define GX_STICK(i) do {} while (0)
 #endif
 template <uint32_t LM, int LT, bool SPH, bool TEX = false>
-__global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRender r, PathArrays pa, const int *__restrict__ queue, const unsigned int *n_dev, int lds_dims, int lds_nperm) {
-    extern __shared__ int shade_smem[];   // the Halton tables of dimensions [0, lds_dims): device_sampler.h LdsSampler
+__global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRender r, PathArrays pa, const int *__restrict__ queue, const unsigned int *n_dev, int lds_dims, int lds_nperm, int lds_mats, int lds_lights) {
+    extern __shared__ int shade_smem[];   // the Halton tables of dimensions [0, lds_dims): device_sampler.h LdsSampler | the scene's DMaterial[] | DLight[]
     const int n = (int)*n_dev;
     if (blockIdx.x * blockDim.x >= (unsigned)n) return;   // this block has no item: skip the table fill
     const LdsSampler lsam = lds_sampler_fill(sc.st, lds_dims, lds_nperm, shade_smem, threadIdx.x, kBlock);
+    // The lobe parameters of the hit material and the sampled light are read field by field along the BSDF code -- each a dependent
+    // gather that two or three waves per SIMD cannot hide.  Small scenes' tables (a few KB) are copied into LDS; `mats` / `ltab.lights`
+    // then point there (generic pointers: same code either way).
+    const DMaterial *mats = sc.materials;
+    DLightTables ltab = sc.lt;
+    {
+        int *dst = shade_smem + (lds_sampler_bytes(lds_nperm, lds_dims) >> 2);
+        if (!TEX && lds_mats > 0) {
+            const int *src = reinterpret_cast<const int *>(sc.materials);
+            const int nd = lds_mats * (int)(sizeof(DMaterial) / 4);
+            for (int k = threadIdx.x; k < nd; k += kBlock) dst[k] = src[k];
+            mats = reinterpret_cast<const DMaterial *>(dst);
+            dst += nd;
+        }
+        if (lds_lights > 0) {
+            const int *src = reinterpret_cast<const int *>(sc.lt.lights);
+            const int nd = lds_lights * (int)(sizeof(DLight) / 4);
+            for (int k = threadIdx.x; k < nd; k += kBlock) dst[k] = src[k];
+            ltab.lights = reinterpret_cast<const DLight *>(dst);
+        }
+    }
     __syncthreads();
 #ifdef GX_SHADE_STATS
     unsigned long long sst_[16] = {0};
@@ -381,7 +402,7 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
                 triMat = sph.material;
                 float tH;
                 found = sphere_test(sph, ro, rd, o4.w, &tH);
-                if (found) sp = sphere_surface_point(sph, ro, rd, tH, triMat >= 0 ? sc.materials[triMat].has_bump != 0 : false);
+                if (found) sp = sphere_surface_point(sph, ro, rd, tH, triMat >= 0 ? mats[triMat].has_bump != 0 : false);
             } else if (found) {
                 const float4 *q = reinterpret_cast<const float4 *>(sc.tris + leaf);
                 float4 a = q[0], b = q[1], c = q[2];
@@ -389,10 +410,10 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
                 triMat = __float_as_int(b.w); triLight = __float_as_int(c.w);
                 tri_hit_recompute(p0, p1, p2, ro, rd, &h);   // the traversal accepted this triangle for this ray: same arithmetic, same (t, b0, b1, b2)
                 if (found) {
-                    sp = surface_point(p0, p1, p2, h, triMat >= 0 ? sc.materials[triMat].has_bump != 0 : false);
+                    sp = surface_point(p0, p1, p2, h, triMat >= 0 ? mats[triMat].has_bump != 0 : false);
                     if (TEX) {   // per-corner uvs / shading normals (defaults when the triangle has none: same arithmetic as above)
                         V3 dndu, dndv;
-                        sp = surface_point_tables(tex_tables(sc.materials), leaf, p0, p1, p2, h, triMat >= 0 ? sc.materials[triMat].has_bump != 0 : false, &dndu, &dndv);
+                        sp = surface_point_tables(tex_tables(sc.materials), leaf, p0, p1, p2, h, triMat >= 0 ? mats[triMat].has_bump != 0 : false, &dndu, &dndv);
                     }
                     found = sp.valid;
                 }
@@ -401,9 +422,9 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
             // PathIntegrator.cpp:101-111: emitted light at the vertex / from the environment
             if (bounces == 0 || specularBounce) {
                 if (found) {
-                    if (triLight >= 0) L = L + beta * area_L(sc.lt.lights[triLight], sp.n, -rd);
+                    if (triLight >= 0) L = L + beta * area_L(ltab.lights[triLight], sp.n, -rd);
                 } else {
-                    for (int k = 0; k < sc.lt.n_infinite; ++k) L = L + beta * light_Le<LT>(sc.lt, sc.lt.infinite[k], ro, rd);
+                    for (int k = 0; k < ltab.n_infinite; ++k) L = L + beta * light_Le<LT>(ltab, ltab.infinite[k], ro, rd);
                 }
             }
             GX_STICK(1);   // Le
@@ -414,7 +435,7 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
                     pa.ray_o[path] = make_float4(o2.x, o2.y, o2.z, GX_INF);
                     survive = true;
                 } else {
-                    const DMaterial *mat = sc.materials + triMat;
+                    const DMaterial *mat = mats + triMat;
                     DMaterial tm;
                     if (TEX && leaf >= 0 && (mat->kd_tex | mat->ks_tex)) {
                         float tu, tv;
@@ -430,9 +451,10 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
                     SampleStream ss(sc.st, index, dim, lsam);
                     V3 woN = normalize(-rd);  // Interaction::wo
                     // ---- UniformSampleOneLight, Integrator.cpp:57-79
-                    if (mat->n_nonspecular > 0 && sc.lt.n_lights > 0) {
+                    if (mat->n_nonspecular > 0 && ltab.n_lights > 0) {
                         float lightPdfSel;
-                        int lightNum = light_select(sc.lt, sp.p, ss.get1d(), &lightPdfSel);
+                        // (fetching the voxel's whole record ahead of the Halton value and searching it in registers was tried: +2.4 % shade time)
+                        int lightNum = light_select(ltab, sp.p, ss.get1d(), &lightPdfSel);
                         GX_STICK(2);   // light selection (1 Halton value + grid lookup)
                         if (lightPdfSel != 0) {
                             float ul0, ul1, us0, us1;
@@ -446,7 +468,7 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
                             V3 so, sd, mo, wi2;
                             Spec X(0.f), Y(0.f);
                             int expect = -1;
-                            LightSample ls = light_sample<LT>(sc.lt, lightNum, sp.p, ul0, ul1);
+                            LightSample ls = light_sample<LT>(ltab, lightNum, sp.p, ul0, ul1);
                             GX_STICK(4);   // light_sample
                             float scatteringPdf = 0;
                             if (ls.pdf > 0 && !ls.Li.is_black()) {
@@ -455,13 +477,13 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
                                 if (!f.is_black()) {
                                     // visibility.Unoccluded(scene): shadow ray p0.SpawnRayTo(p1), Light.cpp:28-31
                                     spawn_ray_to(sp.p, sp.pError, sp.n, ls.p1, ls.p1Error, ls.n1, &so, &sd);
-                                    float weight = light_is_delta<LT>(sc.lt.lights[lightNum]) ? 1.f : power_heuristic(ls.pdf, scatteringPdf);
+                                    float weight = light_is_delta<LT>(ltab.lights[lightNum]) ? 1.f : power_heuristic(ls.pdf, scatteringPdf);
                                     X = f * ls.Li * weight / ls.pdf;
                                     nflags |= 1;
                                 }
                             }
                             GX_STICK(5);   // BSDF f / pdf towards the light sample, shadow ray
-                            if (!light_is_delta<LT>(sc.lt.lights[lightNum])) {
+                            if (!light_is_delta<LT>(ltab.lights[lightNum])) {
                                 int sampledType;
                                 Spec f = bsdf.sample_f(woN, &wi2, us0, us1, &scatteringPdf, bsdfFlags, &sampledType);
                                 f = f * absdot(wi2, sp.ns);
@@ -471,14 +493,14 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
                                     float weight = 1;
                                     bool skip = false;
                                     if (!sampledSpecular) {
-                                        float lightPdf = light_pdf<LT>(sc.lt, lightNum, sp.p, sp.pError, sp.n, wi2);
+                                        float lightPdf = light_pdf<LT>(ltab, lightNum, sp.p, sp.pError, sp.n, wi2);
                                         if (lightPdf == 0) skip = true;  // `return Ld`
                                         else weight = power_heuristic(scatteringPdf, lightPdf);
                                     }
                                     if (!skip) {
                                         // closest-hit ray isect.SpawnRay(wi) (Integrator.cpp:193-197); what it must find for
                                         // the light to contribute is known up front: this light's triangle, or nothing.
-                                        const DLight &lt = sc.lt.lights[lightNum];
+                                        const DLight &lt = ltab.lights[lightNum];
                                         mo = offset_ray_origin(sp.p, sp.pError, sp.n, wi2);
                                         Spec Li2;
                                         if (LT == LT_AREA || lt.type == GNXR_LIGHT_AREA_TRI) {
@@ -487,7 +509,7 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
                                             Li2 = area_L(lt, ln, -wi2);
                                             expect = lt.tri_leaf;
                                         } else {
-                                            Li2 = light_Le<LT>(sc.lt, lightNum, mo, wi2);
+                                            Li2 = light_Le<LT>(ltab, lightNum, mo, wi2);
                                             expect = -1;
                                         }
                                         if (!Li2.is_black()) Y = f * Li2 * Spec(1.f) * weight / scatteringPdf;
