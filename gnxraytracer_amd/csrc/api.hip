@@ -245,6 +245,7 @@ struct gnxr_scene {
         if (on_device) {
             const size_t nv = (size_t)grid.nvox[0] * grid.nvox[1] * grid.nvox[2];
             if ((rc = grid_table.alloc(nv * grid.stride)) != GNXR_OK) return rc;
+            HIP_TRY(hipMemset(grid_table.p, 0, nv * grid.stride * sizeof(float)));   // padded records: the pad floats are zero, as in the host-built table
             float ri[5 * 128];
             light_grid_probes(cs, ri);
             DevBuf<float> d_ri;

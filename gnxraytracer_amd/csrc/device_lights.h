@@ -265,6 +265,27 @@ GX_DEV int light_select(const DLightTables &t, V3 p, float u, float *pdf) {
         int pz = min(max((int)(o.z * g.nvox[2]), 0), g.nvox[2] - 1);
         rec += (((size_t)px * g.nvox[1] + py) * g.nvox[2] + pz) * g.stride;
     }
+    if (nl <= 3 && (g.stride & 3) == 0) {
+        // padded record (build_light_grid): the whole of it in one or two aligned loads, then the same search on registers
+        const float4 a = *reinterpret_cast<const float4 *>(rec);
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (nl >= 2) b = *reinterpret_cast<const float4 *>(rec + 4);
+        float c0 = a.x, c1 = 0.f, c2 = 0.f, f0, f1 = 0.f, f2 = 0.f, fi;
+        if (nl == 1) { f0 = a.y; fi = a.z; }
+        else if (nl == 2) { c1 = a.y; f0 = a.z; f1 = a.w; fi = b.x; }
+        else { c1 = a.y; c2 = a.z; f0 = a.w; f1 = b.x; f2 = b.y; fi = b.z; }
+        int first = 0, len = nl + 1;
+        while (len > 0) {
+            int half = len >> 1, middle = first + half;
+            float c = (middle == 0) ? 0.f : (middle == 1 ? c0 : (middle == 2 ? c1 : c2));
+            if (c <= u) { first = middle + 1; len -= half + 1; }
+            else len = half;
+        }
+        int offset = min(max(first - 1, 0), nl - 1);
+        float func = offset == 0 ? f0 : (offset == 1 ? f1 : f2);
+        *pdf = (fi > 0) ? func / (fi * nl) : 0;
+        return offset;
+    }
     // FindInterval over cdf[0..nl] where cdf[0] = 0 and rec[i] = cdf[i+1]
     int first = 0, len = nl + 1;
     while (len > 0) {
