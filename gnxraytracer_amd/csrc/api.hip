@@ -572,6 +572,8 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
     DScene sc = s->device_scene(p.width, p.height);
     // the device sampler keeps the Halton index in 32 bits
     if ((unsigned long long)sc.st.h.stride * ((unsigned long long)p.spp * max_light_samples + 1) >= (1ull << 32)) { set_error("spp too large for 32-bit Halton indices"); return GNXR_ERR_UNSUPPORTED; }
+    // every index this render draws is below stride * (spp * n + 1); reversedDigits of base b stays below b * index (device_sampler.h)
+    sc.st.h.base32_max = (int32_t)std::min<unsigned long long>(0x7fffffffull, 0xffffffffull / ((unsigned long long)sc.st.h.stride * ((unsigned long long)p.spp * max_light_samples + 1)));
     DRender r;
     memset(&r, 0, sizeof(r));
     r.cam = make_camera(s->cs.camera, p.width, p.height, s->cs.camera_medium);
@@ -868,7 +870,7 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
                 static const bool shade_lds_tabs = getenv("GNXR_SHADE_LDS_TABLES") ? atoi(getenv("GNXR_SHADE_LDS_TABLES")) != 0 : true;   // experiment switch
                 const int lmats = (shade_lds_tabs && s->cs.materials.size() <= 12) ? (int)s->cs.materials.size() : 0;
                 const int llights = (shade_lds_tabs && nL > 0 && nL <= 16) ? nL : 0;
-                const size_t slds = (sdims > 0 ? ((((size_t)snperm * 2 + 15) & ~(size_t)15) + (size_t)sdims * 16) : 0) + (size_t)lmats * sizeof(DMaterial) + (size_t)llights * sizeof(DLight);
+                const size_t slds = (sdims > 0 ? ((((size_t)snperm * 2 + 15) & ~(size_t)15) + (size_t)sdims * 32) : 0) + (size_t)lmats * sizeof(DMaterial) + (size_t)llights * sizeof(DLight);
 #define GX_SHADE(LMV, LTV, C)                                                                                                                        \
     do {                                                                                                                                             \
         if (spheres) hipLaunchKernelGGL((k_shade<LMV, LTV, true>), g, b, slds, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C], sdims, snperm, lmats, llights); \
@@ -1124,6 +1126,12 @@ int gnxr_sample_halton(int32_t width, int32_t height, const int32_t *px, const i
     if ((rc = probe_tables(&cs, &perms, &primes, &sums, &magic, &st, width, height))) return rc;
     DevBuf<int32_t> dpx, dpy, ddim; DevBuf<long long> ds; DevBuf<float> dout;
     if ((rc = dpx.upload(px, n)) || (rc = dpy.upload(py, n)) || (rc = ddim.upload(dim, n)) || (rc = ds.upload((const long long *)sidx, n)) || (rc = dout.alloc(n))) return rc;
+    {   // the probe takes the render path's 32-bit accumulator wherever its indices allow it
+        unsigned long long smax = 0;
+        for (int64_t i = 0; i < n; ++i) smax = std::max<unsigned long long>(smax, (unsigned long long)std::max<int64_t>(0, sidx[i]));
+        const unsigned long long bound = (unsigned long long)st.h.stride * (smax + 2);
+        st.h.base32_max = bound >= (1ull << 32) ? 0 : (int32_t)std::min<unsigned long long>(0x7fffffffull, 0xffffffffull / bound);
+    }
     hipLaunchKernelGGL(k_halton_probe, dim3(grid_for(n)), dim3(kBlock), 0, 0, st, (const int *)dpx.p, (const int *)dpy.p, (const long long *)ds.p, (const int *)ddim.p, (long long)n, dout.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out, dout.p, n * sizeof(float), hipMemcpyDeviceToHost));

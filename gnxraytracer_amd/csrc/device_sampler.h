@@ -26,28 +26,43 @@ GX_DEV uint32_t div_magic(uint32_t n, uint32_t M, uint32_t s) {
     return (t + ((n - t) >> 1)) >> (s - 1);
 }
 
+// What a scrambled radical inverse needs to know about its dimension.  invBase = 1 / (float)base and the tail of the reference's last line,
+// invBase * perm[0] / (1 - invBase) (LowDiscrepancy.cpp:392: the digits beyond the index's own are all perm[0]), are constants of the
+// dimension: the LDS copy holds them (computed once per block with the same IEEE operations), the global path computes them per call.
+struct DimInfo { uint32_t base, M, s, off; float invBase, tail; };
+GX_DEV float halton_tail(float invBase, uint32_t perm0) { return invBase * (float)(int)perm0 / (1 - invBase); }
+
 // Where the tables are read from.  GlobalTab: the scene's arrays in global memory.  LdsTab: a block's LDS copy of the first `dims`
 // dimensions (k_shade: the permutation digits of a path vertex are ~90 per-lane gathers, and the vector-memory path takes ~1 lane per
 // clock per CU whatever they hit -- tools/probes/gather_probe.hip; from LDS they are ds_reads).  Same values, same arithmetic.
 struct GlobalTab {
     const DSamplerTables &t;
-    GX_DEV void dim(int d, uint32_t *base, uint32_t *M, uint32_t *s, uint32_t *off) const {
-        *base = (uint32_t)t.primes[d]; *M = t.prime_magic[2 * d]; *s = t.prime_magic[2 * d + 1]; *off = (uint32_t)t.prime_sums[d];
-    }
     GX_DEV uint32_t perm(uint32_t i) const { return t.perms[i]; }
+    GX_DEV DimInfo dim(int d) const {
+        DimInfo q;
+        q.base = (uint32_t)t.primes[d]; q.M = t.prime_magic[2 * d]; q.s = t.prime_magic[2 * d + 1]; q.off = (uint32_t)t.prime_sums[d];
+        q.invBase = 1.f / (float)q.base;
+        q.tail = halton_tail(q.invBase, perm(q.off));
+        return q;
+    }
 };
 typedef __attribute__((address_space(3))) const uint16_t lds_u16c;
 typedef unsigned int u4v __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const u4v lds_u4c;
 struct LdsSampler {
     lds_u16c *perms;   // perms[0 .. prime_sums[dims])
-    lds_u4c *tab;      // per dimension: (prime, magic M, magic s, prime_sum)
+    lds_u4c *tab;      // per dimension two entries: (prime, magic M, magic s, prime_sum), (invBase, tail, 0, 0)
     int dims;          // dimensions [0, dims) are in LDS; 0 == no LDS copy
 };
 struct LdsTab {
     const LdsSampler &l;
-    GX_DEV void dim(int d, uint32_t *base, uint32_t *M, uint32_t *s, uint32_t *off) const { const u4v v = l.tab[d]; *base = v.x; *M = v.y; *s = v.z; *off = v.w; }
     GX_DEV uint32_t perm(uint32_t i) const { return l.perms[i]; }
+    GX_DEV DimInfo dim(int d) const {
+        const u4v v = l.tab[2 * d], w = l.tab[2 * d + 1];
+        DimInfo q;
+        q.base = v.x; q.M = v.y; q.s = v.z; q.off = v.w; q.invBase = __uint_as_float(w.x); q.tail = __uint_as_float(w.y);
+        return q;
+    }
 };
 
 // RadicalInverseSpecialized<base>, LowDiscrepancy.cpp:358-372
@@ -67,21 +82,24 @@ GX_DEV float radical_inverse_base(uint32_t a, uint32_t base, uint32_t M, uint32_
 // ScrambledRadicalInverseSpecialized<base>, LowDiscrepancy.cpp:374-393.  Digits are peeled four at a time so that the four
 // permutation-table loads are independent and in flight together (the serial loop waited for one L1/L2 round trip per
 // digit); the accumulation then runs in the reference's order, digit by digit, for as many digits as the index has.
-template <class TAB>
-GX_DEV float scrambled_radical_inverse_base(uint32_t a, uint32_t base, uint32_t M, uint32_t s, const TAB &tab, uint32_t off) {
-    const float invBase = 1.f / (float)base;
-    uint64_t reversedDigits = 0;
+// ACC: the integer type reversedDigits is kept in.  The reference's is 64 bits wide; its value stays below base * index, so when that
+// fits 32 bits (DHalton::base32_max, set per render from the largest index) a 32-bit accumulator holds the same integer, the digit
+// step is one multiply-add instead of a two-part 64-bit one, and the final conversion to float rounds the same integer once.
+template <class ACC, class TAB>
+GX_DEV float scrambled_radical_inverse_acc(uint32_t a, const DimInfo &q, const TAB &tab) {
+    const uint32_t base = q.base, M = q.M, s = q.s, off = q.off;
+    ACC reversedDigits = 0;
     float invBaseN = 1;
     while (a) {
         const uint32_t n1 = div_magic(a, M, s), n2 = div_magic(n1, M, s), n3 = div_magic(n2, M, s), n4 = div_magic(n3, M, s);
         const uint32_t p0 = tab.perm(off + a - n1 * base), p1 = tab.perm(off + n1 - n2 * base), p2 = tab.perm(off + n2 - n3 * base), p3 = tab.perm(off + n3 - n4 * base);
-        reversedDigits = reversedDigits * base + p0; invBaseN *= invBase;
-        if (n1) { reversedDigits = reversedDigits * base + p1; invBaseN *= invBase; }
-        if (n2) { reversedDigits = reversedDigits * base + p2; invBaseN *= invBase; }
-        if (n3) { reversedDigits = reversedDigits * base + p3; invBaseN *= invBase; }
+        reversedDigits = reversedDigits * base + p0; invBaseN *= q.invBase;
+        reversedDigits = n1 ? reversedDigits * base + p1 : reversedDigits; invBaseN = n1 ? invBaseN * q.invBase : invBaseN;
+        reversedDigits = n2 ? reversedDigits * base + p2 : reversedDigits; invBaseN = n2 ? invBaseN * q.invBase : invBaseN;
+        reversedDigits = n3 ? reversedDigits * base + p3 : reversedDigits; invBaseN = n3 ? invBaseN * q.invBase : invBaseN;
         a = n4;
     }
-    return fminf(invBaseN * ((float)reversedDigits + invBase * (float)(int)tab.perm(off) / (1 - invBase)), GX_ONE_MINUS_EPS);
+    return fminf(invBaseN * ((float)reversedDigits + q.tail), GX_ONE_MINUS_EPS);
 }
 // base 2: ReverseBits64(a) * 2^-64 evaluated in double, LowDiscrepancy.cpp:396-403.  For a < 2^32 the
 // reversed word is brev(a) << 32, so the product is brev(a) * 2^-32 and one rounding to float remains.
@@ -91,10 +109,10 @@ GX_DEV float radical_inverse_2(uint32_t a) { return (float)((double)__brev(a) * 
 template <class TAB>
 GX_DEV float halton_sample_t(const TAB &tab, const DHalton &h, uint32_t index, int dim) {
     if (dim == 0) return radical_inverse_2(index >> h.base_exp[0]);
-    uint32_t base, M, s, off;
-    tab.dim(dim, &base, &M, &s, &off);
-    if (dim == 1) return radical_inverse_base(index / (uint32_t)h.base_scale[1], base, M, s);
-    return scrambled_radical_inverse_base(index, base, M, s, tab, off);
+    const DimInfo q = tab.dim(dim);
+    if (dim == 1) return radical_inverse_base(index / (uint32_t)h.base_scale[1], q.base, q.M, q.s);
+    if (q.base <= (uint32_t)h.base32_max) return scrambled_radical_inverse_acc<uint32_t>(index, q, tab);
+    return scrambled_radical_inverse_acc<uint64_t>(index, q, tab);
 }
 GX_DEV float halton_sample(const DSamplerTables &t, uint32_t index, int dim) {
     if (dim >= 1000) dim = 2 + (dim - 2) % 998;  // reference reads PrimeSums out of bounds here; defined to wrap
@@ -103,41 +121,45 @@ GX_DEV float halton_sample(const DSamplerTables &t, uint32_t index, int dim) {
 
 // Two consecutive dimensions (both >= 2, already wrapped) of the same sample index at once: the two digit chains are independent, so
 // their permutation-table loads overlap (one memory round trip instead of two).  Same operations per dimension as
-// scrambled_radical_inverse_base, hence the same values.
-template <class TAB>
-GX_DEV void halton_sample_pair_t(const TAB &tab, uint32_t index, int d0, int d1, float *u0, float *u1) {
-    uint32_t b0, M0, s0, o0, b1, M1, s1, o1;
-    tab.dim(d0, &b0, &M0, &s0, &o0);
-    tab.dim(d1, &b1, &M1, &s1, &o1);
-    const float inv0 = 1.f / (float)b0, inv1 = 1.f / (float)b1;
-    uint64_t rev0 = 0, rev1 = 0;
+// scrambled_radical_inverse_acc, hence the same values.
+template <class ACC, class TAB>
+GX_DEV void halton_sample_pair_acc(const TAB &tab, uint32_t index, const DimInfo &q0, const DimInfo &q1, float *u0, float *u1) {
+    const uint32_t b0 = q0.base, M0 = q0.M, s0 = q0.s, o0 = q0.off, b1 = q1.base, M1 = q1.M, s1 = q1.s, o1 = q1.off;
+    const float inv0 = q0.invBase, inv1 = q1.invBase;
+    ACC rev0 = 0, rev1 = 0;
     float invN0 = 1, invN1 = 1;
     uint32_t a0 = index, a1 = index;
-    const uint32_t z0 = tab.perm(o0), z1 = tab.perm(o1);
     while (a0 | a1) {
         const uint32_t n01 = div_magic(a0, M0, s0), n02 = div_magic(n01, M0, s0), n03 = div_magic(n02, M0, s0), n04 = div_magic(n03, M0, s0);
         const uint32_t n11 = div_magic(a1, M1, s1), n12 = div_magic(n11, M1, s1), n13 = div_magic(n12, M1, s1), n14 = div_magic(n13, M1, s1);
         const uint32_t p00 = tab.perm(o0 + a0 - n01 * b0), p01 = tab.perm(o0 + n01 - n02 * b0), p02 = tab.perm(o0 + n02 - n03 * b0), p03 = tab.perm(o0 + n03 - n04 * b0);
         const uint32_t p10 = tab.perm(o1 + a1 - n11 * b1), p11 = tab.perm(o1 + n11 - n12 * b1), p12 = tab.perm(o1 + n12 - n13 * b1), p13 = tab.perm(o1 + n13 - n14 * b1);
-        if (a0) { rev0 = rev0 * b0 + p00; invN0 *= inv0; }
-        if (n01) { rev0 = rev0 * b0 + p01; invN0 *= inv0; }
-        if (n02) { rev0 = rev0 * b0 + p02; invN0 *= inv0; }
-        if (n03) { rev0 = rev0 * b0 + p03; invN0 *= inv0; }
-        if (a1) { rev1 = rev1 * b1 + p10; invN1 *= inv1; }
-        if (n11) { rev1 = rev1 * b1 + p11; invN1 *= inv1; }
-        if (n12) { rev1 = rev1 * b1 + p12; invN1 *= inv1; }
-        if (n13) { rev1 = rev1 * b1 + p13; invN1 *= inv1; }
+        rev0 = a0 ? rev0 * b0 + p00 : rev0; invN0 = a0 ? invN0 * inv0 : invN0;
+        rev0 = n01 ? rev0 * b0 + p01 : rev0; invN0 = n01 ? invN0 * inv0 : invN0;
+        rev0 = n02 ? rev0 * b0 + p02 : rev0; invN0 = n02 ? invN0 * inv0 : invN0;
+        rev0 = n03 ? rev0 * b0 + p03 : rev0; invN0 = n03 ? invN0 * inv0 : invN0;
+        rev1 = a1 ? rev1 * b1 + p10 : rev1; invN1 = a1 ? invN1 * inv1 : invN1;
+        rev1 = n11 ? rev1 * b1 + p11 : rev1; invN1 = n11 ? invN1 * inv1 : invN1;
+        rev1 = n12 ? rev1 * b1 + p12 : rev1; invN1 = n12 ? invN1 * inv1 : invN1;
+        rev1 = n13 ? rev1 * b1 + p13 : rev1; invN1 = n13 ? invN1 * inv1 : invN1;
         a0 = n04; a1 = n14;
     }
-    *u0 = fminf(invN0 * ((float)rev0 + inv0 * (float)(int)z0 / (1 - inv0)), GX_ONE_MINUS_EPS);
-    *u1 = fminf(invN1 * ((float)rev1 + inv1 * (float)(int)z1 / (1 - inv1)), GX_ONE_MINUS_EPS);
+    *u0 = fminf(invN0 * ((float)rev0 + q0.tail), GX_ONE_MINUS_EPS);
+    *u1 = fminf(invN1 * ((float)rev1 + q1.tail), GX_ONE_MINUS_EPS);
+}
+template <class TAB>
+GX_DEV void halton_sample_pair_t(const TAB &tab, const DHalton &h, uint32_t index, int d0, int d1, float *u0, float *u1) {
+    const DimInfo q0 = tab.dim(d0), q1 = tab.dim(d1);
+    if (q1.base <= (uint32_t)h.base32_max) halton_sample_pair_acc<uint32_t>(tab, index, q0, q1, u0, u1);   // primes ascend with the dimension
+    else halton_sample_pair_acc<uint64_t>(tab, index, q0, q1, u0, u1);
 }
 GX_DEV void halton_sample_pair(const DSamplerTables &t, uint32_t index, int dim, float *u0, float *u1) {
     int d0 = dim, d1 = dim + 1;
     if (d0 >= 1000) d0 = 2 + (d0 - 2) % 998;
     if (d1 >= 1000) d1 = 2 + (d1 - 2) % 998;
     if (d0 < 2 || d1 < 2) { *u0 = halton_sample(t, index, dim); *u1 = halton_sample(t, index, dim + 1); return; }
-    halton_sample_pair_t(GlobalTab{t}, index, d0, d1, u0, u1);
+    if (d1 < d0) { *u0 = halton_sample(t, index, d0); *u1 = halton_sample(t, index, d1); return; }   // the pair straddles the wrap
+    halton_sample_pair_t(GlobalTab{t}, t.h, index, d0, d1, u0, u1);
 }
 
 // HaltonSampler::GetIndexForSample offset part, HaltonSampler.cpp:63-83 (kMaxResolution = 128)
@@ -169,12 +191,12 @@ struct SampleStream {
     GX_DEV void get2d(float *u0, float *u1) {
         const int d = dim;
         dim += 2;
-        if (d >= 2 && d + 1 < lds.dims) { halton_sample_pair_t(LdsTab{lds}, index, d, d + 1, u0, u1); return; }
+        if (d >= 2 && d + 1 < lds.dims) { halton_sample_pair_t(LdsTab{lds}, t.h, index, d, d + 1, u0, u1); return; }
         halton_sample_pair(t, index, d, u0, u1);
     }
 };
 // a block's LDS copy of the first `dims` dimensions: perms[0 .. prime_sums[dims]) followed (16-byte aligned) by the per-dimension table
-GX_DEV size_t lds_sampler_bytes(int n_perm, int dims) { return (((size_t)n_perm * 2 + 15) & ~(size_t)15) + (size_t)dims * 16; }
+GX_DEV size_t lds_sampler_bytes(int n_perm, int dims) { return (((size_t)n_perm * 2 + 15) & ~(size_t)15) + (size_t)dims * 32; }
 GX_DEV LdsSampler lds_sampler_fill(const DSamplerTables &t, int dims, int n_perm, int *smem, int tid, int nthreads) {
     LdsSampler l;
     l.perms = nullptr; l.tab = nullptr; l.dims = 0;
@@ -186,7 +208,13 @@ GX_DEV LdsSampler lds_sampler_fill(const DSamplerTables &t, int dims, int n_perm
     const int nw = (n_perm + 1) / 2;
     for (int i = tid; i < nw; i += nthreads) pw[i] = gp[i];
     lds_u4 *tb = (lds_u4 *)((__attribute__((address_space(3))) char *)smem + (((size_t)n_perm * 2 + 15) & ~(size_t)15));
-    for (int d = tid; d < dims; d += nthreads) { u4v v; v.x = (uint32_t)t.primes[d]; v.y = t.prime_magic[2 * d]; v.z = t.prime_magic[2 * d + 1]; v.w = (uint32_t)t.prime_sums[d]; tb[d] = v; }
+    for (int d = tid; d < dims; d += nthreads) {
+        const DimInfo q = GlobalTab{t}.dim(d);
+        u4v v, w;
+        v.x = q.base; v.y = q.M; v.z = q.s; v.w = q.off;
+        w.x = __float_as_uint(q.invBase); w.y = __float_as_uint(q.tail); w.z = 0; w.w = 0;
+        tb[2 * d] = v; tb[2 * d + 1] = w;
+    }
     l.perms = (lds_u16c *)smem; l.tab = (lds_u4c *)tb; l.dims = dims;
     return l;
 }

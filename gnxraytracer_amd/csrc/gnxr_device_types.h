@@ -108,7 +108,7 @@ struct DLight {
 struct DHalton {
     int32_t base_scale[2], base_exp[2];
     int32_t stride, mult_inv[2];
-    int32_t _pad;
+    int32_t base32_max;   // radical inverses of bases <= this keep reversedDigits in 32 bits: base * (largest sample index in use) < 2^32 (0: never)
 };
 
 struct DCamera {
