@@ -175,6 +175,42 @@ GX_DEV uint32_t halton_pixel_offset(const DHalton &h, int px, int py) {
     return (uint32_t)(offset % (uint64_t)h.stride);
 }
 
+// The radical inverses as real (non-inlined) functions: a path vertex draws seven to nine values from five call sites, and every inlined
+// copy carries the LDS / global and 32- / 64-bit variants of the unrolled digit loop -- tens of KB of code per shade kernel, more than the
+// instruction cache holds.  GX_HALTON_CALLS = 0 inlines them again.
+#ifndef GX_HALTON_CALLS
+#define GX_HALTON_CALLS 1
+#endif
+#if GX_HALTON_CALLS
+#define GX_NOINLINE_DEV static __device__ __attribute__((noinline))
+GX_NOINLINE_DEV float2 halton_pair_lds_call(lds_u16c *perms, lds_u4c *tab, int base32_max, uint32_t index, int d) {
+    LdsSampler l; l.perms = perms; l.tab = tab; l.dims = 0;
+    DHalton h; h.base32_max = base32_max;
+    float u0, u1;
+    halton_sample_pair_t(LdsTab{l}, h, index, d, d + 1, &u0, &u1);
+    return make_float2(u0, u1);
+}
+GX_NOINLINE_DEV float halton_one_lds_call(lds_u16c *perms, lds_u4c *tab, int base_scale1, int base32_max, uint32_t index, int d) {
+    LdsSampler l; l.perms = perms; l.tab = tab; l.dims = 0;
+    DHalton h; h.base_scale[1] = base_scale1; h.base_exp[0] = 0; h.base32_max = base32_max;
+    return halton_sample_t(LdsTab{l}, h, index, d);   // d >= 1
+}
+GX_NOINLINE_DEV float2 halton_pair_global_call(const uint16_t *perms, const int32_t *primes, const int32_t *prime_sums, const uint32_t *prime_magic, int base_exp0, int base_scale1,
+                                               int base32_max, uint32_t index, int d) {
+    DSamplerTables t; t.perms = perms; t.primes = primes; t.prime_sums = prime_sums; t.prime_magic = prime_magic;
+    t.h.base_exp[0] = base_exp0; t.h.base_scale[1] = base_scale1; t.h.base32_max = base32_max;
+    float u0, u1;
+    halton_sample_pair(t, index, d, &u0, &u1);
+    return make_float2(u0, u1);
+}
+GX_NOINLINE_DEV float halton_one_global_call(const uint16_t *perms, const int32_t *primes, const int32_t *prime_sums, const uint32_t *prime_magic, int base_exp0, int base_scale1,
+                                             int base32_max, uint32_t index, int d) {
+    DSamplerTables t; t.perms = perms; t.primes = primes; t.prime_sums = prime_sums; t.prime_magic = prime_magic;
+    t.h.base_exp[0] = base_exp0; t.h.base_scale[1] = base_scale1; t.h.base32_max = base32_max;
+    return halton_sample(t, index, d);
+}
+#endif
+
 // GlobalSampler::Get1D / Get2D view of one pixel sample, core/Sampler.cpp:162-179
 struct SampleStream {
     const DSamplerTables &t;
@@ -185,14 +221,25 @@ struct SampleStream {
     GX_DEV SampleStream(const DSamplerTables &t, uint32_t index, int dim, const LdsSampler &l) : t(t), index(index), dim(dim), lds(l) {}
     GX_DEV float get1d() {
         const int d = dim++;
+#if GX_HALTON_CALLS
+        if (d >= 1 && d < lds.dims) return halton_one_lds_call(lds.perms, lds.tab, t.h.base_scale[1], t.h.base32_max, index, d);
+        return halton_one_global_call(t.perms, t.primes, t.prime_sums, t.prime_magic, t.h.base_exp[0], t.h.base_scale[1], t.h.base32_max, index, d);
+#else
         if (d >= 1 && d < lds.dims) return halton_sample_t(LdsTab{lds}, t.h, index, d);
         return halton_sample(t, index, d);
+#endif
     }
     GX_DEV void get2d(float *u0, float *u1) {
         const int d = dim;
         dim += 2;
+#if GX_HALTON_CALLS
+        const float2 r = (d >= 2 && d + 1 < lds.dims) ? halton_pair_lds_call(lds.perms, lds.tab, t.h.base32_max, index, d)
+                                                      : halton_pair_global_call(t.perms, t.primes, t.prime_sums, t.prime_magic, t.h.base_exp[0], t.h.base_scale[1], t.h.base32_max, index, d);
+        *u0 = r.x; *u1 = r.y;
+#else
         if (d >= 2 && d + 1 < lds.dims) { halton_sample_pair_t(LdsTab{lds}, t.h, index, d, d + 1, u0, u1); return; }
         halton_sample_pair(t, index, d, u0, u1);
+#endif
     }
 };
 // a block's LDS copy of the first `dims` dimensions: perms[0 .. prime_sums[dims]) followed (16-byte aligned) by the per-dimension table
