@@ -11,7 +11,9 @@ The mesh is the seeded SYNTHETIC stand-in for the reference's dragon.3d, which i
 (.MISSING_LARGE_BLOBS) -- numbers are not comparable with anyone else's "dragon".
 
 A step = one pass of the hot path over one batch: `--spp-per-step` (default 128) consecutive Halton samples of every pixel.
-The default --steps 8 renders the full 1024 spp image, so `wall_to_1024spp_s` is measured, not extrapolated.
+The default --steps 8 renders the full 1024 spp image, so `wall_to_1024spp_s` is measured, not extrapolated.  The steps of a
+contiguous sample range are submitted as one library call; the library renders them pass by pass with two passes in flight
+(the thin late bounces of a pass share kernel launches with the first bounces of the next).
 
 --gpus N > 1: one rank per GPU.  When no launcher has set WORLD_SIZE, bench.py starts its own ranks
 (`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process, before anything touches the GPU),
@@ -44,7 +46,7 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--spp-per-step", type=int, default=128,
-                    help="samples of every pixel rendered by one step = one pass; 128 at 1080p keeps 265 M paths (47 GB of the 288 GB) in flight")
+                    help="samples of every pixel rendered by one step = one pass; 128 at 1080p is 265 M paths, and two passes are in flight (118 GB of the 288 GB)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=1024, help="HaltonSampler samplesPerPixel")
@@ -348,19 +350,29 @@ def main():
     # pixel are rendered inside the timed region either way.
     fuse = args.fuse_steps if args.fuse_steps > 0 else world
 
-    def step(i, g=1):
-        """steps i .. i+g-1 (g may shrink at the end of the Halton sample range); returns (stats, steps done)"""
-        s0 = (i * sps) % args.spp
-        s1 = min(s0 + g * sps, args.spp)
-        done = max(1, (s1 - s0 + sps - 1) // sps)
-        st = integ.RenderDevice(scene, out.data_ptr(), W, H, args.spp, stream=stream, spp_begin=s0, spp_end=s1,
-                                samples_per_pass=s1 - s0, **shard)
-        acc.add_(out)
-        return st, done
+    def run_steps(i0, nsteps):
+        """steps i0 .. i0+nsteps-1 = samples [i0*sps, (i0+nsteps)*sps) of every pixel (mod the Halton range --spp), submitted as ONE library
+        call per contiguous sample range with samples_per_pass = fuse x sps: the library renders a call's passes two at a time -- the thin
+        late bounces of one pass share launches with the camera rays and first bounces of the next (csrc/api.hip, pipelined path loop).
+        Returns the summed stats."""
+        agg = {}
+        i = i0
+        while i < i0 + nsteps:
+            s0 = (i * sps) % args.spp
+            m = min(i0 + nsteps - i, max(1, (args.spp - s0) // sps))   # steps up to the end of the Halton sample range
+            s1 = min(s0 + m * sps, args.spp)
+            st = integ.RenderDevice(scene, out.data_ptr(), W, H, args.spp, stream=stream, spp_begin=s0, spp_end=s1,
+                                    samples_per_pass=min(fuse * sps, s1 - s0), **shard)
+            acc.add_(out)
+            for k_, v_ in st.items():
+                if isinstance(v_, (int, float)):
+                    agg[k_] = agg.get(k_, 0) + v_
+            i += m
+        return agg
 
     note(f"scene ready in {scene_setup_s:.2f} s; {args.warmup} warm-up + {args.steps} timed steps of {sps} spp")
-    for i in range(args.warmup):
-        step(i, fuse)
+    if args.warmup > 0:
+        run_steps(0, args.warmup)
     acc.zero_()
     if not args.no_kernel_timing:
         gx.lib().gnxr_set_profiling(1)
@@ -375,12 +387,9 @@ def main():
                launches_nee=0, rays_closest_nee=0, camera_samples=0, kernel_launches=0, media_segments=0)
     sync()
     t0 = time.perf_counter()
-    i = 0
-    while i < args.steps:
-        st, done = step(i, min(fuse, args.steps - i))
-        i += done
-        for k in tot:
-            tot[k] += st[k]
+    st = run_steps(0, args.steps)
+    for k in tot:
+        tot[k] += st[k]
     # final FrameBuffer gather: each rank owns rows y with y % world == rank (one RCCL gather, timed)
     if world > 1:
         from gnxraytracer_amd.distributed import gather_framebuffer
@@ -439,7 +448,8 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": wl, "spp_per_step": sps, "steps_per_pass": fuse, "spp_rendered": spp_done, "spp_timed": spp_timed,
+        "config": {"workload": wl, "spp_per_step": sps, "steps_per_pass": fuse, "passes_in_flight": 1 if args.workload == "cfg5" else 2,
+                   "submission": "one library call per contiguous sample range; the library keeps two passes in flight", "spp_rendered": spp_done, "spp_timed": spp_timed,
                    "sharding": f"rows y % {world} == rank" if world > 1 else "none",
                    "gather": "RCCL gather of row shards to rank 0 (in timed region)" if world > 1 else "n/a",
                    "world_size": dist.get_world_size() if world > 1 else 1, "backend": (backend if world > 1 else "none"),

@@ -593,10 +593,19 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) target = std::max<long long>(target, std::min<long long>(256ll << 20, (long long)(free_b / 4 / 230)));
         if (volpath) target = std::min<long long>(target, 64ll << 20);   // + 8 float4 of VolPath state per path
         if (whitted) target = (4ll << 20) / std::max(1, n_records / 4);
+        if (!whitted && !volpath && (getenv("GNXR_PIPELINE") ? atoi(getenv("GNXR_PIPELINE")) != 0 : true) && target / r.npix < nsamples) target /= 2;   // two passes in flight
         k = (int)std::max<long long>(1, std::min<long long>(nsamples, target / r.npix));
     }
     k = std::min(k, nsamples);
-    size_t cap = (size_t)r.npix * k;
+    // PathIntegrator: two passes in flight at once, each in its own half of the state arrays (the pipelined loop below).  Halving the
+    // pass size instead of doubling the state was measured and loses: thick launches of half the size are ~3 % less efficient, more than
+    // the merged tails give back.
+    static const bool pipeline = getenv("GNXR_PIPELINE") ? atoi(getenv("GNXR_PIPELINE")) != 0 : true;   // experiment switch: 0 = one pass at a time
+    const bool path_int = !whitted && !volpath;
+    const int in_flight = (path_int && pipeline && k < nsamples) ? 2 : 1;
+    const int kh = k;
+    const size_t half = (size_t)r.npix * kh;
+    size_t cap = (size_t)in_flight * half;
     // k_trace's work cursor is 32-bit unsigned: continuation rays + two NEE items per record; record slots are `record * cap + path`
     {
         const unsigned long long recs = whitted ? (unsigned long long)std::max(1, n_records) : 1ull;
@@ -629,7 +638,7 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
     }
     if ((rc = s->accum.alloc(r.npix)) != GNXR_OK) return rc;
     const int max_tiles = (int)((cap + kCompactTile - 1) / kCompactTile);
-    if ((rc = s->tile_counts.alloc((size_t)4 * max_tiles)) != GNXR_OK) return rc;
+    if ((rc = s->tile_counts.alloc((size_t)5 * max_tiles)) != GNXR_OK) return rc;
     PathArrays pa;
     pa.ray_o = s->ray_o.p; pa.ray_d = s->ray_d.p; pa.beta = s->beta.p; pa.L = s->L.p; pa.meta = s->meta.p; pa.hit = s->hit.p; pa.pflags = s->pflags.p; pa.pclass = s->pclass.p;
     pa.sh_o = s->sh_o.p; pa.sh_d = s->sh_d.p; pa.sh_X = s->sh_X.p; pa.mis_o = s->mis_o.p; pa.mis_d = s->mis_d.p; pa.mis_Y = s->mis_Y.p; pa.nbeta = s->nbeta.p; pa.nee_vis = s->nee_vis.p;
@@ -673,6 +682,215 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
     }
     KernelTimer timer;
     Counters *dctr = s->counters.p;
+    auto launch_trace = [&](TraceWork w, int n_sh, int n_mis) {
+        long long total = (long long)w.n_closest + 2ll * w.n_nee;
+        if (total <= 0) return;
+        w.order = nullptr;
+        static const int sort_rays = getenv("GNXR_SORT_RAYS") ? atoi(getenv("GNXR_SORT_RAYS")) : 0;   // experiment: bin the rays of a launch by kind / octant / origin cell
+        if (sort_rays > 0 && total >= (1 << 16)) {
+            if (s->sort_keys_a.alloc(3 * cap) || s->sort_keys_b.alloc(3 * cap) || s->sort_items_a.alloc(3 * cap) || s->sort_items_b.alloc(3 * cap)) return;
+            const Box3 &wb = s->cs.world_bound;
+            const float3 lo = make_float3(wb.lo.x, wb.lo.y, wb.lo.z);
+            const float3 scale = make_float3(32.f / std::max(1e-20f, wb.hi.x - wb.lo.x), 32.f / std::max(1e-20f, wb.hi.y - wb.lo.y), 32.f / std::max(1e-20f, wb.hi.z - wb.lo.z));
+            if (timing) timer.begin(1, stream);
+            hipLaunchKernelGGL(k_trace_keys, dim3(grid_for(total)), dim3(kBlock), 0, stream, pa, w, lo, scale, s->sort_keys_a.p, s->sort_items_a.p);
+            size_t bytes = 0;
+            const int b0 = sort_rays >= 2 ? 0 : 15, b1 = kTraceKeyBits;   // 1: kind + octant only; 2: + origin cell
+            (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, s->sort_keys_a.p, s->sort_keys_b.p, s->sort_items_a.p, s->sort_items_b.p, (int)total, b0, b1, stream);
+            if (s->sort_tmp.alloc(bytes)) return;
+            (void)hipcub::DeviceRadixSort::SortPairs(s->sort_tmp.p, bytes, s->sort_keys_a.p, s->sort_keys_b.p, s->sort_items_a.p, s->sort_items_b.p, (int)total, b0, b1, stream);
+            if (timing) timer.end(stream);
+            w.order = s->sort_items_b.p;
+        }
+        (void)hipMemsetAsync(&dctr->cursor, 0, sizeof(unsigned int), stream);
+        // LDS traversal stack: one column per lane, depth from the BVH (binary walk: depth + 1; 4-wide walk: stack4_need)
+        const bool wide = s->wide_ok && !counting;
+        const int entries = wide ? s->cs.stack4_need + 1 : s->cs.bvh_max_depth + 2;
+        // 5 blocks of 4 waves per CU is what k_trace4's 96 VGPRs allow (5 waves per SIMD); the LDS of a block -- stack levels plus, for
+        // the 4-wide kernel, the set-up ray records and the node cache -- must fit 5 times into the 160 KB; deeper levels spill to
+        // global memory (LDS levels are worth more than a bigger node cache: profiles/README.md, r02 A/B table)
+        const int per_cu = g_trace_blocks_per_cu;
+        // besides the stack: the set-up ray records, the top-of-tree node cache and the order table
+        const size_t fixed_b = wide ? (size_t)(kRayRecDwords + (spheres ? 1 : 0)) * kRqStride * sizeof(int) + (size_t)kTopCache * 128 + 128 : 0;
+        static const int lds_levels_cap = getenv("GNXR_TRACE_LDS_LEVELS") ? std::max(2, atoi(getenv("GNXR_TRACE_LDS_LEVELS"))) : 64;   // tuning knob
+        const int lds_entries = std::min(std::min(entries, lds_levels_cap), std::max(2, (int)(((160 * 1024) / per_cu - 1024 - fixed_b) / (kBlock * sizeof(int)))));
+        const bool spill_needed = entries > lds_entries;
+        const size_t lds = (size_t)lds_entries * kBlock * sizeof(int) + fixed_b;
+        const int n_top = (int)std::min<size_t>(kTopCache, s->cs.root4 >= 0 ? s->cs.nodes4.size() : 0);
+        // persistent waves: enough blocks to fill the chip, never more than the work needs
+        int blocks = (int)std::min<long long>((long long)g_num_cus * per_cu, (total + kBlock - 1) / kBlock);
+        if (timing) timer.begin(0, stream);
+        // rays per atomic: kTraceChunk for big launches; for thin ones (late bounces) small enough that every wave gets a chunk --
+        // the number of atomics stays <= the number of waves, well under the ~88/us a single address sustains
+        const long long waves = (long long)blocks * (kBlock / 64);
+        static const int chunk_max = getenv("GNXR_TRACE_CHUNK") ? std::max(64, atoi(getenv("GNXR_TRACE_CHUNK")) / 64 * 64) : kTraceChunk;   // tuning knob
+        const int chunk = (int)std::min<long long>(chunk_max, std::max<long long>(64, ((total + waves - 1) / waves + 63) / 64 * 64));
+#define GX_TRACE(C, W, S) hipLaunchKernelGGL((k_trace<C, W, S>), dim3(blocks), dim3(kBlock), lds, stream, sc, pa, w, &dctr->cursor, dctr, lds_entries, s->trace_spill.p, chunk)
+#define GX_TRACE4(C, S, P) hipLaunchKernelGGL((k_trace4<C, S, P>), dim3(blocks), dim3(kBlock), lds, stream, sc, pa, w, &dctr->cursor, dctr, lds_entries, s->trace_spill.p, chunk, n_top)
+#define GX_TRACE4_CS(C, S) do { if (spill_needed) GX_TRACE4(C, S, true); else GX_TRACE4(C, S, false); } while (0)
+        if (wide) {   // the 4-wide walk (trace4_kernel.hip.h); count_wide: its counting variant
+            if (spheres) { if (count_wide) GX_TRACE4_CS(true, true); else GX_TRACE4_CS(false, true); }
+            else { if (count_wide) GX_TRACE4_CS(true, false); else GX_TRACE4_CS(false, false); }
+        } else {      // the reference's binary tree: counting runs on BVHAccel's own walk, and scenes the 4-wide encoding cannot hold
+            const bool cnt = counting || count_wide;
+            if (spheres) { if (cnt) GX_TRACE(true, false, true); else GX_TRACE(false, false, true); }
+            else { if (cnt) GX_TRACE(true, false, false); else GX_TRACE(false, false, false); }
+        }
+#undef GX_TRACE4_CS
+#undef GX_TRACE4
+#undef GX_TRACE
+        if (timing) timer.end(stream);
+        rays_closest += (unsigned long long)w.n_closest + (unsigned long long)n_mis;
+        rays_any += (unsigned long long)n_sh;
+        rays_mis += (unsigned long long)n_mis;
+        ++launches;
+    };
+    // stream compaction (compact_kernel.hip.h): count -> scan -> scatter, no global atomics
+    auto compact = [&](int mode, const int *qin, int nin, const unsigned char *keys, int nout, int nscatter, unsigned int *totals, int *o0, int *o1, int *o2, int *o3 = nullptr, int split = 0) {
+        int tiles = (nin + kCompactTile - 1) / kCompactTile;
+        int g = std::min(tiles, g_num_cus * 8);
+        // FLAGS with a fifth count: the paths that continue AND live in the lower half of the state arrays (slot < split): how many paths of
+        // each of the two sub-passes in flight are left
+        if (mode == COMPACT_FLAGS && nout == 5) hipLaunchKernelGGL((k_compact_count<COMPACT_FLAGS, 5>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles, (const int *)nullptr, (const unsigned char *)nullptr, (unsigned char *)nullptr, split);
+        else if (mode == COMPACT_FLAGS) hipLaunchKernelGGL((k_compact_count<COMPACT_FLAGS, 4>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles);
+        else if (mode == COMPACT_HITCLASS) {   // class of the triangle a path hit, looked up and left in `keys` for the scatter pass
+            if (nout == 4) hipLaunchKernelGGL((k_compact_count<COMPACT_HITCLASS, 4>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles, (const int *)s->hit.p, (const unsigned char *)s->tri_class.p, s->pclass.p);
+            else hipLaunchKernelGGL((k_compact_count<COMPACT_HITCLASS, 3>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles, (const int *)s->hit.p, (const unsigned char *)s->tri_class.p, s->pclass.p);
+            mode = COMPACT_CLASS;
+        }
+        else if (nout == 4) hipLaunchKernelGGL((k_compact_count<COMPACT_CLASS, 4>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles);
+        else hipLaunchKernelGGL((k_compact_count<COMPACT_CLASS, 3>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles);
+        hipLaunchKernelGGL(k_compact_scan, dim3(nout), dim3(1024), 0, stream, s->tile_counts.p, tiles, totals);
+        if (mode == COMPACT_FLAGS && nscatter == 3) hipLaunchKernelGGL((k_compact_scatter<COMPACT_FLAGS, 3>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, (const unsigned int *)s->tile_counts.p, tiles, o0, o1, o2);
+        else if (mode == COMPACT_FLAGS) hipLaunchKernelGGL((k_compact_scatter<COMPACT_FLAGS, 2>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, (const unsigned int *)s->tile_counts.p, tiles, o0, o1, o2);
+        else if (nscatter == 4) hipLaunchKernelGGL((k_compact_scatter<COMPACT_CLASS, 4>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, (const unsigned int *)s->tile_counts.p, tiles, o0, o1, o2, o3);
+        else hipLaunchKernelGGL((k_compact_scatter<COMPACT_CLASS, 3>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, (const unsigned int *)s->tile_counts.p, tiles, o0, o1, o2);
+        launches += 3;
+    };
+    // ---- PathIntegrator: one vertex of every live path per iteration, two sub-passes in flight.
+    // shade_stage: PathIntegrator::Li at the vertices the last trace found (class binning, one k_shade per class, queue compaction), then
+    // the counts of what they spawned come back to the host.
+    auto shade_stage = [&](const int *q_in, int n, int *q_out, int split) -> int {
+    if (timing) timer.begin(2, stream);
+    // bin the paths by the shade specialisation of the material they hit (pclass written by k_trace)
+    const int n_classes = (class_mask & 8) ? 4 : 3;   // image-textured materials have a shade queue of their own
+    compact(COMPACT_HITCLASS, q_in, n, s->pclass.p, n_classes, n_classes, &dctr->q_class[0], s->queue_c0.p, s->queue_c1.p, s->queue_c2.p, s->queue_c3.p);
+    {
+        int *qc[4] = {s->queue_c0.p, s->queue_c1.p, s->queue_c2.p, s->queue_c3.p};
+        dim3 g(grid_for(n)), b(kBlock);
+        // the Halton tables of the first dimensions go to LDS (device_sampler.h LdsSampler): 64 dimensions (the camera sample + 6 path vertices:
+        // 18.8 KB per block; deeper vertices read global memory).  A/B on cfg 3: shade -3 % at 64 / 88 dimensions, +4 % at 112 (occupancy)
+        static const int shade_lds_dims = getenv("GNXR_SHADE_LDS_DIMS") ? std::max(0, std::min(128, atoi(getenv("GNXR_SHADE_LDS_DIMS")))) : 64;   // tuning knob
+        const int sdims = std::min<int>(shade_lds_dims, (int)s->cs.prime_sums.size() - 1);
+        const int snperm = sdims > 0 ? s->cs.prime_sums[sdims] : 0;
+        // + the scene's material and light tables when they are small (k_shade: dependent gathers along the BSDF code become LDS reads)
+        static const bool shade_lds_tabs = getenv("GNXR_SHADE_LDS_TABLES") ? atoi(getenv("GNXR_SHADE_LDS_TABLES")) != 0 : true;   // experiment switch
+        const int lmats = (shade_lds_tabs && s->cs.materials.size() <= 12) ? (int)s->cs.materials.size() : 0;
+        const int llights = (shade_lds_tabs && nL > 0 && nL <= 16) ? nL : 0;
+        const size_t slds = (sdims > 0 ? ((((size_t)snperm * 2 + 15) & ~(size_t)15) + (size_t)sdims * 32) : 0) + (size_t)lmats * sizeof(DMaterial) + (size_t)llights * sizeof(DLight);
+#define GX_SHADE(LMV, LTV, C)                                                                                                                        \
+    do {                                                                                                                                             \
+if (spheres) hipLaunchKernelGGL((k_shade<LMV, LTV, true>), g, b, slds, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C], sdims, snperm, lmats, llights); \
+else hipLaunchKernelGGL((k_shade<LMV, LTV, false>), g, b, slds, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C], sdims, snperm, lmats, llights);       \
+    } while (0)
+#define GX_SHADE_TEX(LTV)                                                                                                                            \
+    do {                                                                                                                                             \
+if (spheres) hipLaunchKernelGGL((k_shade<LM_ALL, LTV, true, true>), g, b, slds, stream, sc, r, pa, (const int *)qc[3], (const unsigned int *)&dctr->q_class[3], sdims, snperm, lmats, llights); \
+else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, slds, stream, sc, r, pa, (const int *)qc[3], (const unsigned int *)&dctr->q_class[3], sdims, snperm, lmats, llights);       \
+    } while (0)
+        if (area_only) {
+            GX_SHADE(LM_DIFFUSE, LT_AREA, 0);
+            if (class_mask & 2) GX_SHADE(LM_GLOSSY, LT_AREA, 1);
+            if (class_mask & 4) GX_SHADE(LM_ALL, LT_AREA, 2);
+            if (class_mask & 8) GX_SHADE_TEX(LT_AREA);
+        } else if (area_env_only && !spheres && !(class_mask & 8)) {
+            // BASELINE config 4's light set (area lights + one InfiniteAreaLight): without the delta-light and sky-box code
+#define GX_SHADE_AE(LMV, C) hipLaunchKernelGGL((k_shade<LMV, LT_AREA | LT_ENV, false>), g, b, slds, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C], sdims, snperm, lmats, llights)
+            GX_SHADE_AE(LM_DIFFUSE, 0);
+            if (class_mask & 2) GX_SHADE_AE(LM_GLOSSY, 1);
+            if (class_mask & 4) GX_SHADE_AE(LM_ALL, 2);
+#undef GX_SHADE_AE
+        } else {
+            GX_SHADE(LM_DIFFUSE, LT_ALL, 0);
+            if (class_mask & 2) GX_SHADE(LM_GLOSSY, LT_ALL, 1);
+            if (class_mask & 4) GX_SHADE(LM_ALL, LT_ALL, 2);
+            if (class_mask & 8) GX_SHADE_TEX(LT_ALL);
+        }
+#undef GX_SHADE
+        launches += 1 + ((class_mask & 2) ? 1 : 0) + ((class_mask & 4) ? 1 : 0) + ((class_mask & 8) ? 1 : 0);
+    }
+    // next-vertex queue + NEE queue from the per-path flags; totals also count shadow and MIS rays
+    compact(COMPACT_FLAGS, q_in, n, s->pflags.p, 5, 2, &dctr->q_next, q_out, s->queue_nee.p, nullptr, nullptr, split);
+    if (timing) timer.end(stream);
+    if (hipMemcpyAsync(s->h_counters, dctr, sizeof(Counters), hipMemcpyDeviceToHost, stream) != hipSuccess) return GNXR_ERR_RUNTIME;
+    if (hipStreamSynchronize(stream) != hipSuccess) return GNXR_ERR_RUNTIME;
+        return GNXR_OK;
+    };
+    if (!whitted && !volpath) {
+        // A pass's late bounces are thin (Russian roulette, escapes): a few hundred thousand rays cannot fill 327 k lanes, and a launch
+        // then costs the latency of its longest rays (~1 ms per bounce: 6 ms of an otherwise 60 ms pass).  So the samples of a call are
+        // cut into sub-passes of half the pass size, each in its own half of the state arrays, and a new sub-pass starts (k_raygen +
+        // k_queue_merge) when the one in flight has done `cut` vertices: its camera rays and first bounces share launches with the tail
+        // of the older one.  Queues hold slots of both halves in ascending order; results per path do not depend on who shares a
+        // launch, and k_resolve runs per sub-pass in sample order, so images are unchanged bit for bit.
+        struct Sub { int s0, kk, n_paths; size_t base; long long alive; int iters; };
+        std::vector<Sub> subs;
+        for (int s0 = p.spp_begin, i = 0; s0 < p.spp_end; s0 += kh, ++i) {
+            const int kk = std::min(kh, p.spp_end - s0);
+            subs.push_back(Sub{s0, kk, r.npix * kk, in_flight == 2 ? (size_t)(i & 1) * half : 0, 0, 0});
+        }
+        static const int cut_env = getenv("GNXR_PIPE_CUT") ? atoi(getenv("GNXR_PIPE_CUT")) : -1;   // tuning knob
+        const int cut = cut_env >= 0 ? cut_env : (p.max_depth + 2) / 2;
+        auto pa_at = [&](size_t base) {
+            PathArrays q = pa;
+            q.ray_o += base; q.ray_d += base; q.beta += base; q.L += base; q.meta += base; q.hit += base; q.pflags += base; q.pclass += base;
+            q.sh_o += base; q.sh_d += base; q.sh_X += base; q.mis_o += base; q.mis_d += base; q.mis_Y += base; q.nbeta += base; q.nee_vis += base;
+            return q;
+        };
+        int *qbuf[2] = {s->queue_a.p, s->queue_b.p};
+        int in_idx = 0, n = 0;
+        size_t oldest = 0, next = 0;
+        int guard = 0;
+        while (oldest < subs.size()) {
+            // A. shade what the last trace found; survivors go to the buffer that does not hold the input queue
+            int n_next = 0, n_nee = 0, n_sh = 0, n_mis = 0, n_low = 0, out_idx = 1 - in_idx;
+            if (n > 0) {
+                if ((rc = shade_stage(qbuf[in_idx], n, qbuf[out_idx], (int)half)) != GNXR_OK) { set_error("HIP runtime error in the path loop: %s", hipGetErrorString(hipGetLastError())); return rc; }
+                n_next = (int)s->h_counters->q_next; n_nee = (int)s->h_counters->q_nee;
+                n_sh = (int)s->h_counters->q_shadow; n_mis = (int)s->h_counters->q_mis; n_low = (int)s->h_counters->q_low;
+                for (size_t i = oldest; i < next; ++i) { subs[i].alive = subs[i].base == 0 ? n_low : n_next - n_low; subs[i].iters++; }
+            }
+            // B. start the next sub-pass when its half is free and the one in flight has reached its thin bounces
+            int trace_idx = out_idx, n_trace = n_next;
+            if (next < subs.size() && next - oldest < (size_t)in_flight && (next == oldest || subs[oldest].iters >= cut)) {
+                Sub &nw = subs[next];
+                hipLaunchKernelGGL(k_raygen, dim3(grid_for(nw.n_paths)), dim3(kBlock), 0, stream, sc, r, pa_at(nw.base), nw.n_paths, nw.s0);
+                // survivors of the older sub-pass + every slot of the new one, ascending: into the buffer the shaded queue came from
+                hipLaunchKernelGGL(k_queue_merge, dim3(grid_for((long long)n_next + nw.n_paths)), dim3(kBlock), 0, stream, (const int *)qbuf[out_idx], n_next, (int)nw.base, nw.n_paths,
+                                   nw.base > 0 ? 1 : 0, qbuf[in_idx]);
+                launches += 2;
+                trace_idx = in_idx; n_trace = n_next + nw.n_paths;
+                nw.alive = nw.n_paths; nw.iters = 0;
+                ++next;
+            }
+            // C. continuation rays (and new camera rays), shadow and MIS rays of the vertices just shaded; then their light estimates
+            launch_trace(TraceWork{qbuf[trace_idx], n_trace, s->queue_nee.p, n_nee, nullptr, reinterpret_cast<unsigned char *>(s->nee_vis.p)}, n_sh, n_mis);
+            if (n_nee > 0) {
+                if (timing) timer.begin(1, stream);
+                hipLaunchKernelGGL(k_nee_combine, dim3(grid_for(n_nee)), dim3(kBlock), 0, stream, pa, (const int *)s->queue_nee.p, n_nee, reinterpret_cast<const unsigned char *>(s->nee_vis.p));
+                if (timing) timer.end(stream);
+                ++launches;
+            }
+            // D. a sub-pass none of whose paths continues is complete once the estimates above are added: colObj += Li in sample order
+            while (oldest < next && subs[oldest].alive == 0) {
+                const Sub &d = subs[oldest];
+                hipLaunchKernelGGL(k_resolve, dim3(grid_for(r.npix)), dim3(kBlock), 0, stream, pa_at(d.base), s->accum.p, r.npix, d.kk);
+                ++launches; ++passes; ++oldest;
+            }
+            in_idx = trace_idx; n = n_trace;
+            if (++guard > (1 << 16)) { set_error("path loop did not terminate"); return GNXR_ERR_INVALID; }
+        }
+    } else
     for (int s0 = p.spp_begin; s0 < p.spp_end; s0 += k) {
         int kk = std::min(k, p.spp_end - s0);
         int n_paths = r.npix * kk;
@@ -682,88 +900,6 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
         const int *q_in = nullptr;            // paths alive at this vertex (nullptr == identity), ascending
         int *q_cur = s->queue_a.p, *q_other = s->queue_b.p;
         int guard = 0;
-        auto launch_trace = [&](TraceWork w, int n_sh, int n_mis) {
-            long long total = (long long)w.n_closest + 2ll * w.n_nee;
-            if (total <= 0) return;
-            w.order = nullptr;
-            static const int sort_rays = getenv("GNXR_SORT_RAYS") ? atoi(getenv("GNXR_SORT_RAYS")) : 0;   // experiment: bin the rays of a launch by kind / octant / origin cell
-            if (sort_rays > 0 && total >= (1 << 16)) {
-                if (s->sort_keys_a.alloc(3 * cap) || s->sort_keys_b.alloc(3 * cap) || s->sort_items_a.alloc(3 * cap) || s->sort_items_b.alloc(3 * cap)) return;
-                const Box3 &wb = s->cs.world_bound;
-                const float3 lo = make_float3(wb.lo.x, wb.lo.y, wb.lo.z);
-                const float3 scale = make_float3(32.f / std::max(1e-20f, wb.hi.x - wb.lo.x), 32.f / std::max(1e-20f, wb.hi.y - wb.lo.y), 32.f / std::max(1e-20f, wb.hi.z - wb.lo.z));
-                if (timing) timer.begin(1, stream);
-                hipLaunchKernelGGL(k_trace_keys, dim3(grid_for(total)), dim3(kBlock), 0, stream, pa, w, lo, scale, s->sort_keys_a.p, s->sort_items_a.p);
-                size_t bytes = 0;
-                const int b0 = sort_rays >= 2 ? 0 : 15, b1 = kTraceKeyBits;   // 1: kind + octant only; 2: + origin cell
-                (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, s->sort_keys_a.p, s->sort_keys_b.p, s->sort_items_a.p, s->sort_items_b.p, (int)total, b0, b1, stream);
-                if (s->sort_tmp.alloc(bytes)) return;
-                (void)hipcub::DeviceRadixSort::SortPairs(s->sort_tmp.p, bytes, s->sort_keys_a.p, s->sort_keys_b.p, s->sort_items_a.p, s->sort_items_b.p, (int)total, b0, b1, stream);
-                if (timing) timer.end(stream);
-                w.order = s->sort_items_b.p;
-            }
-            (void)hipMemsetAsync(&dctr->cursor, 0, sizeof(unsigned int), stream);
-            // LDS traversal stack: one column per lane, depth from the BVH (binary walk: depth + 1; 4-wide walk: stack4_need)
-            const bool wide = s->wide_ok && !counting;
-            const int entries = wide ? s->cs.stack4_need + 1 : s->cs.bvh_max_depth + 2;
-            // 5 blocks of 4 waves per CU is what k_trace4's 96 VGPRs allow (5 waves per SIMD); the LDS of a block -- stack levels plus, for
-            // the 4-wide kernel, the set-up ray records and the node cache -- must fit 5 times into the 160 KB; deeper levels spill to
-            // global memory (LDS levels are worth more than a bigger node cache: profiles/README.md, r02 A/B table)
-            const int per_cu = g_trace_blocks_per_cu;
-            // besides the stack: the set-up ray records, the top-of-tree node cache and the order table
-            const size_t fixed_b = wide ? (size_t)(kRayRecDwords + (spheres ? 1 : 0)) * kRqStride * sizeof(int) + (size_t)kTopCache * 128 + 128 : 0;
-            static const int lds_levels_cap = getenv("GNXR_TRACE_LDS_LEVELS") ? std::max(2, atoi(getenv("GNXR_TRACE_LDS_LEVELS"))) : 64;   // tuning knob
-            const int lds_entries = std::min(std::min(entries, lds_levels_cap), std::max(2, (int)(((160 * 1024) / per_cu - 1024 - fixed_b) / (kBlock * sizeof(int)))));
-            const bool spill_needed = entries > lds_entries;
-            const size_t lds = (size_t)lds_entries * kBlock * sizeof(int) + fixed_b;
-            const int n_top = (int)std::min<size_t>(kTopCache, s->cs.root4 >= 0 ? s->cs.nodes4.size() : 0);
-            // persistent waves: enough blocks to fill the chip, never more than the work needs
-            int blocks = (int)std::min<long long>((long long)g_num_cus * per_cu, (total + kBlock - 1) / kBlock);
-            if (timing) timer.begin(0, stream);
-            // rays per atomic: kTraceChunk for big launches; for thin ones (late bounces) small enough that every wave gets a chunk --
-            // the number of atomics stays <= the number of waves, well under the ~88/us a single address sustains
-            const long long waves = (long long)blocks * (kBlock / 64);
-            static const int chunk_max = getenv("GNXR_TRACE_CHUNK") ? std::max(64, atoi(getenv("GNXR_TRACE_CHUNK")) / 64 * 64) : kTraceChunk;   // tuning knob
-            const int chunk = (int)std::min<long long>(chunk_max, std::max<long long>(64, ((total + waves - 1) / waves + 63) / 64 * 64));
-#define GX_TRACE(C, W, S) hipLaunchKernelGGL((k_trace<C, W, S>), dim3(blocks), dim3(kBlock), lds, stream, sc, pa, w, &dctr->cursor, dctr, lds_entries, s->trace_spill.p, chunk)
-#define GX_TRACE4(C, S, P) hipLaunchKernelGGL((k_trace4<C, S, P>), dim3(blocks), dim3(kBlock), lds, stream, sc, pa, w, &dctr->cursor, dctr, lds_entries, s->trace_spill.p, chunk, n_top)
-#define GX_TRACE4_CS(C, S) do { if (spill_needed) GX_TRACE4(C, S, true); else GX_TRACE4(C, S, false); } while (0)
-            if (wide) {   // the 4-wide walk (trace4_kernel.hip.h); count_wide: its counting variant
-                if (spheres) { if (count_wide) GX_TRACE4_CS(true, true); else GX_TRACE4_CS(false, true); }
-                else { if (count_wide) GX_TRACE4_CS(true, false); else GX_TRACE4_CS(false, false); }
-            } else {      // the reference's binary tree: counting runs on BVHAccel's own walk, and scenes the 4-wide encoding cannot hold
-                const bool cnt = counting || count_wide;
-                if (spheres) { if (cnt) GX_TRACE(true, false, true); else GX_TRACE(false, false, true); }
-                else { if (cnt) GX_TRACE(true, false, false); else GX_TRACE(false, false, false); }
-            }
-#undef GX_TRACE4_CS
-#undef GX_TRACE4
-#undef GX_TRACE
-            if (timing) timer.end(stream);
-            rays_closest += (unsigned long long)w.n_closest + (unsigned long long)n_mis;
-            rays_any += (unsigned long long)n_sh;
-            rays_mis += (unsigned long long)n_mis;
-            ++launches;
-        };
-        // stream compaction (compact_kernel.hip.h): count -> scan -> scatter, no global atomics
-        auto compact = [&](int mode, const int *qin, int nin, const unsigned char *keys, int nout, int nscatter, unsigned int *totals, int *o0, int *o1, int *o2, int *o3 = nullptr) {
-            int tiles = (nin + kCompactTile - 1) / kCompactTile;
-            int g = std::min(tiles, g_num_cus * 8);
-            if (mode == COMPACT_FLAGS) hipLaunchKernelGGL((k_compact_count<COMPACT_FLAGS, 4>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles);
-            else if (mode == COMPACT_HITCLASS) {   // class of the triangle a path hit, looked up and left in `keys` for the scatter pass
-                if (nout == 4) hipLaunchKernelGGL((k_compact_count<COMPACT_HITCLASS, 4>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles, (const int *)s->hit.p, (const unsigned char *)s->tri_class.p, s->pclass.p);
-                else hipLaunchKernelGGL((k_compact_count<COMPACT_HITCLASS, 3>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles, (const int *)s->hit.p, (const unsigned char *)s->tri_class.p, s->pclass.p);
-                mode = COMPACT_CLASS;
-            }
-            else if (nout == 4) hipLaunchKernelGGL((k_compact_count<COMPACT_CLASS, 4>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles);
-            else hipLaunchKernelGGL((k_compact_count<COMPACT_CLASS, 3>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles);
-            hipLaunchKernelGGL(k_compact_scan, dim3(nout), dim3(1024), 0, stream, s->tile_counts.p, tiles, totals);
-            if (mode == COMPACT_FLAGS && nscatter == 3) hipLaunchKernelGGL((k_compact_scatter<COMPACT_FLAGS, 3>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, (const unsigned int *)s->tile_counts.p, tiles, o0, o1, o2);
-            else if (mode == COMPACT_FLAGS) hipLaunchKernelGGL((k_compact_scatter<COMPACT_FLAGS, 2>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, (const unsigned int *)s->tile_counts.p, tiles, o0, o1, o2);
-            else if (nscatter == 4) hipLaunchKernelGGL((k_compact_scatter<COMPACT_CLASS, 4>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, (const unsigned int *)s->tile_counts.p, tiles, o0, o1, o2, o3);
-            else hipLaunchKernelGGL((k_compact_scatter<COMPACT_CLASS, 3>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, (const unsigned int *)s->tile_counts.p, tiles, o0, o1, o2);
-            launches += 3;
-        };
         if (whitted) {
             // depth-first recursion per path (whitted_kernel.hip.h): the path's ray + the previous vertex's shadow rays per round
             hipLaunchKernelGGL(k_whitted_init, dim3(grid_for(n_paths)), dim3(kBlock), 0, stream, pa, wa, n_paths);
@@ -852,74 +988,6 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
                 std::swap(q_cur, q_other);
                 if (++guard > (1 << 20)) { set_error("path loop did not terminate"); return GNXR_ERR_INVALID; }
             }
-        } else launch_trace(TraceWork{nullptr, n, nullptr, 0}, 0, 0);   // camera rays
-        while (n > 0) {
-            if (timing) timer.begin(2, stream);
-            // bin the paths by the shade specialisation of the material they hit (pclass written by k_trace)
-            const int n_classes = (class_mask & 8) ? 4 : 3;   // image-textured materials have a shade queue of their own
-            compact(COMPACT_HITCLASS, q_in, n, s->pclass.p, n_classes, n_classes, &dctr->q_class[0], s->queue_c0.p, s->queue_c1.p, s->queue_c2.p, s->queue_c3.p);
-            {
-                int *qc[4] = {s->queue_c0.p, s->queue_c1.p, s->queue_c2.p, s->queue_c3.p};
-                dim3 g(grid_for(n)), b(kBlock);
-                // the Halton tables of the first dimensions go to LDS (device_sampler.h LdsSampler): 64 dimensions (the camera sample + 6 path vertices:
-                // 18.8 KB per block; deeper vertices read global memory).  A/B on cfg 3: shade -3 % at 64 / 88 dimensions, +4 % at 112 (occupancy)
-                static const int shade_lds_dims = getenv("GNXR_SHADE_LDS_DIMS") ? std::max(0, std::min(128, atoi(getenv("GNXR_SHADE_LDS_DIMS")))) : 64;   // tuning knob
-                const int sdims = std::min<int>(shade_lds_dims, (int)s->cs.prime_sums.size() - 1);
-                const int snperm = sdims > 0 ? s->cs.prime_sums[sdims] : 0;
-                // + the scene's material and light tables when they are small (k_shade: dependent gathers along the BSDF code become LDS reads)
-                static const bool shade_lds_tabs = getenv("GNXR_SHADE_LDS_TABLES") ? atoi(getenv("GNXR_SHADE_LDS_TABLES")) != 0 : true;   // experiment switch
-                const int lmats = (shade_lds_tabs && s->cs.materials.size() <= 12) ? (int)s->cs.materials.size() : 0;
-                const int llights = (shade_lds_tabs && nL > 0 && nL <= 16) ? nL : 0;
-                const size_t slds = (sdims > 0 ? ((((size_t)snperm * 2 + 15) & ~(size_t)15) + (size_t)sdims * 32) : 0) + (size_t)lmats * sizeof(DMaterial) + (size_t)llights * sizeof(DLight);
-#define GX_SHADE(LMV, LTV, C)                                                                                                                        \
-    do {                                                                                                                                             \
-        if (spheres) hipLaunchKernelGGL((k_shade<LMV, LTV, true>), g, b, slds, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C], sdims, snperm, lmats, llights); \
-        else hipLaunchKernelGGL((k_shade<LMV, LTV, false>), g, b, slds, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C], sdims, snperm, lmats, llights);       \
-    } while (0)
-#define GX_SHADE_TEX(LTV)                                                                                                                            \
-    do {                                                                                                                                             \
-        if (spheres) hipLaunchKernelGGL((k_shade<LM_ALL, LTV, true, true>), g, b, slds, stream, sc, r, pa, (const int *)qc[3], (const unsigned int *)&dctr->q_class[3], sdims, snperm, lmats, llights); \
-        else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, slds, stream, sc, r, pa, (const int *)qc[3], (const unsigned int *)&dctr->q_class[3], sdims, snperm, lmats, llights);       \
-    } while (0)
-                if (area_only) {
-                    GX_SHADE(LM_DIFFUSE, LT_AREA, 0);
-                    if (class_mask & 2) GX_SHADE(LM_GLOSSY, LT_AREA, 1);
-                    if (class_mask & 4) GX_SHADE(LM_ALL, LT_AREA, 2);
-                    if (class_mask & 8) GX_SHADE_TEX(LT_AREA);
-                } else if (area_env_only && !spheres && !(class_mask & 8)) {
-                    // BASELINE config 4's light set (area lights + one InfiniteAreaLight): without the delta-light and sky-box code
-#define GX_SHADE_AE(LMV, C) hipLaunchKernelGGL((k_shade<LMV, LT_AREA | LT_ENV, false>), g, b, slds, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C], sdims, snperm, lmats, llights)
-                    GX_SHADE_AE(LM_DIFFUSE, 0);
-                    if (class_mask & 2) GX_SHADE_AE(LM_GLOSSY, 1);
-                    if (class_mask & 4) GX_SHADE_AE(LM_ALL, 2);
-#undef GX_SHADE_AE
-                } else {
-                    GX_SHADE(LM_DIFFUSE, LT_ALL, 0);
-                    if (class_mask & 2) GX_SHADE(LM_GLOSSY, LT_ALL, 1);
-                    if (class_mask & 4) GX_SHADE(LM_ALL, LT_ALL, 2);
-                    if (class_mask & 8) GX_SHADE_TEX(LT_ALL);
-                }
-#undef GX_SHADE
-                launches += 1 + ((class_mask & 2) ? 1 : 0) + ((class_mask & 4) ? 1 : 0) + ((class_mask & 8) ? 1 : 0);
-            }
-            // next-vertex queue + NEE queue from the per-path flags; totals also count shadow and MIS rays
-            compact(COMPACT_FLAGS, q_in, n, s->pflags.p, 4, 2, &dctr->q_next, q_cur, s->queue_nee.p, nullptr);
-            if (timing) timer.end(stream);
-            HIP_TRY(hipMemcpyAsync(s->h_counters, dctr, sizeof(Counters), hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipStreamSynchronize(stream));
-            int n_next = (int)s->h_counters->q_next, n_nee = (int)s->h_counters->q_nee;
-            int n_sh = (int)s->h_counters->q_shadow, n_mis = (int)s->h_counters->q_mis;
-            launch_trace(TraceWork{q_cur, n_next, s->queue_nee.p, n_nee, nullptr, reinterpret_cast<unsigned char *>(s->nee_vis.p)}, n_sh, n_mis);
-            if (n_nee > 0) {
-                if (timing) timer.begin(1, stream);
-                hipLaunchKernelGGL(k_nee_combine, dim3(grid_for(n_nee)), dim3(kBlock), 0, stream, pa, (const int *)s->queue_nee.p, n_nee, reinterpret_cast<const unsigned char *>(s->nee_vis.p));
-                if (timing) timer.end(stream);
-                ++launches;
-            }
-            q_in = q_cur;
-            std::swap(q_cur, q_other);
-            n = n_next;
-            if (++guard > 4096) { set_error("path loop did not terminate"); return GNXR_ERR_INVALID; }
         }
         hipLaunchKernelGGL(k_resolve, dim3(grid_for(r.npix)), dim3(kBlock), 0, stream, pa, s->accum.p, r.npix, kk);
         ++launches;
@@ -932,6 +1000,7 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
     HIP_TRY(hipMemcpyAsync(s->h_counters, dctr, sizeof(Counters), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     HIP_TRY(hipGetLastError());
+    if (timing) timer.collect();
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
     if (stats) {

@@ -34,7 +34,7 @@ constexpr int kCompactTile = kCompactBlock * kCompactChunks;
 template <int MODE, int NOUT>
 __global__ void __launch_bounds__(kCompactBlock) k_compact_count(const int *__restrict__ q_in, int n, const unsigned char *__restrict__ keys, unsigned int *tile_counts,
                                                                  int nTiles, const int *__restrict__ hit = nullptr, const unsigned char *__restrict__ tri_class = nullptr,
-                                                                 unsigned char *keys_out = nullptr) {
+                                                                 unsigned char *keys_out = nullptr, int split = 0) {
     __shared__ unsigned int wsum[NOUT][kCompactBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
@@ -45,8 +45,9 @@ __global__ void __launch_bounds__(kCompactBlock) k_compact_count(const int *__re
             const long long i = (long long)tile * kCompactTile + c * kCompactBlock + threadIdx.x;
             unsigned key = 0xffu;
             const bool valid = i < n;
+            int path = -1;
             if (valid) {
-                const int path = q_in ? q_in[i] : (int)i;
+                path = q_in ? q_in[i] : (int)i;
                 if (MODE == COMPACT_HITCLASS) {
                     const int h = hit[path];
                     if (h >= 0) { key = tri_class[h]; keys_out[path] = (unsigned char)key; }
@@ -54,7 +55,11 @@ __global__ void __launch_bounds__(kCompactBlock) k_compact_count(const int *__re
                 } else key = compact_key<MODE>(keys, path);
             }
 #pragma unroll
-            for (int o = 0; o < NOUT; ++o) acc[o] += (unsigned)__popcll(__ballot(valid && compact_pred<MODE>(key, o)));   // wave-uniform
+            for (int o = 0; o < NOUT; ++o) {
+                // FLAGS, fifth count: continues and lives below `split` (the sub-pass in the lower half of the state arrays)
+                const bool pr = (MODE == COMPACT_FLAGS && o == 4) ? ((key & 1u) != 0 && path < split) : compact_pred<MODE>(key, o);
+                acc[o] += (unsigned)__popcll(__ballot(valid && pr));   // wave-uniform
+            }
         }
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) if (lane == 0) wsum[o][wave] = acc[o];

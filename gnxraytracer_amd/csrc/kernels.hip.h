@@ -46,6 +46,7 @@ struct PathArrays {
 struct Counters {
     unsigned long long nodes, tris;
     unsigned int q_next, q_nee, q_shadow, q_mis;   // k_compact_scan totals: paths that continue / have NEE / shadow rays / MIS rays
+    unsigned int q_low;                             // ... / continue and live in the lower half of the state arrays (follows q_mis: the fifth total)
     unsigned int q_class[4];                        // fill counts of the per-material-class shade queues (3: image-textured)
     unsigned int cursor;                            // k_trace work cursor
     unsigned long long whitted_shadow;              // shadow rays queued by k_whitted_step
@@ -576,6 +577,18 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
 #ifdef GX_SHADE_STATS
     if ((threadIdx.x & 63) == 0) for (int k = 0; k < 16; ++k) if (sst_[k]) atomicAdd(&g_shade_stats[k], sst_[k]);
 #endif
+}
+
+// The queue of the next trace when a sub-pass starts: the survivors of the older sub-pass (ascending slots of the other half of the
+// state arrays) and every slot [base, base + n_new) of the new one, merged in ascending order.
+static __global__ void __launch_bounds__(kBlock) k_queue_merge(const int *__restrict__ q_old, int n_old, int base, int n_new, int new_is_upper, int *__restrict__ q_out) {
+    const long long total = (long long)n_old + n_new;
+    for (long long i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int v;
+        if (new_is_upper) v = i < n_old ? q_old[i] : base + (int)(i - n_old);
+        else v = i < n_new ? base + (int)i : q_old[i - n_new];
+        q_out[i] = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,5 +1,5 @@
 """A/B timing of library builds / tuning knobs on the headline workload (dev tool).
-usage: python tests/dev_ab.py [--spp N] [--workload cfg3|cfg4] variant ...      variant = name[:lib.so][:ENV=VAL,ENV=VAL]
+usage: python tests/dev_ab.py [--spp N] [--passes P] [--workload cfg3|cfg4] variant ...   (each timed call renders P passes of N spp)      variant = name[:lib.so][:ENV=VAL,ENV=VAL]
 Each variant runs in its own process (GNXR_LIB selects the build, the environment carries the knobs); prints one JSON line each."""
 import os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,7 +7,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np, torch
     import gnxraytracer_amd as gx, scenes
-    spp, workload = int(sys.argv[2]), sys.argv[3]
+    spp, workload, passes = int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
     gx.init(0)
     b = scenes.dragon_cornell(100000, "glass+metal") if workload == "cfg3" else scenes.dragon_cornell(100000, "zoo", env=scenes.synthetic_env_path(1000, 500))
     scene = gx.Scene(b); integ = gx.PathIntegrator(8, 1.0, "spatial")
@@ -15,7 +15,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     gx.lib().gnxr_set_profiling(1)
     best = None
     for rep in range(4):
-        st = integ.RenderDevice(scene, out.data_ptr(), 1920, 1080, 1024, spp_begin=spp * rep, spp_end=spp * rep + spp, samples_per_pass=spp)
+        st = integ.RenderDevice(scene, out.data_ptr(), 1920, 1080, 1024, spp_begin=(spp * passes * rep) % 1024, spp_end=(spp * passes * rep) % 1024 + spp * passes, samples_per_pass=spp)
         if rep and (best is None or st["seconds_render"] < best["seconds_render"]): best = st
     rays = best["rays_closest"] + best["rays_any"]
     print(json.dumps({"variant": os.environ.get("GNXR_AB_NAME", "default"), "ms": round(best["seconds_render"] * 1e3, 3), "Mrays/s": round(rays / best["seconds_render"] / 1e6, 1),
@@ -23,10 +23,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
                       "checksum": float(out.double().sum().item())}))
 else:
     args = sys.argv[1:]
-    spp, workload = 32, "cfg3"
+    spp, workload, passes = 32, "cfg3", 1
     while args and args[0].startswith("--"):
         if args[0] == "--spp": spp = int(args[1])
         if args[0] == "--workload": workload = args[1]
+        if args[0] == "--passes": passes = int(args[1])
         args = args[2:]
     for v in args:
         parts = v.split(":")
@@ -37,5 +38,5 @@ else:
                     k, val = kv.split("="); env[k] = val
             elif p:
                 env["GNXR_LIB"] = os.path.abspath(p)
-        r = subprocess.run([sys.executable, __file__, "--child", str(spp), workload], env=env, capture_output=True, text=True)
+        r = subprocess.run([sys.executable, __file__, "--child", str(spp), workload, str(passes)], env=env, capture_output=True, text=True)
         print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ("FAILED " + v + " " + r.stderr[-800:]), flush=True)
