@@ -529,6 +529,28 @@ def test_randomised_sweep_against_oracle(gpu):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("name", ["cornell", "mesh2k"])
+def test_pipelined_passes_equal_one_pass(gpu, name):
+    """The pipelined path loop (csrc/api.hip: two passes in flight, the late bounces of one sharing launches with the first bounces of the
+    next, k_queue_merge) against the same samples rendered as ONE pass and against the oracle: images and ray counts bit for bit, for
+    pass sizes that divide the sample range, that do not, and for a sample sub-range."""
+    b = scenes.cornell() if name == "cornell" else _scene("mesh2k")
+    scene = gpu.Scene(b)
+    integ = gpu.PathIntegrator(8, 1.0, "spatial")
+    W, H, spp = 48, 40, 7
+    one, st1 = integ.Render(scene, W, H, spp, samples_per_pass=spp)
+    oimg, ost = ol.OracleScene(b).render(integ, W, H, spp)
+    assert (st1["rays_closest"], st1["rays_any"]) == (ost["rays_closest"], ost["rays_any"]) and biteq(one, oimg)
+    for k in (1, 2, 3, 4):
+        img, st = integ.Render(scene, W, H, spp, samples_per_pass=k)
+        assert st["passes"] == (spp + k - 1) // k
+        assert (st["rays_closest"], st["rays_any"]) == (st1["rays_closest"], st1["rays_any"]), k
+        assert biteq(img, one), k
+    a, sa = integ.Render(scene, W, H, spp, spp_begin=2, spp_end=6, samples_per_pass=1)
+    c, sc_ = integ.Render(scene, W, H, spp, spp_begin=2, spp_end=6, samples_per_pass=4)
+    assert biteq(a, c) and (sa["rays_closest"], sa["rays_any"]) == (sc_["rays_closest"], sc_["rays_any"])
+
+
 def test_edge_cases(gpu):
     scene = gpu.Scene(scenes.cornell())
     img, st = gpu.PathIntegrator(0).Render(scene, 8, 8, 2)               # maxDepth 0
