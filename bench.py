@@ -213,7 +213,7 @@ def load_profile_json(name, args, sps, world):
     return tj
 
 
-def roofline(kernel, secs, launches, units, unit_name, bytes_per_unit, byte_terms, args, sps, world, peaks, gathers_per_unit, extra):
+def roofline(kernel, secs, launches, units, unit_name, bytes_per_unit, byte_terms, args, sps, world, peaks, gathers_per_unit, extra, steps=None):
     """Three ceilings for the dominant kernel, each a fraction of a stated peak; `bound` names the one the kernel sits closest to.
     hbm   : bytes that actually reached HBM per launch (PMC: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes, profiles/) over
             the HIP-event launch time vs 8 TB/s.  The ALGORITHMIC byte rate (SURVEY 8d's model, counted on the walk that is timed)
@@ -235,19 +235,25 @@ def roofline(kernel, secs, launches, units, unit_name, bytes_per_unit, byte_term
     traffic = None
     tj = load_profile_json("traffic_latest.json", args, sps, world)
     if tj and kernel in tj:
-        traffic = tj[kernel].get("hbm_bytes_per_launch")
+        # counter totals are kept per STEP (the library merges the launches of consecutive passes, so "per launch" depends on how many
+        # steps a call covers); per launch of THIS run = per step x steps / launches
+        if steps and tj[kernel].get("hbm_bytes_per_step"):
+            traffic = tj[kernel]["hbm_bytes_per_step"] * steps / launches
+        else:
+            traffic = tj[kernel].get("hbm_bytes_per_launch")
         meas = traffic / avg_s / 1e9
         hbm.update({"achieved": meas, "frac": meas / HBM_PEAK_GBS, "algorithmic_over_measured": upl * bytes_per_unit / traffic,
                     "traffic_source": {"file": f"profiles/traffic_latest_{args.workload}.json", "commit": tj.get("_measured_on", {}).get("commit"),
-                                       "raw_bytes_per_launch": tj[kernel].get("hbm_bytes_per_launch_uncorrected"),
+                                       "raw_bytes_per_step": tj[kernel].get("hbm_bytes_per_step_uncorrected"), "steps_profiled": tj.get("_measured_on", {}).get("steps_profiled"),
                                        "correction": "FETCH_SIZE x 2 (gfx950, MI355X_MICROARCH.md) + WRITE_SIZE"}})
     valu = None
     pj = load_profile_json("pmc_latest.json", args, sps, world)
     if pj and kernel in pj and peaks.get("valu"):
         k = pj[kernel]
-        ach = k["valu_insts_per_launch"] / avg_s / 1e9
+        vpl = k["valu_insts_per_step"] * steps / launches if (steps and k.get("valu_insts_per_step")) else k["valu_insts_per_launch"]
+        ach = vpl / avg_s / 1e9
         valu = {"achieved": ach, "peak": peaks["valu"], "unit": "G wave-instr/s", "frac": ach / peaks["valu"],
-                "wave_insts_per_" + one: k["valu_insts_per_launch"] / upl, "lane_util": k.get("lane_util"), "valu_busy_pmc": k.get("valu_busy"),
+                "wave_insts_per_" + one: vpl / upl, "lane_util": k.get("lane_util"), "valu_busy_pmc": k.get("valu_busy"),
                 "wait_frac": k.get("wait_frac"), "waves_per_simd": k.get("waves_per_simd"),
                 "source": {"file": f"profiles/pmc_latest_{args.workload}.json", "commit": pj.get("_measured_on", {}).get("commit")},
                 "peak_source": "gnxr_probe_valu_peak in this run: independent v_fma_f32 chains, 8 waves per SIMD on every CU"}
@@ -487,7 +493,7 @@ def main():
             # per-lane loads: 8 density values per step + the permutation-table digits of its two Halton values (~2 x 5) + 4 per segment
             result["roofline"] = roofline("k_vol_media", tot["seconds_nee"], tot["launches_nee"], tot["media_segments"], "segments", b_seg,
                                           "64 B per segment (ray, state, result) + 32 B per tracking step (8 density loads)", args, sps, world, peaks,
-                                          4.0 + 18.0 * steps, {"tracking_steps_per_segment": steps, "kernel_seconds": kernel_seconds})
+                                          4.0 + 18.0 * steps, {"tracking_steps_per_segment": steps, "kernel_seconds": kernel_seconds}, steps=args.steps)
         else:
             n_re, n_mem = stc["leaf_retests"] / nr, stc["nodes_from_memory"] / nr
             b_ray = 136.0 + 128.0 * n4 + 48.0 * n_tris + 32.0 * n_re   # SURVEY 8(d) with the node term of the tree that is walked: 128-B DNode4
@@ -496,7 +502,7 @@ def main():
                                           "32 B x leaf boxes re-tested, counted by k_trace4<COUNT> on the timed walk", args, sps, world, peaks,
                                           8.0 * n_mem + 3.0 * n_tris + 2.0 * n_re + 3.0,
                                           {"nodes4_per_ray": n4, "nodes4_from_memory_per_ray": n_mem, "tris_per_ray": n_tris, "leaf_retests_per_ray": n_re,
-                                           "kernel_seconds": kernel_seconds})
+                                           "kernel_seconds": kernel_seconds}, steps=args.steps)
         result["roofline"]["note"] = ("nodes and triangles (11 MB) are served by LDS (the top 64 nodes: half of all visits), L2 and Infinity Cache, so the "
                                       "algorithmic byte model over-states what reaches HBM; the walk is a dependent chain per ray (load a node, test four "
                                       "boxes, pick the next) and sits below all three ceilings -- DESIGN.md section 4 has the measurements that rule each one out")

@@ -14,6 +14,7 @@ ap.add_argument("pmc_dir"); ap.add_argument("out")
 ap.add_argument("--workload", default="cfg3"); ap.add_argument("--spp-per-step", type=int, default=128)
 ap.add_argument("--width", type=int, default=1920); ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--commit", default=None); ap.add_argument("--traffic", default=None)
+ap.add_argument("--steps-profiled", type=int, default=3, help="steps the profiled command rendered (warm-up + timed): totals / this = per-step figures, which do not depend on how the library merges launches")
 a = ap.parse_args()
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 commit = a.commit
@@ -22,7 +23,7 @@ if commit is None:
     except Exception:
         try: commit = open(os.path.join(ROOT, ".build_commit")).read().strip()
         except Exception: commit = None
-on = {"workload": a.workload, "spp_per_step": a.spp_per_step, "width": a.width, "height": a.height, "commit": commit,
+on = {"steps_profiled": a.steps_profiled, "workload": a.workload, "spp_per_step": a.spp_per_step, "width": a.width, "height": a.height, "commit": commit,
       "command": f"rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --workload {a.workload} --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing"}
 
 def short(name):
@@ -37,7 +38,7 @@ for f in files:
 out = {"_measured_on": on}
 for k, c in agg.items():
     n = len(disp[k]); e = {"dispatches": n, "variants": sorted(variants[k]), "raw_totals": {kk: vv for kk, vv in c.items()}}
-    if "SQ_INSTS_VALU" in c: e["valu_insts_per_launch"] = c["SQ_INSTS_VALU"] / n
+    if "SQ_INSTS_VALU" in c: e["valu_insts_per_launch"] = c["SQ_INSTS_VALU"] / n; e["valu_insts_per_step"] = c["SQ_INSTS_VALU"] / a.steps_profiled
     if c.get("SQ_ACTIVE_INST_VALU"): e["lane_util"] = c.get("SQ_THREAD_CYCLES_VALU", 0) / (64 * c["SQ_ACTIVE_INST_VALU"])
     if c.get("SQ_BUSY_CYCLES") and "SQ_ACTIVE_INST_VALU" in c: e["valu_busy"] = c["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * c["SQ_BUSY_CYCLES"] / 32)
     if c.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in c: e["wait_frac"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
@@ -46,6 +47,11 @@ for k, c in agg.items():
     out[k] = e
 json.dump(out, open(a.out, "w"), indent=1)
 if a.traffic and os.path.exists(a.traffic):
-    t = json.load(open(a.traffic)); t["_measured_on"] = dict(on, command=on["command"].replace("<counters>", "FETCH_SIZE | WRITE_SIZE (separate passes)")); json.dump(t, open(a.traffic, "w"), indent=1)
+    t = json.load(open(a.traffic))
+    for k_, v_ in t.items():
+        if isinstance(v_, dict) and "hbm_bytes_per_launch" in v_:
+            v_["hbm_bytes_per_step"] = v_["hbm_bytes_per_launch"] * v_["dispatches"] / a.steps_profiled
+            v_["hbm_bytes_per_step_uncorrected"] = v_["hbm_bytes_per_launch_uncorrected"] * v_["dispatches"] / a.steps_profiled
+    t["_measured_on"] = dict(on, command=on["command"].replace("<counters>", "FETCH_SIZE | WRITE_SIZE (separate passes)")); json.dump(t, open(a.traffic, "w"), indent=1)
 for k in ("k_trace", "k_shade", "k_vol_media", "k_vol_step"):
     if k in out: print(k, {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in out[k].items() if kk not in ("raw_totals", "variants")})

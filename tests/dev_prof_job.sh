@@ -34,7 +34,7 @@ for W in cfg3 cfg4 cfg5; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write_$W --output-format csv -- python3 bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $O/write_$W.log 2>&1
   python tests/dev_traffic.py $O/fetch_$W $O/write_$W $O/traffic_$W.json
   X=""; if [ $W = cfg5 ]; then X="--width 512 --height 512 --spp-per-step 256"; fi
-  python tests/dev_pmc_json.py $O/pmc_sq_$W $O/pmc_$W.json --workload $W $X --traffic $O/traffic_$W.json
+  python tests/dev_pmc_json.py $O/pmc_sq_$W $O/pmc_$W.json --workload $W $X --steps-profiled 3 --traffic $O/traffic_$W.json
   echo "pmc $W done"
 done
 fi
