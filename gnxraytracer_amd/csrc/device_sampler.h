@@ -29,7 +29,7 @@ GX_DEV uint32_t div_magic(uint32_t n, uint32_t M, uint32_t s) {
 // What a scrambled radical inverse needs to know about its dimension.  invBase = 1 / (float)base and the tail of the reference's last line,
 // invBase * perm[0] / (1 - invBase) (LowDiscrepancy.cpp:392: the digits beyond the index's own are all perm[0]), are constants of the
 // dimension: the LDS copy holds them (computed once per block with the same IEEE operations), the global path computes them per call.
-struct DimInfo { uint32_t base, M, s, off; float invBase, tail; };
+struct DimInfo { uint32_t base, M, s, off; float invBase, tail; uint32_t M32; };   // M32 = ceil(2^32 / base): n / base == umulhi(n, M32) while n * base < 2^32
 GX_DEV float halton_tail(float invBase, uint32_t perm0) { return invBase * (float)(int)perm0 / (1 - invBase); }
 
 // Where the tables are read from.  GlobalTab: the scene's arrays in global memory.  LdsTab: a block's LDS copy of the first `dims`
@@ -43,6 +43,7 @@ struct GlobalTab {
         q.base = (uint32_t)t.primes[d]; q.M = t.prime_magic[2 * d]; q.s = t.prime_magic[2 * d + 1]; q.off = (uint32_t)t.prime_sums[d];
         q.invBase = 1.f / (float)q.base;
         q.tail = halton_tail(q.invBase, perm(q.off));
+        q.M32 = div_magic(0xffffffffu, q.M, q.s) + 1u;   // ceil(2^32 / base) for an odd prime: floor((2^32 - 1) / base) + 1, without a 64-bit division
         return q;
     }
 };
@@ -60,7 +61,7 @@ struct LdsTab {
     GX_DEV DimInfo dim(int d) const {
         const u4v v = l.tab[2 * d], w = l.tab[2 * d + 1];
         DimInfo q;
-        q.base = v.x; q.M = v.y; q.s = v.z; q.off = v.w; q.invBase = __uint_as_float(w.x); q.tail = __uint_as_float(w.y);
+        q.base = v.x; q.M = v.y; q.s = v.z; q.off = v.w; q.invBase = __uint_as_float(w.x); q.tail = __uint_as_float(w.y); q.M32 = w.z;
         return q;
     }
 };
@@ -79,6 +80,12 @@ GX_DEV float radical_inverse_base(uint32_t a, uint32_t base, uint32_t M, uint32_
     }
     return fminf((float)reversedDigits * invBaseN, GX_ONE_MINUS_EPS);
 }
+// n / base for the digit loop.  With a 32-bit accumulator the index satisfies n * base < 2^32 (DHalton::base32_max), and then one
+// multiply-high by ceil(2^32 / base) is exact: the error term n * e / 2^32 (e = M32 * base - 2^32 < base) stays below 1 / base.  (MI355X
+// issues v_mul_hi_u32 and shifts at half the rate of adds: the general round-up form costs four times as much, tools/probes/valu_probe.hip.)
+template <class ACC> GX_DEV uint32_t digit_div(uint32_t n, const DimInfo &q);
+template <> GX_DEV uint32_t digit_div<uint32_t>(uint32_t n, const DimInfo &q) { return __umulhi(n, q.M32); }
+template <> GX_DEV uint32_t digit_div<uint64_t>(uint32_t n, const DimInfo &q) { return div_magic(n, q.M, q.s); }
 // ScrambledRadicalInverseSpecialized<base>, LowDiscrepancy.cpp:374-393.  Digits are peeled four at a time so that the four
 // permutation-table loads are independent and in flight together (the serial loop waited for one L1/L2 round trip per
 // digit); the accumulation then runs in the reference's order, digit by digit, for as many digits as the index has.
@@ -87,11 +94,11 @@ GX_DEV float radical_inverse_base(uint32_t a, uint32_t base, uint32_t M, uint32_
 // step is one multiply-add instead of a two-part 64-bit one, and the final conversion to float rounds the same integer once.
 template <class ACC, class TAB>
 GX_DEV float scrambled_radical_inverse_acc(uint32_t a, const DimInfo &q, const TAB &tab) {
-    const uint32_t base = q.base, M = q.M, s = q.s, off = q.off;
+    const uint32_t base = q.base, off = q.off;
     ACC reversedDigits = 0;
     float invBaseN = 1;
     while (a) {
-        const uint32_t n1 = div_magic(a, M, s), n2 = div_magic(n1, M, s), n3 = div_magic(n2, M, s), n4 = div_magic(n3, M, s);
+        const uint32_t n1 = digit_div<ACC>(a, q), n2 = digit_div<ACC>(n1, q), n3 = digit_div<ACC>(n2, q), n4 = digit_div<ACC>(n3, q);
         const uint32_t p0 = tab.perm(off + a - n1 * base), p1 = tab.perm(off + n1 - n2 * base), p2 = tab.perm(off + n2 - n3 * base), p3 = tab.perm(off + n3 - n4 * base);
         reversedDigits = reversedDigits * base + p0; invBaseN *= q.invBase;
         reversedDigits = n1 ? reversedDigits * base + p1 : reversedDigits; invBaseN = n1 ? invBaseN * q.invBase : invBaseN;
@@ -124,14 +131,14 @@ GX_DEV float halton_sample(const DSamplerTables &t, uint32_t index, int dim) {
 // scrambled_radical_inverse_acc, hence the same values.
 template <class ACC, class TAB>
 GX_DEV void halton_sample_pair_acc(const TAB &tab, uint32_t index, const DimInfo &q0, const DimInfo &q1, float *u0, float *u1) {
-    const uint32_t b0 = q0.base, M0 = q0.M, s0 = q0.s, o0 = q0.off, b1 = q1.base, M1 = q1.M, s1 = q1.s, o1 = q1.off;
+    const uint32_t b0 = q0.base, o0 = q0.off, b1 = q1.base, o1 = q1.off;
     const float inv0 = q0.invBase, inv1 = q1.invBase;
     ACC rev0 = 0, rev1 = 0;
     float invN0 = 1, invN1 = 1;
     uint32_t a0 = index, a1 = index;
     while (a0 | a1) {
-        const uint32_t n01 = div_magic(a0, M0, s0), n02 = div_magic(n01, M0, s0), n03 = div_magic(n02, M0, s0), n04 = div_magic(n03, M0, s0);
-        const uint32_t n11 = div_magic(a1, M1, s1), n12 = div_magic(n11, M1, s1), n13 = div_magic(n12, M1, s1), n14 = div_magic(n13, M1, s1);
+        const uint32_t n01 = digit_div<ACC>(a0, q0), n02 = digit_div<ACC>(n01, q0), n03 = digit_div<ACC>(n02, q0), n04 = digit_div<ACC>(n03, q0);
+        const uint32_t n11 = digit_div<ACC>(a1, q1), n12 = digit_div<ACC>(n11, q1), n13 = digit_div<ACC>(n12, q1), n14 = digit_div<ACC>(n13, q1);
         const uint32_t p00 = tab.perm(o0 + a0 - n01 * b0), p01 = tab.perm(o0 + n01 - n02 * b0), p02 = tab.perm(o0 + n02 - n03 * b0), p03 = tab.perm(o0 + n03 - n04 * b0);
         const uint32_t p10 = tab.perm(o1 + a1 - n11 * b1), p11 = tab.perm(o1 + n11 - n12 * b1), p12 = tab.perm(o1 + n12 - n13 * b1), p13 = tab.perm(o1 + n13 - n14 * b1);
         rev0 = a0 ? rev0 * b0 + p00 : rev0; invN0 = a0 ? invN0 * inv0 : invN0;
@@ -259,7 +266,7 @@ GX_DEV LdsSampler lds_sampler_fill(const DSamplerTables &t, int dims, int n_perm
         const DimInfo q = GlobalTab{t}.dim(d);
         u4v v, w;
         v.x = q.base; v.y = q.M; v.z = q.s; v.w = q.off;
-        w.x = __float_as_uint(q.invBase); w.y = __float_as_uint(q.tail); w.z = 0; w.w = 0;
+        w.x = __float_as_uint(q.invBase); w.y = __float_as_uint(q.tail); w.z = q.M32; w.w = 0;
         tb[2 * d] = v; tb[2 * d + 1] = w;
     }
     l.perms = (lds_u16c *)smem; l.tab = (lds_u4c *)tb; l.dims = dims;
