@@ -963,9 +963,12 @@ else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, slds, stream,
                 compact(COMPACT_CLASS, q_in, n, s->vol_state.p, 3, 3, &dctr->q_class[0], s->queue_c0.p, s->queue_c1.p, s->queue_c2.p);
                 {
                     int *qc[3] = {s->queue_c0.p, s->queue_c1.p, s->queue_c2.p};
-#define GX_VS1(LMV, LTV, ST) hipLaunchKernelGGL((k_vol_step<LMV, LTV, ST>), dim3(grid_for(n)), dim3(kBlock), 0, stream, sc, mt, r, pa, va, (const int *)qc[ST], (const unsigned int *)&dctr->q_class[ST])
+                    // the scene's material and light tables go to LDS when they are small (as for k_shade)
+                    const int vmats = s->cs.materials.size() <= 12 ? (int)s->cs.materials.size() : 0, vlights = (nL > 0 && nL <= 16) ? nL : 0;
+                    const size_t vlds = (size_t)vmats * sizeof(DMaterial) + (size_t)vlights * sizeof(DLight);
+#define GX_VS1(LMV, LTV, ST) hipLaunchKernelGGL((k_vol_step<LMV, LTV, ST>), dim3(grid_for(n)), dim3(kBlock), vlds, stream, sc, mt, r, pa, va, (const int *)qc[ST], (const unsigned int *)&dctr->q_class[ST], vmats, vlights)
 #define GX_VS(LMV, LTV) do { GX_VS1(LMV, LTV, VS_MAIN); GX_VS1(LMV, LTV, VS_SHADOW); GX_VS1(LMV, LTV, VS_MIS); } while (0)
-#define GX_VST1(LTV, ST) hipLaunchKernelGGL((k_vol_step<LM_ALL, LTV, ST, true>), dim3(grid_for(n)), dim3(kBlock), 0, stream, sc, mt, r, pa, va, (const int *)qc[ST], (const unsigned int *)&dctr->q_class[ST])
+#define GX_VST1(LTV, ST) hipLaunchKernelGGL((k_vol_step<LM_ALL, LTV, ST, true>), dim3(grid_for(n)), dim3(kBlock), vlds, stream, sc, mt, r, pa, va, (const int *)qc[ST], (const unsigned int *)&dctr->q_class[ST], vmats, vlights)
 #define GX_VST(LTV) do { GX_VST1(LTV, VS_MAIN); GX_VST1(LTV, VS_SHADOW); GX_VST1(LTV, VS_MIS); } while (0)
                     if (textured) { if (area_only) GX_VST(LT_AREA); else GX_VST(LT_ALL); }
                     else if (area_only) { if (class_mask <= 1) GX_VS(LM_DIFFUSE, LT_AREA); else if (class_mask <= 3) GX_VS(LM_GLOSSY, LT_AREA); else GX_VS(LM_ALL, LT_AREA); }

@@ -21,4 +21,4 @@
 #define GX_WHITTED_SIGNATURE(M, L, S, T) \
     __global__ void gnxr::k_whitted_step<M, L, S, T>(gnxr::DScene, gnxr::DRender, gnxr::PathArrays, gnxr::WhittedArrays, const int *, int, unsigned long long *);
 #define GX_VOL_SIGNATURE(M, L, ST, T) \
-    __global__ void gnxr::k_vol_step<M, L, ST, T>(gnxr::DScene, gnxr::DMediaTables, gnxr::DRender, gnxr::PathArrays, gnxr::VolArrays, const int *, const unsigned int *);
+    __global__ void gnxr::k_vol_step<M, L, ST, T>(gnxr::DScene, gnxr::DMediaTables, gnxr::DRender, gnxr::PathArrays, gnxr::VolArrays, const int *, const unsigned int *, int, int);

@@ -243,8 +243,29 @@ __global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt
 // VolPathIntegrator.cpp:30) until the ray is replaced (pass-through, medium or surface scattering all assign a plain SpawnRay), so
 // a surface vertex reached by the camera ray itself filters its textures with the camera differentials (vs.w).
 template <uint32_t LM, int LT, int ST, bool TEX = false>
-__global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt, DRender r, PathArrays pa, VolArrays va, const int *__restrict__ queue, const unsigned int *n_dev) {
+__global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt, DRender r, PathArrays pa, VolArrays va, const int *__restrict__ queue, const unsigned int *n_dev, int lds_mats, int lds_lights) {
+    extern __shared__ int vstep_smem[];   // the scene's DMaterial[] | DLight[] when they are small (as in k_shade: dependent gathers along the BSDF code become LDS reads)
     const int n = (int)*n_dev;
+    if (blockIdx.x * blockDim.x >= (unsigned)n) return;
+    const DMaterial *mats = sc.materials;
+    DLightTables ltab = sc.lt;
+    {
+        int *dst = vstep_smem;
+        if (!TEX && lds_mats > 0) {
+            const int *src = reinterpret_cast<const int *>(sc.materials);
+            const int nd = lds_mats * (int)(sizeof(DMaterial) / 4);
+            for (int k = threadIdx.x; k < nd; k += kBlock) dst[k] = src[k];
+            mats = reinterpret_cast<const DMaterial *>(dst);
+            dst += nd;
+        }
+        if (lds_lights > 0) {
+            const int *src = reinterpret_cast<const int *>(sc.lt.lights);
+            const int nd = lds_lights * (int)(sizeof(DLight) / 4);
+            for (int k = threadIdx.x; k < nd; k += kBlock) dst[k] = src[k];
+            ltab.lights = reinterpret_cast<const DLight *>(dst);
+        }
+    }
+    __syncthreads();
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int path = queue[i];
         int4 vs = va.vs[path];
@@ -384,9 +405,9 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
                 miT = -1.f;
                 if (bounces == 0 || specularBounce) {
                     if (found) {
-                        if (triLight >= 0) L = L + beta * area_L(sc.lt.lights[triLight], sp0.n, -rd);
+                        if (triLight >= 0) L = L + beta * area_L(ltab.lights[triLight], sp0.n, -rd);
                     } else {
-                        for (int k = 0; k < sc.lt.n_infinite; ++k) L = L + beta * light_Le<LT>(sc.lt, sc.lt.infinite[k], ro, rd);
+                        for (int k = 0; k < ltab.n_infinite; ++k) L = L + beta * light_Le<LT>(ltab, ltab.infinite[k], ro, rd);
                     }
                 }
                 if (!found || bounces >= r.max_depth) alive = false;
@@ -431,7 +452,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
                 const DSphere &sph = sc.spheres[-2 - vleaf];
                 triMat = sph.material;
                 (void)sphere_test(sph, ro, rd, o4.w, &h.t);
-                mat = sc.materials + triMat;
+                mat = mats + triMat;
                 sp = sphere_surface_point(sph, ro, rd, h.t, mat->has_bump != 0);
             } else {
                 const float4 *q = reinterpret_cast<const float4 *>(sc.tris + vleaf);
@@ -439,7 +460,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
                 p0 = V3(a.x, a.y, a.z); p1 = V3(b.x, b.y, b.z); p2 = V3(c.x, c.y, c.z);
                 triMat = __float_as_int(b.w);
                 (void)tri_test(p0, p1, p2, ro, rd, o4.w, &h);
-                mat = sc.materials + triMat;
+                mat = mats + triMat;
                 sp = surface_point(p0, p1, p2, h, mat->has_bump != 0);
                 if (TEX) { V3 dndu, dndv; sp = surface_point_tables(tex_tables(sc.materials), vleaf, p0, p1, p2, h, mat->has_bump != 0, &dndu, &dndv); }
                 if (TEX && (mat->kd_tex | mat->ks_tex)) {
@@ -464,10 +485,10 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
         const V3 woN = normalize(-rd);   // SurfaceInteraction::wo
         const V3 woM = -rd;              // MediumInteraction::wo
 
-        if (vertexNew && sc.lt.n_lights > 0) {
+        if (vertexNew && ltab.n_lights > 0) {
             // ---- UniformSampleOneLight + EstimateDirect(handleMedia = true), Integrator.cpp:57-79, 93-210
             float lightPdfSel;
-            int lightNum = light_select(sc.lt, itP, ss.get1d(), &lightPdfSel);
+            int lightNum = light_select(ltab, itP, ss.get1d(), &lightPdfSel);
             if (lightPdfSel != 0) {
                 float ul0, ul1, us0, us1;
                 ss.get2d(&ul0, &ul1);
@@ -478,7 +499,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
                 Spec fX(0.f), Y(0.f);
                 float weightX = 0, weightY = 0, scatPdf2 = 0;
                 int expect = -1, shMedium = -1, misMedium = -1;
-                LightSample ls = light_sample<LT>(sc.lt, lightNum, itP, ul0, ul1);
+                LightSample ls = light_sample<LT>(ltab, lightNum, itP, ul0, ul1);
                 if (ls.pdf > 0 && !ls.Li.is_black()) {
                     float scatteringPdf;
                     if (isMedium) {
@@ -491,11 +512,11 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
                     if (!fX.is_black()) {
                         spawn_ray_to(itP, itPError, itN, ls.p1, ls.p1Error, ls.n1, &so, &sd);
                         shMedium = dot(sd, itN) > 0 ? medOut : medIn;
-                        weightX = light_is_delta<LT>(sc.lt.lights[lightNum]) ? 1.f : power_heuristic(ls.pdf, scatteringPdf);   // IsDeltaLight: no MIS weight
+                        weightX = light_is_delta<LT>(ltab.lights[lightNum]) ? 1.f : power_heuristic(ls.pdf, scatteringPdf);   // IsDeltaLight: no MIS weight
                         nflags |= 1;
                     }
                 }
-                if (!light_is_delta<LT>(sc.lt.lights[lightNum])) {   // ... and no scattering-sample half (Integrator.cpp:168)
+                if (!light_is_delta<LT>(ltab.lights[lightNum])) {   // ... and no scattering-sample half (Integrator.cpp:168)
                     Spec f2;
                     bool sampledSpecular = false;
                     if (isMedium) {
@@ -511,12 +532,12 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
                         weightY = 1;
                         bool skip = false;
                         if (!sampledSpecular) {
-                            float lightPdf = light_pdf<LT>(sc.lt, lightNum, itP, itPError, itN, wi2);
+                            float lightPdf = light_pdf<LT>(ltab, lightNum, itP, itPError, itN, wi2);
                             if (lightPdf == 0) skip = true;
                             else weightY = power_heuristic(scatPdf2, lightPdf);
                         }
                         if (!skip) {
-                            const DLight &lt = sc.lt.lights[lightNum];
+                            const DLight &lt = ltab.lights[lightNum];
                             mo = offset_ray_origin(itP, itPError, itN, wi2);
                             misMedium = dot(wi2, itN) > 0 ? medOut : medIn;
                             Spec Li2;
@@ -526,7 +547,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt,
                                 Li2 = area_L(lt, ln, -wi2);
                                 expect = lt.tri_leaf;
                             } else {
-                                Li2 = light_Le<LT>(sc.lt, lightNum, mo, wi2);
+                                Li2 = light_Le<LT>(ltab, lightNum, mo, wi2);
                                 expect = -1;
                             }
                             if (!Li2.is_black()) { Y = f2 * Li2; nflags |= 4; }
