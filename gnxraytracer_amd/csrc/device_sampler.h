@@ -16,7 +16,7 @@ struct DSamplerTables {
     const uint16_t *perms;
     const int32_t *primes;
     const int32_t *prime_sums;
-    const uint32_t *prime_magic;  // (M, s) per prime
+    const uint32_t *prime_magic;  // 8 words per prime: M, s (exact division), base, permutation offset, 1 / base, perm[0] tail, ceil(2^32 / base), 0
     DHalton h;
 };
 
@@ -38,12 +38,12 @@ GX_DEV float halton_tail(float invBase, uint32_t perm0) { return invBase * (floa
 struct GlobalTab {
     const DSamplerTables &t;
     GX_DEV uint32_t perm(uint32_t i) const { return t.perms[i]; }
-    GX_DEV DimInfo dim(int d) const {
+    GX_DEV DimInfo dim(int d) const {   // one 32-byte record per dimension, built by the scene compiler (build_sampler_tables)
+        typedef unsigned int u4g __attribute__((ext_vector_type(4)));
+        const u4g *rec = reinterpret_cast<const u4g *>(t.prime_magic) + 2 * (size_t)d;
+        const u4g v = rec[0], w = rec[1];
         DimInfo q;
-        q.base = (uint32_t)t.primes[d]; q.M = t.prime_magic[2 * d]; q.s = t.prime_magic[2 * d + 1]; q.off = (uint32_t)t.prime_sums[d];
-        q.invBase = 1.f / (float)q.base;
-        q.tail = halton_tail(q.invBase, perm(q.off));
-        q.M32 = div_magic(0xffffffffu, q.M, q.s) + 1u;   // ceil(2^32 / base) for an odd prime: floor((2^32 - 1) / base) + 1, without a 64-bit division
+        q.M = v.x; q.s = v.y; q.base = v.z; q.off = v.w; q.invBase = __uint_as_float(w.x); q.tail = __uint_as_float(w.y); q.M32 = w.z;
         return q;
     }
 };

@@ -69,7 +69,7 @@ struct CompiledScene {
     // sampler
     std::vector<uint16_t> perms;
     std::vector<int32_t> primes, prime_sums;
-    std::vector<uint32_t> prime_magic;   // 2 words per prime: multiplier, shift (exact u32 division)
+    std::vector<uint32_t> prime_magic;   // 8 words per prime: multiplier, shift (exact u32 division), base, permutation offset, 1 / base, perm[0] tail, ceil(2^32 / base), 0
     // env light
     bool has_env = false;
     DEnv env;

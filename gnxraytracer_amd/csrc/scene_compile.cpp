@@ -525,14 +525,26 @@ static void build_sampler_tables(CompiledScene *cs) {
     }
     // exact unsigned 32-bit division by each prime: q = (mulhi(n, M) + ((n - mulhi(n, M)) >> 1)) >> (s - 1)
     // with s = ceil(log2 d), M = floor(2^32 * (2^s - d) / d) + 1  (Granlund-Montgomery, valid for all n < 2^32)
-    cs->prime_magic.resize(2 * N);
+    // One 32-byte record per dimension (device_sampler.h DimInfo): the two magic words, the base, the offset of its permutation, and the
+    // per-dimension constants of ScrambledRadicalInverse -- 1 / (float)base, the perm[0] tail invBase * perm[0] / (1 - invBase)
+    // (LowDiscrepancy.cpp:392; float operations, IEEE on host and device alike) and ceil(2^32 / base) for the one-multiply digit division.
+    cs->prime_magic.resize(8 * (size_t)N);
     for (int i = 0; i < N; ++i) {
         uint32_t d = (uint32_t)cs->primes[i];
         int s = 0;
         while ((1ull << s) < d) ++s;
         uint64_t M = ((1ull << 32) * ((1ull << s) - d)) / d + 1;
-        cs->prime_magic[2 * i] = (uint32_t)M;
-        cs->prime_magic[2 * i + 1] = (uint32_t)s;
+        uint32_t *rec = &cs->prime_magic[8 * (size_t)i];
+        rec[0] = (uint32_t)M;
+        rec[1] = (uint32_t)s;
+        rec[2] = d;
+        rec[3] = (uint32_t)cs->prime_sums[i];
+        const float invBase = 1.f / (float)d;
+        const float tail = invBase * (float)(int)cs->perms[cs->prime_sums[i]] / (1 - invBase);
+        memcpy(&rec[4], &invBase, 4);
+        memcpy(&rec[5], &tail, 4);
+        rec[6] = (uint32_t)((0x100000000ull + d - 1) / d);
+        rec[7] = 0;
     }
 }
 
