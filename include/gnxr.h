@@ -263,7 +263,10 @@ typedef struct gnxr_render_params {
     int32_t integrator;         /* gnxr_integrator                                           */
     int32_t light_strategy;     /* gnxr_light_strategy                                       */
     int32_t shard_index, shard_count, shard_rows;
-    int32_t samples_per_pass;   /* 0 = auto; samples of one pixel in flight per pass         */
+    int32_t samples_per_pass;   /* 0 = auto; samples of one pixel rendered per pass.  GNXR_INTEGRATOR_PATH keeps two
+                                   passes in flight when the call covers more than one (twice the path state): a pass's thin
+                                   late bounces share kernel launches with the first bounces of the next; the image does not
+                                   depend on the pass size */
     int32_t direct_strategy;    /* gnxr_direct_strategy (GNXR_INTEGRATOR_DIRECT only)        */
 } gnxr_render_params;
 
