@@ -356,24 +356,32 @@ def main():
     # pixel are rendered inside the timed region either way.
     fuse = args.fuse_steps if args.fuse_steps > 0 else world
 
+    def calls_of(i0, nsteps):
+        """(s0, s1) sample ranges of the library calls that render steps i0 .. i0+nsteps-1: one per contiguous range of the Halton sequence"""
+        i = i0
+        while i < i0 + nsteps:
+            s0 = (i * sps) % args.spp
+            m = min(i0 + nsteps - i, max(1, (args.spp - s0) // sps))   # steps up to the end of the Halton sample range
+            yield s0, min(s0 + m * sps, args.spp), m
+            i += m
+
+    # path state for the largest call of the run is allocated before the warm-up (gnxr_render_reserve), so that no timed step grows it
+    for s0_, s1_, _ in list(calls_of(0, args.warmup)) + list(calls_of(0, args.steps)):
+        integ.Reserve(scene, W, H, args.spp, spp_begin=s0_, spp_end=s1_, samples_per_pass=min(fuse * sps, s1_ - s0_), **shard)
+
     def run_steps(i0, nsteps):
         """steps i0 .. i0+nsteps-1 = samples [i0*sps, (i0+nsteps)*sps) of every pixel (mod the Halton range --spp), submitted as ONE library
         call per contiguous sample range with samples_per_pass = fuse x sps: the library renders a call's passes two at a time -- the thin
         late bounces of one pass share launches with the camera rays and first bounces of the next (csrc/api.hip, pipelined path loop).
         Returns the summed stats."""
         agg = {}
-        i = i0
-        while i < i0 + nsteps:
-            s0 = (i * sps) % args.spp
-            m = min(i0 + nsteps - i, max(1, (args.spp - s0) // sps))   # steps up to the end of the Halton sample range
-            s1 = min(s0 + m * sps, args.spp)
+        for s0, s1, m in calls_of(i0, nsteps):
             st = integ.RenderDevice(scene, out.data_ptr(), W, H, args.spp, stream=stream, spp_begin=s0, spp_end=s1,
                                     samples_per_pass=min(fuse * sps, s1 - s0), **shard)
             acc.add_(out)
             for k_, v_ in st.items():
                 if isinstance(v_, (int, float)):
                     agg[k_] = agg.get(k_, 0) + v_
-            i += m
         return agg
 
     note(f"scene ready in {scene_setup_s:.2f} s; {args.warmup} warm-up + {args.steps} timed steps of {sps} spp")

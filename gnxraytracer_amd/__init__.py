@@ -376,6 +376,11 @@ class PathIntegrator:
         _check(lib().gnxr_render(scene._h, C.byref(p), img.ctypes.data_as(C.POINTER(C.c_float)), C.byref(st)))
         return img, stats_dict(st)
 
+    def Reserve(self, scene, width, height, spp, **kw):
+        """gnxr_render_reserve: allocate the path state of a Render / RenderDevice call with these arguments, without rendering."""
+        p = self.params(width, height, spp, **kw)
+        _check(lib().gnxr_render_reserve(scene._h, C.byref(p)))
+
     def RenderDevice(self, scene, d_ptr, width, height, spp, stream=None, **kw):
         p = self.params(width, height, spp, **kw)
         st = Stats()

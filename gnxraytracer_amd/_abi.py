@@ -124,6 +124,7 @@ PROTOTYPES = {
     "gnxr_scene_info": (C.c_int, [VP, P(i32), P(i32), P(i32)]),
     "gnxr_render": (C.c_int, [VP, P(RenderParams), P(f32), P(Stats)]),
     "gnxr_render_device": (C.c_int, [VP, P(RenderParams), VP, VP, P(Stats)]),
+    "gnxr_render_reserve": (C.c_int, [VP, P(RenderParams)]),
     "gnxr_trace_closest": (C.c_int, [VP, P(Ray), i64, P(Hit)]),
     "gnxr_trace_any": (C.c_int, [VP, P(Ray), i64, P(u8)]),
     "gnxr_sample_halton": (C.c_int, [i32, i32, P(i32), P(i32), P(i64), P(i32), i64, P(f32)]),

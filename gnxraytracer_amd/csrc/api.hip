@@ -307,17 +307,27 @@ bool device_morton_sort(const float *centroids3, int n, const float lo[3], const
 }  // namespace
 
 namespace {
-// Issue-rate probe: 8 independent fp32 FMA chains per lane, no memory traffic; with 8 waves on every SIMD the loop is bound by
-// VALU issue alone.  The result is written so that the chains cannot be folded away.
-__global__ void __launch_bounds__(256) k_valu_peak(float *out, int iters, float a, float b) {
+// Issue-rate probe: 8 independent v_fma_f32 chains per lane with all three operands in vector registers, no memory traffic; with 8 waves
+// on every SIMD the loop is bound by VALU issue alone.  Inline asm: the compiler would otherwise keep `a` and `b` in scalar registers (a
+// VOP3 with two scalar operands issues at half the rate: 578 instead of ~900 G wave-instructions/s) or pack pairs of chains into
+// v_pk_fma_f32 (half the instructions at half the rate).  tools/probes/valu_probe.hip has the same loop for every instruction kind the
+// kernels use: add / sub / mul / fma / logic issue in 2 cycles per wave64, min / max / compare / shift / integer multiply / conversion /
+// packed and fp64 arithmetic in 4, rcp / sqrt in 8 (profiles/r02_valu_probe.log).
+__global__ void __launch_bounds__(256) k_valu_peak(float *out, int iters, float a_in, float b_in) {
     float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+    float a = a_in, b = b_in;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_mov_b32 %0, %0" : "+v"(a));
+    asm volatile("v_mov_b32 %0, %0" : "+v"(b));
+#define GX_FMA1(x) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b));
+#else
+#define GX_FMA1(x) x = __builtin_fmaf(x, a, b);
+#endif
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            x0 = __builtin_fmaf(x0, a, b); x1 = __builtin_fmaf(x1, a, b); x2 = __builtin_fmaf(x2, a, b); x3 = __builtin_fmaf(x3, a, b);
-            x4 = __builtin_fmaf(x4, a, b); x5 = __builtin_fmaf(x5, a, b); x6 = __builtin_fmaf(x6, a, b); x7 = __builtin_fmaf(x7, a, b);
-        }
+        for (int k = 0; k < 8; ++k) { GX_FMA1(x0) GX_FMA1(x1) GX_FMA1(x2) GX_FMA1(x3) GX_FMA1(x4) GX_FMA1(x5) GX_FMA1(x6) GX_FMA1(x7) }
     }
+#undef GX_FMA1
     out[blockIdx.x * blockDim.x + threadIdx.x] = ((x0 + x1) + (x2 + x3)) + ((x4 + x5) + (x6 + x7));
 }
 // Gather-rate probe: every lane reads the 8 dwordx4 of its own pseudo-random 128-byte record (a BVH node visit without the arithmetic),
@@ -521,6 +531,8 @@ static int count_local_rows(const gnxr_render_params *p) {
     return rows;
 }
 
+static thread_local bool g_reserve_only = false;   // gnxr_render_reserve: render_one stops after its allocations
+
 // One device: the wavefront loop over the rows `pin` assigns to this shard, on the device the scene's tables live on.
 static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba_out, void *hip_stream, gnxr_stats *stats) {
     if (!s || !pin || !d_rgba_out) { set_error("null argument"); return GNXR_ERR_INVALID; }
@@ -657,6 +669,7 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
         pa.sh_o = s->sh_o.p; pa.sh_d = s->sh_d.p; pa.sh_X = s->sh_X.p; pa.mis_o = s->mis_o.p; pa.mis_d = s->mis_d.p; pa.mis_Y = s->mis_Y.p;
     }
 
+    if (g_reserve_only) { if (stats) memset(stats, 0, sizeof(*stats)); return GNXR_OK; }
     HIP_TRY(hipMemsetAsync(s->accum.p, 0, sizeof(float4) * r.npix, stream));
     HIP_TRY(hipMemsetAsync(s->counters.p, 0, sizeof(Counters), stream));
     struct EventPair {   // destroyed on every exit path
@@ -1051,7 +1064,9 @@ static int render_sharded(gnxr_scene *s, const gnxr_render_params *pin, void *d_
     int rc = s->bind();
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(caller));   // the image must be safe to write from the other devices' streams
+    const bool reserve_only = g_reserve_only;   // (thread-local: handed to the worker threads)
     auto worker = [&](int i) {
+        g_reserve_only = reserve_only;
         gnxr_scene *r = i == 0 ? s : s->replicas[i - 1].get();
         gnxr_render_params p = base;   // rows y == shard_index (mod shard_count) of the caller, every nd-th of them
         p.shard_index = base.shard_index + base.shard_count * i;
@@ -1060,7 +1075,7 @@ static int render_sharded(gnxr_scene *s, const gnxr_render_params *pin, void *d_
         void *dst = d_rgba_out;
         if (rc_ == GNXR_OK && i > 0) { rc_ = r->shard_out.alloc(npx); dst = r->shard_out.p; }
         if (rc_ == GNXR_OK) rc_ = render_one(r, &p, dst, i == 0 ? hip_stream : nullptr, &sts[i]);
-        if (rc_ == GNXR_OK && i > 0) {
+        if (rc_ == GNXR_OK && i > 0 && !reserve_only) {
             // rows p.shard_index, + p.shard_count, ...: one strided copy into the primary's image (UVA: the runtime routes it over the peer link)
             const int first = p.shard_index, step = p.shard_count;
             const int rows = first < base.height ? (base.height - first + step - 1) / step : 0;
@@ -1098,6 +1113,17 @@ static int render_sharded(gnxr_scene *s, const gnxr_render_params *pin, void *d_
 
 int gnxr_render_device(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba_out, void *hip_stream, gnxr_stats *stats) {
     return render_sharded(s, pin, d_rgba_out, hip_stream, stats);
+}
+
+// Allocates the path state a render with these parameters needs (on every device of the handle) without rendering: a caller that times
+// its renders -- or a viewer that must not stall in its first frame -- pays for the allocation up front.  State only ever grows.
+int gnxr_render_reserve(gnxr_scene *s, const gnxr_render_params *pin) {
+    if (!s || !pin) { set_error("null argument"); return GNXR_ERR_INVALID; }
+    g_reserve_only = true;
+    int dummy = 0;   // never written: render_one returns before anything touches the output
+    const int rc = render_sharded(s, pin, &dummy, nullptr, nullptr);
+    g_reserve_only = false;
+    return rc;
 }
 
 int gnxr_render(gnxr_scene *s, const gnxr_render_params *p, float *rgba_out, gnxr_stats *stats) {

@@ -354,6 +354,11 @@ int gnxr_render(gnxr_scene *scene, const gnxr_render_params *params, float *rgba
 int gnxr_render_device(gnxr_scene *scene, const gnxr_render_params *params, void *d_rgba_out,
                        void *hip_stream, gnxr_stats *stats);
 
+/* Allocates, on every device of the handle, the path state a render with these parameters needs, without rendering anything: the
+ * first gnxr_render / gnxr_render_device call with them then runs at its steady-state speed (the reference has no counterpart: its
+ * per-thread MemoryArena grows inside Render, core/Integrator.cpp:262).  State buffers only ever grow; they are released with the scene. */
+int gnxr_render_reserve(gnxr_scene *scene, const gnxr_render_params *params);
+
 /* -- Aggregate seam (replaces Scene::Intersect / Scene::IntersectP), batched ------------ */
 int gnxr_trace_closest(gnxr_scene *scene, const gnxr_ray *rays, int64_t n, gnxr_hit *hits);
 int gnxr_trace_any(gnxr_scene *scene, const gnxr_ray *rays, int64_t n, uint8_t *occluded);
