@@ -415,10 +415,16 @@ struct Bsdf {
         for (int i = 0; i < mat->n_lobes; ++i) if (matches(mat->lobes[i].type, flags)) ++n;
         return n;
     }
+    // The diffuse class (LM_DIFFUSE) holds materials of at most ONE lobe, a Lambert or Oren-Nayar reflection (compile_material): lobe
+    // counting, choice and the sums over "the other lobes" of Reflection.cpp:440-563 reduce to that lobe -- same arithmetic, without the
+    // loops over mat->lobes[i].type (each a dependent table read).
+    static constexpr bool kSingle = (LM == LM_DIFFUSE);
+    static constexpr int kSingleType = BSDF_REFLECTION | BSDF_DIFFUSE;
     GX_DEV Spec f(V3 woW, V3 wiW, int flags) const {
         V3 wi = to_local(wiW), wo = to_local(woW);
         if (wo.z == 0) return Spec(0.f);
         bool refl = dot(wiW, ng) * dot(woW, ng) > 0;
+        if (kSingle) return (mat->n_lobes > 0 && refl && matches(kSingleType, flags)) ? lobe_f<LM>(mat->lobes[0], wo, wi) : Spec(0.f);
         return sum_f(wo, wi, flags, refl);
     }
     // sum of lobe_f over the lobes that match `flags` and the reflect / transmit side, in lobe order (Reflection.cpp:458-463).
@@ -444,6 +450,7 @@ struct Bsdf {
         if (mat->n_lobes == 0) return 0.f;
         V3 wo = to_local(woW), wi = to_local(wiW);
         if (wo.z == 0) return 0.f;
+        if (kSingle) return matches(kSingleType, flags) ? 0.f + lobe_pdf<LM>(mat->lobes[0], wo, wi) : 0.f;   // (p = 0; p += pdf; p / 1)
         float p = 0.f;
         int matching = 0;
         for (int i = 0; i < mat->n_lobes; ++i) {
@@ -453,6 +460,21 @@ struct Bsdf {
         return matching > 0 ? p / matching : 0.f;
     }
     GX_DEV Spec sample_f(V3 woW, V3 *wiW, float u0, float u1, float *pdf, int flags, int *sampledType) const {
+        if (kSingle) {   // matchingComps == 1: comp = 0, uRemapped = min(u[0] * 1 - 0, OneMinusEpsilon), no other lobes' pdfs, f = that lobe's f if it reflects
+            *sampledType = 0;
+            if (mat->n_lobes == 0 || !matches(kSingleType, flags)) { *pdf = 0; return Spec(0.f); }
+            const DLobe &bx = mat->lobes[0];
+            const float ur0 = fminf(u0 * 1 - 0, GX_ONE_MINUS_EPS);
+            V3 wi, wo = to_local(woW);
+            *pdf = 0;
+            if (wo.z == 0) return Spec(0.f);
+            *sampledType = kSingleType;
+            (void)lobe_sample<LM>(bx, wo, &wi, ur0, u1, pdf, sampledType, false);
+            if (*pdf == 0) { *sampledType = 0; return Spec(0.f); }
+            *wiW = to_world(wi);
+            const bool refl = dot(*wiW, ng) * dot(woW, ng) > 0;
+            return refl ? lobe_f<LM>(bx, wo, wi) : Spec(0.f);
+        }
         int matching = num_components(flags);
         *sampledType = 0;
         if (matching == 0) { *pdf = 0; return Spec(0.f); }

@@ -481,6 +481,8 @@ static bool compile_material(const gnxr_material &m, DMaterial *out, bool allowM
                  !out->lobes[i].disney_g) ? 1 : 2;
         out->shade_class = std::max(out->shade_class, c);
     }
+    // class 0 promises the diffuse kernels AT MOST ONE lobe (Lambert or Oren-Nayar reflection): Bsdf<LM_DIFFUSE> then needs no lobe loops
+    if (out->shade_class == 0 && out->n_lobes > 1) out->shade_class = 1;
     if (textured) out->shade_class = 3;   // own shade queue: its kernel evaluates the textures and rebuilds the lobe list per hit
     return true;
 }
