@@ -965,8 +965,8 @@ else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, slds, stream,
                     if (timing) timer.begin(1, stream);
                     const long long mwaves = (long long)blocks * (kBlock / 64);
                     const int mchunk = (int)std::min<long long>(kMediaChunk, std::max<long long>(64, ((n_media + mwaves - 1) / mwaves + 63) / 64 * 64));
-                    if (count_wide) hipLaunchKernelGGL(k_vol_media<true>, dim3(blocks), dim3(kBlock), 0, stream, sc, mt, pa, va, q_media, n_media, &dctr->cursor, mchunk, dctr);
-                    else hipLaunchKernelGGL(k_vol_media<false>, dim3(blocks), dim3(kBlock), 0, stream, sc, mt, pa, va, q_media, n_media, &dctr->cursor, mchunk, dctr);
+                    if (count_wide) hipLaunchKernelGGL(k_vol_media<true>, dim3(blocks), dim3(kBlock), (size_t)kVmRecDwords * kVmStride * sizeof(int), stream, sc, mt, pa, va, q_media, n_media, &dctr->cursor, mchunk, dctr);
+                    else hipLaunchKernelGGL(k_vol_media<false>, dim3(blocks), dim3(kBlock), (size_t)kVmRecDwords * kVmStride * sizeof(int), stream, sc, mt, pa, va, q_media, n_media, &dctr->cursor, mchunk, dctr);
                     media_segments += (unsigned long long)n_media;
                     if (timing) timer.end(stream);
                     ++launches;

@@ -82,13 +82,19 @@ GX_DEV int hit_medium(const DScene &sc, const DMediaTables &mt, int leaf, int ra
 constexpr int kMediaChunk = 256;   // most paths a wave takes per global atomic (smaller for thin launches, chosen by the host)
 
 // COUNT: add the number of tracking-loop iterations to ctr->media_steps (profiling run; gnxr_set_profiling bit 2)
+constexpr int kVmRecDwords = 12;                 // LDS record of a set-up medium segment (k_vol_media)
+constexpr int kVmStride = (kBlock / 64) * 64;     // ints per record field per block
 template <bool COUNT>
 __global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt, PathArrays pa, VolArrays va, const int *__restrict__ queue, int n, unsigned int *cursor, int chunk, Counters *ctr) {
+    // LDS: kVmRecDwords x (4 waves x 64) ints -- the set-up segments a wave has parked (SoA: field * kVmStride + wave * 64 + slot)
+    extern __shared__ int vm_smem[];
+    lds_int *const rq = (lds_int *)&vm_smem[(threadIdx.x >> 6) * 64];
     unsigned long long cntSteps = 0;
     const int lane = __lane_id();
     const unsigned total = (unsigned)n;
     unsigned poolBase = 0, poolCount = 0;
     bool exhausted = false;
+    unsigned rqHead = 0, rqCount = 0;   // wave-uniform: set-up segments waiting in LDS
     // per-lane tracking state (grid media; homogeneous media are closed-form and finish at set-up)
     int path = -1, dim = 0, nx = 0, ny = 0, nz = 0, medium = -1;
     bool sampleMode = false;
@@ -102,78 +108,117 @@ __global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt
         bool need = path < 0;
         unsigned long long needMask = __ballot(need);
         if (needMask) {
-            if (poolCount == 0 && !exhausted) {
-                unsigned base = 0;
-                if (lane == 0) base = atomicAdd(cursor, (unsigned)chunk);
-                base = __shfl(base, 0);
-                if (base >= total) exhausted = true;
-                else { poolBase = base; poolCount = min((unsigned)chunk, total - base); }
-            }
-            if (poolCount > 0) {
-                unsigned rank = (unsigned)__popcll(needMask & ((1ull << lane) - 1ull));
-                unsigned take = min(poolCount, (unsigned)__popcll(needMask));
-                if (need && rank < take) {
-                    const int p = queue ? queue[poolBase + rank] : (int)(poolBase + rank);
-                    int4 vs = va.vs[p];
-                    float4 o4 = pa.ray_o[p], d4 = pa.ray_d[p];
-                    V3 ro(o4.x, o4.y, o4.z), rd(d4.x, d4.y, d4.z);
-                    const int med = __float_as_int(d4.w);
-                    const int leaf = pa.hit[p];
-                    bool found = leaf != -1;
-                    int triMat = -1;
-                    TriHit h;
-                    if (leaf < -1) {
-                        const DSphere &sph = sc.spheres[-2 - leaf];
-                        triMat = sph.material;
-                        found = sphere_test(sph, ro, rd, o4.w, &h.t);
-                    } else if (found) {
-                        const float4 *q = reinterpret_cast<const float4 *>(sc.tris + leaf);
-                        float4 a = q[0], b = q[1], c = q[2];
-                        triMat = __float_as_int(b.w);
-                        found = tri_test(V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), ro, rd, o4.w, &h);
-                    }
-                    // VisibilityTester::Tr returns 0 at an opaque hit before it evaluates the segment's transmittance
-                    const bool skip = med < 0 || (vs.x == VS_SHADOW && found && triMat >= 0);
-                    if (!skip) {
-                        const float tSeg = found ? h.t : o4.w;
-                        const DMedium &m = mt.media[med];
-                        SampleStream ss(sc.st, pa.meta[p].x, vs.y);
-                        if (m.type == GNXR_MEDIUM_HOMOGENEOUS) {
-                            float4 res;
-                            if (vs.x == VS_MAIN) {
-                                bool valid; float tt = -1.f;
-                                Spec w = medium_sample(mt, med, ro, rd, tSeg, ss, &valid, &tt);
-                                res = make_float4(w.r, w.g, w.b, valid ? tt : -1.f);
+            // A segment's set-up (the triangle re-test that gives its length, the ray in medium space, the clip against the grid's box:
+            // ~350 instructions) used to run for whichever lanes had just finished -- one or two of 64 in nearly every iteration of a
+            // loop whose segments take ~20 tracking steps.  As in k_trace4 it now runs in batches: when the wave's ready queue is empty
+            // ALL lanes set one work item up each (lanes in the middle of a segment too: their tracking state is untouched) and park the
+            // grid-medium segments in LDS; an idle lane then just pops a record.
+            if (rqCount == 0) {
+                if (poolCount == 0 && !exhausted) {
+                    unsigned base = 0;
+                    if (lane == 0) base = atomicAdd(cursor, (unsigned)chunk);
+                    base = __shfl(base, 0);
+                    if (base >= total) exhausted = true;
+                    else { poolBase = base; poolCount = min((unsigned)chunk, total - base); }
+                }
+                if (poolCount > 0) {
+                    const unsigned take = min(poolCount, 64u);
+                    bool valid = false;
+                    int rPath = -1, rMed = 0, rDim = 0;
+                    uint32_t rIndex = 0;
+                    V3 rO, rD;
+                    float rT = 0, rTMax = 0;
+                    if ((unsigned)lane < take) {
+                        const int p = queue ? queue[poolBase + lane] : (int)(poolBase + lane);
+                        int4 vs = va.vs[p];
+                        float4 o4 = pa.ray_o[p], d4 = pa.ray_d[p];
+                        V3 ro(o4.x, o4.y, o4.z), rd(d4.x, d4.y, d4.z);
+                        const int med = __float_as_int(d4.w);
+                        const int leaf = pa.hit[p];
+                        bool found = leaf != -1;
+                        int triMat = -1;
+                        TriHit h;
+                        if (leaf < -1) {
+                            const DSphere &sph = sc.spheres[-2 - leaf];
+                            triMat = sph.material;
+                            found = sphere_test(sph, ro, rd, o4.w, &h.t);
+                        } else if (found) {
+                            const float4 *q = reinterpret_cast<const float4 *>(sc.tris + leaf);
+                            float4 a = q[0], b = q[1], c = q[2];
+                            triMat = __float_as_int(b.w);
+                            found = tri_test(V3(a.x, a.y, a.z), V3(b.x, b.y, b.z), V3(c.x, c.y, c.z), ro, rd, o4.w, &h);
+                        }
+                        // VisibilityTester::Tr returns 0 at an opaque hit before it evaluates the segment's transmittance
+                        const bool skip = med < 0 || (vs.x == VS_SHADOW && found && triMat >= 0);
+                        if (!skip) {
+                            const float tSeg = found ? h.t : o4.w;
+                            const DMedium &m = mt.media[med];
+                            SampleStream ss(sc.st, pa.meta[p].x, vs.y);
+                            if (m.type == GNXR_MEDIUM_HOMOGENEOUS) {
+                                float4 res;
+                                if (vs.x == VS_MAIN) {
+                                    bool ok; float tt = -1.f;
+                                    Spec w = medium_sample(mt, med, ro, rd, tSeg, ss, &ok, &tt);
+                                    res = make_float4(w.r, w.g, w.b, ok ? tt : -1.f);
+                                } else {
+                                    Spec w = medium_tr(mt, med, ro, rd, tSeg, ss);
+                                    res = make_float4(w.r, w.g, w.b, -1.f);
+                                }
+                                va.mres[p] = res;
+                                reinterpret_cast<int *>(&va.vs[p])[1] = ss.dim;
                             } else {
-                                Spec w = medium_tr(mt, med, ro, rd, tSeg, ss);
-                                res = make_float4(w.r, w.g, w.b, -1.f);
-                            }
-                            va.mres[p] = res;
-                            reinterpret_cast<int *>(&va.vs[p])[1] = ss.dim;
-                        } else {
-                            // GridDensityMedium::Sample / Tr set-up, GridDensityMedium.cpp:33-40, 59-66
-                            float rtMax, tMin, tEnd;
-                            V3 oo, dd;
-                            xform_ray(m.w2m, ro, normalize(rd), tSeg * length(rd), &oo, &dd, &rtMax);
-                            if (!unit_box_intersect(oo, dd, rtMax, &tMin, &tEnd)) {
-                                va.mres[p] = make_float4(1.f, 1.f, 1.f, -1.f);
-                            } else {
-                                path = p; medium = med; sampleMode = vs.x == VS_MAIN;
-                                index = ss.index; dim = ss.dim; cachedDim = -1;
-                                o = oo; d = dd; t = tMin; tMax = tEnd; Tr = 1;
-                                nx = m.nx; ny = m.ny; nz = m.nz;
-                                invMaxDensity = m.inv_max_density;
-                                stepScale = m.sigma_t;
-                                dens = mt.density + m.density_offset;
+                                // GridDensityMedium::Sample / Tr set-up, GridDensityMedium.cpp:33-40, 59-66
+                                float rtMax, tMin, tEnd;
+                                V3 oo, dd;
+                                xform_ray(m.w2m, ro, normalize(rd), tSeg * length(rd), &oo, &dd, &rtMax);
+                                if (!unit_box_intersect(oo, dd, rtMax, &tMin, &tEnd)) {
+                                    va.mres[p] = make_float4(1.f, 1.f, 1.f, -1.f);
+                                } else {
+                                    valid = true;
+                                    rPath = p; rMed = med | (vs.x == VS_MAIN ? 0x10000 : 0);
+                                    rIndex = ss.index; rDim = ss.dim;
+                                    rO = oo; rD = dd; rT = tMin; rTMax = tEnd;
+                                }
                             }
                         }
                     }
+                    const unsigned long long vmask = __ballot(valid);
+                    if (valid) {
+                        lds_int *q = rq + __popcll(vmask & ((1ull << lane) - 1ull));
+                        q[0 * kVmStride] = rPath; q[1 * kVmStride] = rMed; q[2 * kVmStride] = (int)rIndex; q[3 * kVmStride] = rDim;
+                        q[4 * kVmStride] = __float_as_int(rO.x); q[5 * kVmStride] = __float_as_int(rO.y); q[6 * kVmStride] = __float_as_int(rO.z);
+                        q[7 * kVmStride] = __float_as_int(rD.x); q[8 * kVmStride] = __float_as_int(rD.y); q[9 * kVmStride] = __float_as_int(rD.z);
+                        q[10 * kVmStride] = __float_as_int(rT); q[11 * kVmStride] = __float_as_int(rTMax);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // the records are read by other lanes of this wave
+                    rqCount = (unsigned)__popcll(vmask); rqHead = 0;
+                    poolBase += take; poolCount -= take;
                 }
-                poolBase += take; poolCount -= take;
+            }
+            if (rqCount > 0) {
+                const unsigned rank = (unsigned)__popcll(needMask & ((1ull << lane) - 1ull));
+                if (need && rank < rqCount) {
+                    const lds_int *q = rq + rqHead + rank;
+                    path = q[0 * kVmStride];
+                    const int pm = q[1 * kVmStride];
+                    medium = pm & 0xffff; sampleMode = (pm & 0x10000) != 0;
+                    index = (uint32_t)q[2 * kVmStride]; dim = q[3 * kVmStride]; cachedDim = -1;
+                    o = V3(__int_as_float(q[4 * kVmStride]), __int_as_float(q[5 * kVmStride]), __int_as_float(q[6 * kVmStride]));
+                    d = V3(__int_as_float(q[7 * kVmStride]), __int_as_float(q[8 * kVmStride]), __int_as_float(q[9 * kVmStride]));
+                    t = __int_as_float(q[10 * kVmStride]); tMax = __int_as_float(q[11 * kVmStride]); Tr = 1;
+                    const DMedium &m = mt.media[medium];
+                    nx = m.nx; ny = m.ny; nz = m.nz;
+                    invMaxDensity = m.inv_max_density;
+                    stepScale = m.sigma_t;
+                    dens = mt.density + m.density_offset;
+                }
+                const unsigned tk = min(rqCount, (unsigned)__popcll(needMask));
+                rqHead += tk; rqCount -= tk;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");       // all reads of the queue precede the next batch's writes
             }
         }
         if (__ballot(path >= 0) == 0) {
-            if (exhausted && poolCount == 0) break;
+            if (exhausted && poolCount == 0 && rqCount == 0) break;
             continue;
         }
         // ---------------- one tracking iteration for every active lane ----------------
