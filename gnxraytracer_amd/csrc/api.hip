@@ -614,9 +614,19 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
     // the merged tails give back.
     static const bool pipeline = getenv("GNXR_PIPELINE") ? atoi(getenv("GNXR_PIPELINE")) != 0 : true;   // experiment switch: 0 = one pass at a time
     const bool path_int = !whitted && !volpath;
-    const int in_flight = (path_int && pipeline && k < nsamples) ? 2 : 1;
+    int in_flight = (path_int && pipeline && k < nsamples) ? 2 : 1;
     const int kh = k;
     const size_t half = (size_t)r.npix * kh;
+    if (in_flight == 2) {
+        // two passes in flight need twice the state: fall back to one at a time when that does not fit the 32-bit work indices or the
+        // free HBM (~230 B per path slot beyond what this handle already holds), rather than refusing a pass size that used to render
+        size_t free_b = 0, total_b = 0;
+        const unsigned long long want = 2ull * half, held = (unsigned long long)s->ray_o.n;
+        const bool idx_ok = want < (1ull << 31) && want * 3ull < (1ull << 32);
+        bool mem_ok = true;
+        if (want > held && hipMemGetInfo(&free_b, &total_b) == hipSuccess) mem_ok = (want - held) * 230ull < (unsigned long long)free_b - (unsigned long long)free_b / 16;
+        if (!idx_ok || !mem_ok) in_flight = 1;
+    }
     size_t cap = (size_t)in_flight * half;
     // k_trace's work cursor is 32-bit unsigned: continuation rays + two NEE items per record; record slots are `record * cap + path`
     {

@@ -551,6 +551,21 @@ def test_pipelined_passes_equal_one_pass(gpu, name):
     assert biteq(a, c) and (sa["rays_closest"], sa["rays_any"]) == (sc_["rays_closest"], sc_["rays_any"])
 
 
+def test_render_reserve(gpu):
+    """gnxr_render_reserve allocates the state of a render without rendering: it succeeds for every integrator, leaves results unchanged,
+    and rejects the parameters gnxr_render rejects."""
+    b = scenes.cornell()
+    scene = gpu.Scene(b)
+    for integ in (gpu.PathIntegrator(8, 1.0, "spatial"), gpu.VolPathIntegrator(8, 1.0, "spatial"), gpu.WhittedIntegrator(5)):
+        integ.Reserve(scene, 40, 30, 6, samples_per_pass=2)
+    integ = gpu.PathIntegrator(8, 1.0, "spatial")
+    img, st = integ.Render(scene, 40, 30, 6, samples_per_pass=2)
+    oimg, ost = ol.OracleScene(b).render(integ, 40, 30, 6)
+    assert biteq(img, oimg) and (st["rays_closest"], st["rays_any"]) == (ost["rays_closest"], ost["rays_any"])
+    with pytest.raises(Exception):
+        integ.Reserve(scene, 0, 30, 6)
+
+
 def test_edge_cases(gpu):
     scene = gpu.Scene(scenes.cornell())
     img, st = gpu.PathIntegrator(0).Render(scene, 8, 8, 2)               # maxDepth 0
