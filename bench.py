@@ -107,6 +107,19 @@ def spawn_ranks(n, argv):
     return subprocess.call(cmd, env=env)
 
 
+def call_ranges(i0, nsteps, sps, spp):
+    """(s0, s1, steps) of the library calls that render steps i0 .. i0+nsteps-1 -- step i covers samples [i*sps, (i+1)*sps) of every pixel,
+    modulo the sampler's range `spp`: one call per contiguous stretch of the Halton sequence (pure function; tests/test_host_logic.py)"""
+    out = []
+    i = i0
+    while i < i0 + nsteps:
+        s0 = (i * sps) % spp
+        m = min(i0 + nsteps - i, max(1, (spp - s0) // sps))   # steps up to the end of the sample range
+        out.append((s0, min(s0 + m * sps, spp), m))
+        i += m
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ CPU baseline
 def host_cores():
     """CPU cores this job can actually use: the affinity mask, capped by the cgroup's CPU quota when there is one (a 1-GPU box hands a
@@ -357,13 +370,7 @@ def main():
     fuse = args.fuse_steps if args.fuse_steps > 0 else world
 
     def calls_of(i0, nsteps):
-        """(s0, s1) sample ranges of the library calls that render steps i0 .. i0+nsteps-1: one per contiguous range of the Halton sequence"""
-        i = i0
-        while i < i0 + nsteps:
-            s0 = (i * sps) % args.spp
-            m = min(i0 + nsteps - i, max(1, (args.spp - s0) // sps))   # steps up to the end of the Halton sample range
-            yield s0, min(s0 + m * sps, args.spp), m
-            i += m
+        return call_ranges(i0, nsteps, sps, args.spp)
 
     # path state for the largest call of the run is allocated before the warm-up (gnxr_render_reserve), so that no timed step grows it
     for s0_, s1_, _ in list(calls_of(0, args.warmup)) + list(calls_of(0, args.steps)):

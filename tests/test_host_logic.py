@@ -249,3 +249,18 @@ def test_volume_file_reader(gx, tmp_path):
         q.write_text(bad)
         with pytest.raises(gx.GnxrError):
             b.add_volume_file(str(q))
+
+
+def test_bench_call_ranges():
+    """bench.py submits the steps of a contiguous sample range as one library call: the ranges tile the requested steps exactly, never
+    cross the end of the Halton range, and wrap around it."""
+    import bench
+    assert bench.call_ranges(0, 8, 128, 1024) == [(0, 1024, 8)]
+    assert bench.call_ranges(0, 20, 128, 1024) == [(0, 1024, 8), (0, 1024, 8), (0, 512, 4)]
+    assert bench.call_ranges(0, 5, 128, 1024) == [(0, 640, 5)]
+    assert bench.call_ranges(6, 4, 128, 1024) == [(768, 1024, 2), (0, 256, 2)]
+    assert bench.call_ranges(0, 1, 256, 256) == [(0, 256, 1)]
+    assert bench.call_ranges(0, 3, 100, 256) == [(0, 200, 2), (200, 256, 1)]   # a range the step does not divide: the last call is short
+    for i0, n, sps, spp in ((0, 7, 64, 1024), (3, 40, 128, 1024), (0, 9, 32, 96)):
+        r = bench.call_ranges(i0, n, sps, spp)
+        assert sum(m for _, _, m in r) == n and all(0 <= a < b <= spp for a, b, _ in r)
