@@ -373,10 +373,11 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
 #undef GX_SLAB2
 #define GX_SLAB3(C, BIT)
 #else
+// (rounding is monotone and k > 0, so the smallest of the three k-scaled exits is the k-scaled smallest exit: one multiply instead of three)
 #define GX_SLAB3(C, BIT)                                                                                       \
     {                                                                                                          \
         const float e = fmaxf(fmaxf((nX.C - ro.x) * inv.x, (nY.C - ro.y) * inv.y), (nZ.C - ro.z) * inv.z);      \
-        const float x = fminf(fminf(((fX.C - ro.x) * inv.x) * k, ((fY.C - ro.y) * inv.y) * k), ((fZ.C - ro.z) * inv.z) * k); \
+        const float x = fminf(fminf((fX.C - ro.x) * inv.x, (fY.C - ro.y) * inv.y), (fZ.C - ro.z) * inv.z) * k;  \
         hitMask |= (e <= x && e < tMax && x > 0.f) ? (BIT) : 0u;                                                \
     }
 #endif
