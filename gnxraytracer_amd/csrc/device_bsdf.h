@@ -180,9 +180,10 @@ GX_DEV Spec lobe_f(const DLobe &l, V3 wo, V3 wi) {
             float dCos = cosPhiI * cosPhiO + sinPhiI * sinPhiO;
             maxCos = fmaxf(0.f, dCos);
         }
-        float sinAlpha, tanBeta;
-        if (abs_cos_theta(wi) > abs_cos_theta(wo)) { sinAlpha = sinThetaO; tanBeta = sinThetaI / abs_cos_theta(wi); }
-        else { sinAlpha = sinThetaI; tanBeta = sinThetaO / abs_cos_theta(wo); }
+        // (one division for both branches of Reflection.cpp:189-195)
+        const bool iBig = abs_cos_theta(wi) > abs_cos_theta(wo);
+        const float sinAlpha = iBig ? sinThetaO : sinThetaI;
+        const float tanBeta = (iBig ? sinThetaI : sinThetaO) / (iBig ? abs_cos_theta(wi) : abs_cos_theta(wo));
         return spec3(l.R) * GX_INV_PI * (l.A + l.B * maxCos * sinAlpha * tanBeta);
     }
     break;

@@ -277,9 +277,11 @@ GX_DEV LdsSampler lds_sampler_fill(const DSamplerTables &t, int dims, int n_perm
 GX_DEV void concentric_sample_disk(float u0, float u1, float *dx, float *dy) {
     float ox = 2.f * u0 - 1, oy = 2.f * u1 - 1;
     if (ox == 0 && oy == 0) { *dx = 0; *dy = 0; return; }
-    float theta, r;
-    if (fabsf(ox) > fabsf(oy)) { r = ox; theta = GX_PI_OVER_4 * (oy / ox); }
-    else { r = oy; theta = GX_PI_OVER_2 - GX_PI_OVER_4 * (ox / oy); }
+    // (one division for both branches of Sampling.cpp:95-101: the lanes of a wave split evenly between them)
+    const bool xBig = fabsf(ox) > fabsf(oy);
+    const float q = (xBig ? oy : ox) / (xBig ? ox : oy);
+    const float r = xBig ? ox : oy;
+    const float theta = xBig ? GX_PI_OVER_4 * q : GX_PI_OVER_2 - GX_PI_OVER_4 * q;
     float st, ct;
     gx_sincos(theta, &st, &ct);
     *dx = r * ct;
