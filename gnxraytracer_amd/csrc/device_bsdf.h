@@ -205,7 +205,7 @@ GX_DEV Spec lobe_f(const DLobe &l, V3 wo, V3 wi) {
             if (same_hemisphere(wo, wi)) return Spec(0.f);
             cosThetaO = cos_theta(wo); cosThetaI = cos_theta(wi);
             if (cosThetaI == 0 || cosThetaO == 0) return Spec(0.f);
-            eta = cos_theta(wo) > 0 ? (l.etaB / l.etaA) : (l.etaA / l.etaB);
+            { const bool up = cos_theta(wo) > 0; eta = (up ? l.etaB : l.etaA) / (up ? l.etaA : l.etaB); }   // one division for both sides
             wh = normalize(wo + wi * eta);
             if (wh.z < 0) wh = -wh;
             if (dot(wo, wh) * dot(wi, wh) > 0) return Spec(0.f);
@@ -285,7 +285,8 @@ GX_DEV float lobe_pdf(const DLobe &l, V3 wo, V3 wi) {
             scale = 4 * dot(wo, wh);
         } else {
             if (same_hemisphere(wo, wi)) return 0.f;
-            float eta = cos_theta(wo) > 0 ? (l.etaB / l.etaA) : (l.etaA / l.etaB);
+            const bool up = cos_theta(wo) > 0;
+            float eta = (up ? l.etaB : l.etaA) / (up ? l.etaA : l.etaB);
             wh = normalize(wo + wi * eta);
             if (dot(wo, wh) * dot(wi, wh) > 0) return 0.f;
             float sqrtDenom = dot(wo, wh) + eta * dot(wi, wh);
@@ -362,7 +363,8 @@ GX_DEV Spec lobe_sample(const DLobe &l, V3 wo, V3 *wi, float u0, float u1, float
             if (!same_hemisphere(wo, *wi)) return Spec(0.f);
             *pdf = tr_pdf(l.alphax, l.alphay, wo, wh) / (4 * dot(wo, wh));
         } else {
-            float eta = cos_theta(wo) > 0 ? (l.etaA / l.etaB) : (l.etaB / l.etaA);
+            const bool up = cos_theta(wo) > 0;
+            float eta = (up ? l.etaA : l.etaB) / (up ? l.etaB : l.etaA);
             if (!refract(wo, wh, eta, wi)) return Spec(0.f);
             *pdf = lobe_pdf<LM>(l, wo, *wi);
         }
