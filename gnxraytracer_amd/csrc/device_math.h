@@ -561,8 +561,11 @@ GX_DEV bool is_zero(V3 v) { return v.x == 0 && v.y == 0 && v.z == 0; }
 GX_DEV float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
 GX_DEV float lerpf(float t, float a, float b) { return (1 - t) * a + t * b; }
 GX_DEV void coordinate_system(V3 v1, V3 *v2, V3 *v3) {  // Geometry.h:988-995
-    if (fabsf(v1.x) > fabsf(v1.y)) *v2 = V3(-v1.z, 0, v1.x) / gx_sqrt(v1.x * v1.x + v1.z * v1.z);
-    else *v2 = V3(0, v1.z, -v1.y) / gx_sqrt(v1.y * v1.y + v1.z * v1.z);
+    // (one square root and one division for both branches: the operands are selected first)
+    const bool xBig = fabsf(v1.x) > fabsf(v1.y);
+    const float a = xBig ? v1.x : v1.y;
+    const V3 num = xBig ? V3(-v1.z, 0, v1.x) : V3(0, v1.z, -v1.y);
+    *v2 = num / gx_sqrt(a * a + v1.z * v1.z);
     *v3 = cross(v1, *v2);
 }
 
