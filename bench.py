@@ -37,6 +37,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, MI355X_MICROARCH.md
+# FP32 vector peak of the guide: 157.3 TFLOP/s = 256 CUs x 4 SIMDs x one wave64 FMA every 2 cycles at 2.4 GHz = 1228.8 G wave64 instructions/s
+VALU_SPEC_GWIPS = 1228.8
+VALU_SPEC_SIMDS = 1024
 WORKLOADS = ("cfg3", "cfg4", "cfg5")
 
 
@@ -57,6 +60,9 @@ def parse(argv=None):
     ap.add_argument("--save-image", type=str, default="")
     ap.add_argument("--fuse-steps", type=int, default=0, help="steps a rank submits as one pass (default: the number of ranks)")
     ap.add_argument("--workload", choices=WORKLOADS, default="cfg3")
+    ap.add_argument("--spp-per-pass", type=int, default=0, help="samples per pixel of one sub-pass of the library's path loop (0: the library's choice)")
+    ap.add_argument("--passes-in-flight", type=int, default=0, help="sub-passes the path loop keeps alive at once (0: the library's choice)")
+    ap.add_argument("--no-also", action="store_true", help="default cfg3 run only: skip the short cfg4 / cfg5 runs appended under \"also\"")
     args = ap.parse_args(argv)
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
@@ -174,28 +180,49 @@ def cpu_baseline(builder, args):
     port = {"value": rays / st["seconds_render"] / 1e6, "unit": "Mrays/s", "cores": cores, "cores_detail": core_info, "kind": "port",
             "sample": f"{w}x{h} px, samples 0..{spp - 1} of HaltonSampler({args.spp}), same scene; {rays} rays in {st['seconds_render']:.1f} s; "
                       f"oracle = CPU restatement of the reference path, OpenMP over pixel columns (core/Integrator.cpp:256) on the {cores} cores this job may use, no printf"}
+    def one_thread(run, label):
+        """the same renderer on ONE thread, on a quarter of the pixels and as many samples as ~6 s buy (BASELINE.md asks for both figures)"""
+        w1, h1 = max(16, w // 2), max(16, h // 2)
+        t0_ = time.perf_counter()
+        run(w1, h1, 1, 1)
+        t1_ = max(1e-3, time.perf_counter() - t0_)
+        spp1 = int(max(1, min(args.spp, 6.0 / t1_)))
+        rays1, secs1 = run(w1, h1, spp1, 1)
+        return {"value": rays1 / secs1 / 1e6, "unit": "Mrays/s", "cores": 1, "kind": label,
+                "sample": f"{w1}x{h1} px, {spp1} spp, same scene; {rays1} rays in {secs1:.1f} s on one thread"}
+
+    def run_port(w_, h_, spp_, threads_):
+        _, st_ = osc.render(integ, w_, h_, args.spp, threads=threads_, spp_begin=0, spp_end=spp_)
+        return st_["rays_closest"] + st_["rays_any"], st_["seconds_render"]
+
     if not os.path.exists(ol.REF_BIN):
+        port["one_thread"] = one_thread(run_port, "port")
         return port
     try:
         import tempfile
         with tempfile.TemporaryDirectory() as td:
             sp = os.path.join(td, "scene.bin")
             ol.write_scene_file(builder, sp)
+
+            def run_ref(w_, h_, spp_, threads_):
+                raw_ = ol.run_ref(sp, "render", None, [w_, h_, spp_, args.max_depth, 1.0, 0, threads_, 1 if vol else 0])
+                cnt_ = np.frombuffer(raw_[w_ * h_ * 16:w_ * h_ * 16 + 16], np.uint64)
+                return int(cnt_[0]) + int(cnt_[1]), struct.unpack("<d", raw_[w_ * h_ * 16 + 16:w_ * h_ * 16 + 24])[0]
+
             print(f"[bench] cpu baseline: compiled reference classes, {spp} spp", file=sys.stderr, flush=True)
-            raw = ol.run_ref(sp, "render", None, [w, h, spp, args.max_depth, 1.0, 0, cores, 1 if vol else 0])
-        cnt = np.frombuffer(raw[w * h * 16:w * h * 16 + 16], np.uint64)
-        secs = struct.unpack("<d", raw[w * h * 16 + 16:w * h * 16 + 24])[0]
-        rrays = int(cnt[0]) + int(cnt[1])
+            rrays, secs = run_ref(w, h, spp, cores)
+            single = one_thread(run_ref, "reference")
         return {"value": rrays / secs / 1e6, "unit": "Mrays/s", "cores": cores, "cores_detail": core_info, "kind": "reference",
                 "sample": f"{w}x{h} px, {spp} spp (HaltonSampler({spp})), same scene; {rrays} rays in {secs:.1f} s; the reference's own classes "
                           f"(compiled from its sources) under the restated Render/Li loop, OpenMP over pixel columns on the {cores} cores this job may use, no printf",
-                "port": {"value": port["value"], "sample": port["sample"]}}
+                "one_thread": single, "port": {"value": port["value"], "sample": port["sample"]}}
     except Exception as e:   # the binary is optional: fall back to the port
         port["reference_error"] = str(e)[-120:]
         if vol:
             port["reference_note"] = ("at the volume file's own sigma_t = 100 the tracking loops pass Halton dimension 1000, where the reference "
                                       "indexes PrimeSums[] out of bounds (undefined behaviour; the compiled reference crashes here), so the "
                                       "oracle -- which wraps the dimension like the device -- is the CPU baseline for cfg 5")
+        port["one_thread"] = one_thread(run_port, "port")
         return port
 
 
@@ -255,7 +282,14 @@ def roofline(kernel, secs, launches, units, unit_name, bytes_per_unit, byte_term
         else:
             traffic = tj[kernel].get("hbm_bytes_per_launch")
         meas = traffic / avg_s / 1e9
+        raw_step = tj[kernel].get("hbm_bytes_per_step_uncorrected")
+        raw = (raw_step * steps / launches) if (steps and raw_step) else None
         hbm.update({"achieved": meas, "frac": meas / HBM_PEAK_GBS, "algorithmic_over_measured": upl * bytes_per_unit / traffic,
+                    # the two readings of the counters side by side: FETCH_SIZE as counted + WRITE_SIZE, and with the guide's x2 on the fetch side
+                    # (documented for wide streaming reads; node gathers are not that, so the x2 figure is an upper bound)
+                    "bytes_per_launch_raw": raw, "bytes_per_launch_fetch_x2": traffic,
+                    "achieved_raw": (raw / avg_s / 1e9) if raw else None, "frac_raw": (raw / avg_s / 1e9 / HBM_PEAK_GBS) if raw else None,
+                    "stale_counters": tj.get("_measured_on", {}).get("commit") != git_head(),
                     "traffic_source": {"file": f"profiles/traffic_latest_{args.workload}.json", "commit": tj.get("_measured_on", {}).get("commit"),
                                        "raw_bytes_per_step": tj[kernel].get("hbm_bytes_per_step_uncorrected"), "steps_profiled": tj.get("_measured_on", {}).get("steps_profiled"),
                                        "correction": "FETCH_SIZE x 2 (gfx950, MI355X_MICROARCH.md) + WRITE_SIZE"}})
@@ -265,7 +299,13 @@ def roofline(kernel, secs, launches, units, unit_name, bytes_per_unit, byte_term
         k = pj[kernel]
         vpl = k["valu_insts_per_step"] * steps / launches if (steps and k.get("valu_insts_per_step")) else k["valu_insts_per_launch"]
         ach = vpl / avg_s / 1e9
+        lane = k.get("lane_util")
         valu = {"achieved": ach, "peak": peaks["valu"], "unit": "G wave-instr/s", "frac": ach / peaks["valu"],
+                # against the guide's figure instead of the in-run probe (which moves with the clock the chip settles at under load)
+                "peak_spec": VALU_SPEC_GWIPS, "frac_of_spec": ach / VALU_SPEC_GWIPS,
+                "probe_clock_GHz": peaks["valu"] * 2.0 / VALU_SPEC_SIMDS,   # a saturating v_fma_f32 loop issues one wave64 instruction per SIMD every 2 cycles
+                "useful_lane_frac": (ach / VALU_SPEC_GWIPS * lane) if lane else None,   # issue slots x lanes that do work, of the spec peak
+                "stale_counters": pj.get("_measured_on", {}).get("commit") != git_head(),
                 "wave_insts_per_" + one: vpl / upl, "lane_util": k.get("lane_util"), "valu_busy_pmc": k.get("valu_busy"),
                 "wait_frac": k.get("wait_frac"), "waves_per_simd": k.get("waves_per_simd"),
                 "source": {"file": f"profiles/pmc_latest_{args.workload}.json", "commit": pj.get("_measured_on", {}).get("commit")},
@@ -283,6 +323,29 @@ def roofline(kernel, secs, launches, units, unit_name, bytes_per_unit, byte_term
         r.update({"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None})
     r.update({"traffic": traffic, "hbm": hbm, "valu": valu, "gather": gather})
     return r
+
+
+def also_runs():
+    """Short runs of cfg 4 and cfg 5 as children of the default run: value, wall, and the roofline of their dominant kernel."""
+    out = {}
+    for wl, extra in (("cfg4", ["--steps", "2", "--warmup", "1"]), ("cfg5", ["--warmup", "1"])):
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--no-cpu-baseline", "--no-also"] + extra
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            line = [l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1]
+            j = json.loads(line)
+            rf = j.get("roofline") or {}
+            out[wl] = {"value": j["value"], "unit": j["unit"], "steps": j["steps"], "ms_per_step": j["ms_per_step"], "wall_to_full_spp_s": j["wall_to_full_spp_s"],
+                       "workload": j["config"]["workload"], "passes_in_flight": j["config"].get("passes_in_flight"), "path_state_GB": j["config"].get("path_state_GB"),
+                       "rays_per_camera_sample": j["rays"]["per_camera_sample"],
+                       "roofline": {k: rf.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "traffic", "kernel_seconds")},
+                       "roofline_valu": {k: (rf.get("valu") or {}).get(k) for k in ("frac", "frac_of_spec", "lane_util", "useful_lane_frac", "valu_busy_pmc", "stale_counters")},
+                       "roofline_hbm": {k: (rf.get("hbm") or {}).get(k) for k in ("frac", "frac_raw", "achieved", "achieved_raw", "stale_counters")},
+                       "child_wall_s": round(time.perf_counter() - t0, 1)}
+        except Exception as e:
+            out[wl] = {"error": str(e)[-200:]}
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ the benchmark
@@ -368,13 +431,19 @@ def main():
     # which keeps its kernel launches as thick as the single-GPU ones.  Exactly `steps` x `spp_per_step` samples of every
     # pixel are rendered inside the timed region either way.
     fuse = args.fuse_steps if args.fuse_steps > 0 else world
+    # How a call's samples are cut into sub-passes is the library's business (gnxr_render_params.samples_per_pass = 0: sub-passes of ~16 M
+    # paths, four in flight; csrc/api.hip); --spp-per-pass / --passes-in-flight override it.  VolPath (cfg 5) renders a call as one pass.
+    def pass_args(s0_, s1_):
+        if args.workload == "cfg5":
+            return dict(samples_per_pass=min(fuse * sps, s1_ - s0_))
+        return dict(samples_per_pass=args.spp_per_pass, passes_in_flight=args.passes_in_flight)
 
     def calls_of(i0, nsteps):
         return call_ranges(i0, nsteps, sps, args.spp)
 
     # path state for the largest call of the run is allocated before the warm-up (gnxr_render_reserve), so that no timed step grows it
     for s0_, s1_, _ in list(calls_of(0, args.warmup)) + list(calls_of(0, args.steps)):
-        integ.Reserve(scene, W, H, args.spp, spp_begin=s0_, spp_end=s1_, samples_per_pass=min(fuse * sps, s1_ - s0_), **shard)
+        integ.Reserve(scene, W, H, args.spp, spp_begin=s0_, spp_end=s1_, **pass_args(s0_, s1_), **shard)
 
     def run_steps(i0, nsteps):
         """steps i0 .. i0+nsteps-1 = samples [i0*sps, (i0+nsteps)*sps) of every pixel (mod the Halton range --spp), submitted as ONE library
@@ -383,12 +452,11 @@ def main():
         Returns the summed stats."""
         agg = {}
         for s0, s1, m in calls_of(i0, nsteps):
-            st = integ.RenderDevice(scene, out.data_ptr(), W, H, args.spp, stream=stream, spp_begin=s0, spp_end=s1,
-                                    samples_per_pass=min(fuse * sps, s1 - s0), **shard)
+            st = integ.RenderDevice(scene, out.data_ptr(), W, H, args.spp, stream=stream, spp_begin=s0, spp_end=s1, **pass_args(s0, s1), **shard)
             acc.add_(out)
             for k_, v_ in st.items():
                 if isinstance(v_, (int, float)):
-                    agg[k_] = agg.get(k_, 0) + v_
+                    agg[k_] = max(agg.get(k_, 0), v_) if k_ in ("passes_in_flight", "state_bytes") else agg.get(k_, 0) + v_
         return agg
 
     note(f"scene ready in {scene_setup_s:.2f} s; {args.warmup} warm-up + {args.steps} timed steps of {sps} spp")
@@ -405,7 +473,8 @@ def main():
         torch.cuda.synchronize()
 
     tot = dict(rays_closest=0, rays_any=0, seconds_closest=0.0, seconds_nee=0.0, seconds_shade=0.0, launches_closest=0,
-               launches_nee=0, rays_closest_nee=0, camera_samples=0, kernel_launches=0, media_segments=0)
+               launches_nee=0, rays_closest_nee=0, camera_samples=0, kernel_launches=0, media_segments=0, passes=0, loop_iterations=0,
+               passes_in_flight=0, state_bytes=0)
     sync()
     t0 = time.perf_counter()
     st = run_steps(0, args.steps)
@@ -424,12 +493,17 @@ def main():
     note(f"timed region {dt:.3f} s")
     rays = tot["rays_closest"] + tot["rays_any"]
     tvec = torch.tensor([dt, float(rays), float(tot["rays_closest"]), float(tot["rays_any"])], dtype=torch.float64, device=coll_dev)
+    per_rank = None
     if world > 1:
         tmax = tvec.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = tvec.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt_max, rays_all = tmax[0].item(), tsum[1].item()
+        # load balance of the row shards: every rank's own wall time and ray count
+        every = [torch.zeros_like(tvec) for _ in range(world)]
+        dist.all_gather(every, tvec)
+        per_rank = [{"rank": i, "wall_s": round(v[0].item(), 4), "rays": int(v[1].item())} for i, v in enumerate(every)]
     else:
         dt_max, rays_all = dt, float(rays)
 
@@ -469,12 +543,16 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": wl, "spp_per_step": sps, "steps_per_pass": fuse, "passes_in_flight": 1 if args.workload == "cfg5" else 2,
-                   "submission": "one library call per contiguous sample range; the library keeps two passes in flight", "spp_rendered": spp_done, "spp_timed": spp_timed,
+        "config": {"workload": wl, "spp_per_step": sps,
+                   # reported by the library (gnxr_stats), not assumed here
+                   "passes_in_flight": tot["passes_in_flight"], "sub_passes": tot["passes"], "loop_iterations": tot["loop_iterations"],
+                   "path_state_GB": round(tot["state_bytes"] / 1e9, 2),
+                   "submission": "one library call per contiguous sample range; the library cuts it into sub-passes and keeps several in flight, queue counts stay on the device",
+                   "spp_rendered": spp_done, "spp_timed": spp_timed,
                    "sharding": f"rows y % {world} == rank" if world > 1 else "none",
                    "gather": "RCCL gather of row shards to rank 0 (in timed region)" if world > 1 else "n/a",
                    "world_size": dist.get_world_size() if world > 1 else 1, "backend": (backend if world > 1 else "none"),
-                   "devices_visible": n_visible, "commit": git_head()},
+                   "devices_visible": n_visible, "commit": git_head(), "per_rank": per_rank},
         "wall_to_1024spp_s": dt_max * (1024.0 / spp_timed),
         "wall_to_full_spp_s": dt_max * (float(args.spp) / spp_timed),
         "wall_measured_s": dt_max,
@@ -526,6 +604,12 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(builder, args)
         result["cpu_baseline"]["reference_in_survey_container"] = "cfg 2 only: 1.58 Mrays/s as-is, 6.3 Mrays/s printf-free, 8-core Xeon 2.1 GHz (BASELINE.md)"
+    if world == 1 and args.workload == "cfg3" and not args.no_also and not args.no_kernel_timing:
+        # BASELINE.json's other two GPU configurations, two steps each, so that their numbers are timed by whoever times this run
+        # (child processes: this one first gives its 15 GB of path state back)
+        del scene, out, acc
+        torch.cuda.empty_cache()
+        result["also"] = also_runs()
     print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()

@@ -364,9 +364,10 @@ class PathIntegrator:
                          "power": _abi.LIGHTS_POWER}.get(lightSampleStrategy, _abi.LIGHTS_SPATIAL)
 
     def params(self, width, height, spp, spp_begin=0, spp_end=0, shard_index=0, shard_count=1, shard_rows=1,
-               samples_per_pass=0):
+               samples_per_pass=0, passes_in_flight=0):
         return RenderParams(width, height, spp, spp_begin, spp_end, self.maxDepth, self.rrThreshold, self.integrator,
-                            self.strategy, shard_index, shard_count, shard_rows, samples_per_pass, getattr(self, "directStrategy", 0))
+                            self.strategy, shard_index, shard_count, shard_rows, samples_per_pass, getattr(self, "directStrategy", 0),
+                            passes_in_flight)
 
     def Render(self, scene, width, height, spp, **kw):
         """Integrator::Render: returns (float32 image [H, W, 4], stats dict)."""

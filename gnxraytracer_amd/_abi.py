@@ -5,7 +5,7 @@ include/gnxr.h field for field (tests/test_abi.py checks sizes and exported symb
 """
 import ctypes as C
 
-GNXR_ABI_VERSION = 4
+GNXR_ABI_VERSION = 5
 
 # gnxr_status
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_OOM, ERR_UNSUPPORTED, ERR_IO, ERR_RUNTIME = 0, -1, -2, -3, -4, -5, -6
@@ -83,6 +83,7 @@ class RenderParams(C.Structure):
         ("width", i32), ("height", i32), ("spp", i32), ("spp_begin", i32), ("spp_end", i32), ("max_depth", i32),
         ("rr_threshold", f32), ("integrator", i32), ("light_strategy", i32),
         ("shard_index", i32), ("shard_count", i32), ("shard_rows", i32), ("samples_per_pass", i32), ("direct_strategy", i32),
+        ("passes_in_flight", i32),
     ]
 
 
@@ -94,6 +95,7 @@ class Stats(C.Structure):
         ("seconds_closest", C.c_double), ("seconds_nee", C.c_double), ("seconds_shade", C.c_double),
         ("launches_closest", u32), ("launches_nee", u32), ("rays_closest_nee", u64),
         ("media_segments", u64), ("media_steps", u64), ("leaf_retests", u64), ("nodes_from_memory", u64),
+        ("passes_in_flight", u32), ("loop_iterations", u32), ("state_bytes", u64),
     ]
 
 

@@ -17,6 +17,7 @@
 #include "host_scene.h"
 #include "kernels.hip.h"
 #include "trace4_kernel.hip.h"
+#include "trace4d_kernel.hip.h"
 #include "kernel_instances.h"
 
 using namespace gnxr;
@@ -51,6 +52,7 @@ int hip_status(hipError_t e) {
 
 int g_device = -1;
 std::vector<int> g_devices;        // gnxr_init_devices: every scene is replicated on these and renders shard their rows over them
+std::vector<char> g_peer_ok;       // per entry of g_devices: the primary device and this one can address each other's memory (peer access enabled both ways)
 int g_num_cus = 256;
 int g_profiling = 0;
 int g_trace_blocks_per_cu = 5;   // persistent blocks of the traversal kernel per CU (5 waves per SIMD at its 96 VGPRs, 32 KB of LDS each); GNXR_TRACE_BLOCKS_PER_CU overrides (tuning)
@@ -174,15 +176,27 @@ struct gnxr_scene {
     DevBuf<int> wh_rec;
     DevBuf<Counters> counters;
     Counters *h_counters = nullptr;  // pinned
+    // the device-driven PathIntegrator loop: lagging copies of the counters (pinned ring, one event per slot) -- the host reads them
+    // without ever waiting for the iteration it has just enqueued
+    static constexpr int kRing = 8;
+    Counters *h_ring = nullptr;      // pinned, kRing entries
+    hipEvent_t ring_ev[kRing] = {};
     int stack_size = 32;
     bool wide_ok = true;   // 4-wide traversal usable (leaf sizes / triangle count fit the reference encoding)
     std::recursive_mutex render_mutex;   // one render in flight per handle; gnxr_render holds it around its staging buffer too
     int device = 0;                      // the HIP device the tables live on
     std::vector<std::unique_ptr<gnxr_scene>> replicas;   // the same scene on the other devices of gnxr_init_devices (element 0 of that list is this one)
     DevBuf<float4> shard_out;            // a replica's full-size output plane; its rows are peer-copied into the primary's image
+    void *h_stage = nullptr;             // pinned: a replica's rows on their way to the primary when the two devices have no peer access
+    size_t h_stage_bytes = 0;
 
     int bind() const { HIP_TRY(hipSetDevice(device)); return GNXR_OK; }
-    ~gnxr_scene() { if (h_counters) (void)hipHostFree(h_counters); }
+    ~gnxr_scene() {
+        if (h_counters) (void)hipHostFree(h_counters);
+        if (h_ring) (void)hipHostFree(h_ring);
+        if (h_stage) (void)hipHostFree(h_stage);
+        for (hipEvent_t e : ring_ev) if (e) (void)hipEventDestroy(e);
+    }
 
     DScene device_scene(int W, int H) {
         DScene d;
@@ -412,6 +426,7 @@ int gnxr_init(int device_id) {
     HIP_TRY(hipSetDevice(device_id));
     g_device = -1;
     g_devices.assign(1, device_id);
+    g_peer_ok.assign(1, 1);
     return ensure_device();
 }
 int gnxr_init_devices(int32_t n_devices, const int32_t *device_ids) {
@@ -424,20 +439,28 @@ int gnxr_init_devices(int32_t n_devices, const int32_t *device_ids) {
     int rc = gnxr_init(device_ids[0]);
     if (rc) return rc;
     g_devices.assign(device_ids, device_ids + n_devices);
-    // peer access between the primary and the others (assembling the image); a refusal is not fatal: copies then stage through the host
+    // Peer access between the primary and the others (assembling the image).  Whether it was granted is RECORDED per device: a pair
+    // without it assembles its rows through a pinned host buffer (render_sharded), it is never assumed.
+    g_peer_ok.assign(n_devices, 1);
     for (int i = 1; i < n_devices; ++i) {
-        if (device_ids[i] == device_ids[0]) continue;
-        int can = 0;
-        if (hipDeviceCanAccessPeer(&can, device_ids[0], device_ids[i]) == hipSuccess && can) {
-            (void)hipSetDevice(device_ids[0]); (void)hipDeviceEnablePeerAccess(device_ids[i], 0);
-            (void)hipSetDevice(device_ids[i]); (void)hipDeviceEnablePeerAccess(device_ids[0], 0);
+        if (device_ids[i] == device_ids[0]) continue;   // the same card listed twice: plain device-to-device copies
+        int can01 = 0, can10 = 0;
+        bool ok = hipDeviceCanAccessPeer(&can01, device_ids[0], device_ids[i]) == hipSuccess && can01 &&
+                  hipDeviceCanAccessPeer(&can10, device_ids[i], device_ids[0]) == hipSuccess && can10;
+        if (ok) {
+            hipError_t e0 = hipSetDevice(device_ids[0]) == hipSuccess ? hipDeviceEnablePeerAccess(device_ids[i], 0) : hipErrorInvalidDevice;
+            hipError_t e1 = hipSetDevice(device_ids[i]) == hipSuccess ? hipDeviceEnablePeerAccess(device_ids[0], 0) : hipErrorInvalidDevice;
+            ok = (e0 == hipSuccess || e0 == hipErrorPeerAccessAlreadyEnabled) && (e1 == hipSuccess || e1 == hipErrorPeerAccessAlreadyEnabled);
         }
+        g_peer_ok[i] = ok ? 1 : 0;
+        if (getenv("GNXR_VERBOSE")) fprintf(stderr, "[gnxr] device %d <-> %d: %s\n", device_ids[0], device_ids[i], ok ? "peer access" : "no peer access: rows are staged through the host");
     }
-    (void)hipGetLastError();   // "peer access already enabled" is fine
+    (void)hipGetLastError();
+    if (getenv("GNXR_NO_PEER")) for (int i = 1; i < n_devices; ++i) g_peer_ok[i] = 0;   // test switch: take the host-staged route everywhere
     HIP_TRY(hipSetDevice(device_ids[0]));
     return GNXR_OK;
 }
-void gnxr_shutdown(void) { g_device = -1; g_devices.clear(); }
+void gnxr_shutdown(void) { g_device = -1; g_devices.clear(); g_peer_ok.clear(); }
 int gnxr_set_profiling(int flags) { g_profiling = flags; return GNXR_OK; }
 #ifdef GX_SHADE_STATS
 // development builds only (-DGX_SHADE_STATS): wave-time per section of k_shade
@@ -485,6 +508,8 @@ static int upload_scene(gnxr_scene *s) {
     if ((rc = s->infinite.upload(cs.infinite_lights)) != GNXR_OK) return rc;
     if ((rc = s->counters.alloc(1)) != GNXR_OK) return rc;
     if (hipHostMalloc((void **)&s->h_counters, sizeof(Counters)) != hipSuccess) { set_error("hipHostMalloc failed"); return GNXR_ERR_OOM; }
+    if (hipHostMalloc((void **)&s->h_ring, sizeof(Counters) * gnxr_scene::kRing) != hipSuccess) { set_error("hipHostMalloc failed"); return GNXR_ERR_OOM; }
+    for (hipEvent_t &e : s->ring_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return GNXR_OK;
 }
 
@@ -596,36 +621,42 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
     if (r.npix == 0) { if (stats) memset(stats, 0, sizeof(*stats)); return GNXR_OK; }
     int nsamples = p.spp_end - p.spp_begin;
     int k = p.samples_per_pass;
+    const bool path_int = !whitted && !volpath;
     if (k <= 0) {
-        // auto: big passes keep the thin late bounces from under-filling the GPU (bench.py: 32 -> 128 spp per pass at 1080p is
-        // +4 %), so take up to a quarter of the free HBM for path state (~230 B per path), at most 256 M paths; Whitted /
-        // DirectLighting keep max_depth frames and n_records NEE records per path and stay small
+        // auto.  PathIntegrator: sub-passes of ~16 M paths, several of them in flight (below) -- launches stay thick because they mix
+        // the bounces of different sub-passes, not because a sub-pass is large.  VolPath / Whitted / DirectLighting render one pass at a
+        // time: big passes keep their thin late rounds from under-filling the GPU, so take up to a quarter of the free HBM for path state
+        // (~230 B per path), at most 256 M paths; Whitted / DirectLighting keep max_depth frames and n_records NEE records per path
         long long target = 32ll << 20;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) target = std::max<long long>(target, std::min<long long>(256ll << 20, (long long)(free_b / 4 / 230)));
         if (volpath) target = std::min<long long>(target, 64ll << 20);   // + 8 float4 of VolPath state per path
         if (whitted) target = (4ll << 20) / std::max(1, n_records / 4);
-        if (!whitted && !volpath && (getenv("GNXR_PIPELINE") ? atoi(getenv("GNXR_PIPELINE")) != 0 : true) && target / r.npix < nsamples) target /= 2;   // two passes in flight
+        if (path_int) target = 16ll << 20;
         k = (int)std::max<long long>(1, std::min<long long>(nsamples, target / r.npix));
     }
     k = std::min(k, nsamples);
-    // PathIntegrator: two passes in flight at once, each in its own half of the state arrays (the pipelined loop below).  Halving the
-    // pass size instead of doubling the state was measured and loses: thick launches of half the size are ~3 % less efficient, more than
-    // the merged tails give back.
+    // PathIntegrator: up to kMaxRegions sub-passes in flight at once, each in its own region of the state arrays (the device-driven loop
+    // below).  passes_in_flight = 0 picks 4, fewer when the call has fewer sub-passes or the state would not fit the 32-bit work indices
+    // or ~45 % of the free HBM (~230 B per path slot beyond what this handle already holds).
+    static const int regions_env = getenv("GNXR_REGIONS") ? atoi(getenv("GNXR_REGIONS")) : 0;   // tuning knob
     static const bool pipeline = getenv("GNXR_PIPELINE") ? atoi(getenv("GNXR_PIPELINE")) != 0 : true;   // experiment switch: 0 = one pass at a time
-    const bool path_int = !whitted && !volpath;
-    int in_flight = (path_int && pipeline && k < nsamples) ? 2 : 1;
     const int kh = k;
-    const size_t half = (size_t)r.npix * kh;
-    if (in_flight == 2) {
-        // two passes in flight need twice the state: fall back to one at a time when that does not fit the 32-bit work indices or the
-        // free HBM (~230 B per path slot beyond what this handle already holds), rather than refusing a pass size that used to render
+    const size_t half = (size_t)r.npix * kh;   // slots of one region
+    int in_flight = 1;
+    if (path_int && pipeline) {
+        const int n_subs = (nsamples + kh - 1) / kh;
+        in_flight = p.passes_in_flight > 0 ? p.passes_in_flight : (regions_env > 0 ? regions_env : 4);
+        in_flight = std::max(1, std::min(std::min(in_flight, kMaxRegions), n_subs));
         size_t free_b = 0, total_b = 0;
-        const unsigned long long want = 2ull * half, held = (unsigned long long)s->ray_o.n;
-        const bool idx_ok = want < (1ull << 31) && want * 3ull < (1ull << 32);
-        bool mem_ok = true;
-        if (want > held && hipMemGetInfo(&free_b, &total_b) == hipSuccess) mem_ok = (want - held) * 230ull < (unsigned long long)free_b - (unsigned long long)free_b / 16;
-        if (!idx_ok || !mem_ok) in_flight = 1;
+        const bool have_mem = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+        for (; in_flight > 1; --in_flight) {
+            const unsigned long long want = (unsigned long long)in_flight * half, held = (unsigned long long)s->ray_o.n;
+            const bool idx_ok = want < (1ull << 31) && want * 3ull < (1ull << 32);
+            bool mem_ok = true;
+            if (want > held && have_mem) mem_ok = (want - held) * 230ull < (unsigned long long)(0.45 * (double)free_b);
+            if (idx_ok && mem_ok) break;
+        }
     }
     size_t cap = (size_t)in_flight * half;
     // k_trace's work cursor is 32-bit unsigned: continuation rays + two NEE items per record; record slots are `record * cap + path`
@@ -656,7 +687,7 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
     }
     {   // global part of k_trace's traversal stacks (the deepest walk either BVH layout can need), sized for a full grid
         const int entries = std::max(s->cs.stack4_need + 1, s->cs.bvh_max_depth + 2);
-        if ((rc = s->trace_spill.alloc((size_t)g_num_cus * g_trace_blocks_per_cu * kBlock * (size_t)entries)) != GNXR_OK) return rc;
+        if ((rc = s->trace_spill.alloc((size_t)g_num_cus * g_trace_blocks_per_cu * kBlock * (size_t)entries * 2)) != GNXR_OK) return rc;   // (x 2: k_trace4d keeps two columns per lane)
     }
     if ((rc = s->accum.alloc(r.npix)) != GNXR_OK) return rc;
     const int max_tiles = (int)((cap + kCompactTile - 1) / kCompactTile);
@@ -705,25 +736,30 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
     }
     KernelTimer timer;
     Counters *dctr = s->counters.p;
-    auto launch_trace = [&](TraceWork w, int n_sh, int n_mis) {
+    // (device-driven loop: w.n_closest / w.n_nee are upper bounds that size the launch, the kernel reads the counts through
+    // w.n_closest_dev / w.n_nee_dev, and the rays are counted on the device: count_rays = false)
+    auto launch_trace = [&](TraceWork w, int n_sh, int n_mis, bool count_rays = true) {
         long long total = (long long)w.n_closest + 2ll * w.n_nee;
         if (total <= 0) return;
         w.order = nullptr;
         static const int sort_rays = getenv("GNXR_SORT_RAYS") ? atoi(getenv("GNXR_SORT_RAYS")) : 0;   // experiment: bin the rays of a launch by kind / octant / origin cell
         if (sort_rays > 0 && total >= (1 << 16)) {
-            if (s->sort_keys_a.alloc(3 * cap) || s->sort_keys_b.alloc(3 * cap) || s->sort_items_a.alloc(3 * cap) || s->sort_items_b.alloc(3 * cap)) return;
-            const Box3 &wb = s->cs.world_bound;
-            const float3 lo = make_float3(wb.lo.x, wb.lo.y, wb.lo.z);
-            const float3 scale = make_float3(32.f / std::max(1e-20f, wb.hi.x - wb.lo.x), 32.f / std::max(1e-20f, wb.hi.y - wb.lo.y), 32.f / std::max(1e-20f, wb.hi.z - wb.lo.z));
-            if (timing) timer.begin(1, stream);
-            hipLaunchKernelGGL(k_trace_keys, dim3(grid_for(total)), dim3(kBlock), 0, stream, pa, w, lo, scale, s->sort_keys_a.p, s->sort_items_a.p);
-            size_t bytes = 0;
-            const int b0 = sort_rays >= 2 ? 0 : 15, b1 = kTraceKeyBits;   // 1: kind + octant only; 2: + origin cell
-            (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, s->sort_keys_a.p, s->sort_keys_b.p, s->sort_items_a.p, s->sort_items_b.p, (int)total, b0, b1, stream);
-            if (s->sort_tmp.alloc(bytes)) return;
-            (void)hipcub::DeviceRadixSort::SortPairs(s->sort_tmp.p, bytes, s->sort_keys_a.p, s->sort_keys_b.p, s->sort_items_a.p, s->sort_items_b.p, (int)total, b0, b1, stream);
-            if (timing) timer.end(stream);
-            w.order = s->sort_items_b.p;
+            // (an experiment switch: any failure -- buffers, the library sort -- leaves the launch UNSORTED, it never skips the trace)
+            bool sorted = !(s->sort_keys_a.alloc(3 * cap) || s->sort_keys_b.alloc(3 * cap) || s->sort_items_a.alloc(3 * cap) || s->sort_items_b.alloc(3 * cap));
+            if (sorted) {
+                const Box3 &wb = s->cs.world_bound;
+                const float3 lo = make_float3(wb.lo.x, wb.lo.y, wb.lo.z);
+                const float3 scale = make_float3(32.f / std::max(1e-20f, wb.hi.x - wb.lo.x), 32.f / std::max(1e-20f, wb.hi.y - wb.lo.y), 32.f / std::max(1e-20f, wb.hi.z - wb.lo.z));
+                if (timing) timer.begin(1, stream);
+                hipLaunchKernelGGL(k_trace_keys, dim3(grid_for(total)), dim3(kBlock), 0, stream, pa, w, lo, scale, s->sort_keys_a.p, s->sort_items_a.p);
+                size_t bytes = 0;
+                const int b0 = sort_rays >= 2 ? 0 : 15, b1 = kTraceKeyBits;   // 1: kind + octant only; 2: + origin cell
+                sorted = hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, s->sort_keys_a.p, s->sort_keys_b.p, s->sort_items_a.p, s->sort_items_b.p, (int)total, b0, b1, stream) == hipSuccess &&
+                         s->sort_tmp.alloc(bytes) == GNXR_OK &&
+                         hipcub::DeviceRadixSort::SortPairs(s->sort_tmp.p, bytes, s->sort_keys_a.p, s->sort_keys_b.p, s->sort_items_a.p, s->sort_items_b.p, (int)total, b0, b1, stream) == hipSuccess;
+                if (timing) timer.end(stream);
+            }
+            w.order = sorted ? s->sort_items_b.p : nullptr;
         }
         (void)hipMemsetAsync(&dctr->cursor, 0, sizeof(unsigned int), stream);
         // LDS traversal stack: one column per lane, depth from the BVH (binary walk: depth + 1; 4-wide walk: stack4_need)
@@ -743,14 +779,26 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
         // persistent waves: enough blocks to fill the chip, never more than the work needs
         int blocks = (int)std::min<long long>((long long)g_num_cus * per_cu, (total + kBlock - 1) / kBlock);
         if (timing) timer.begin(0, stream);
-        // rays per atomic: kTraceChunk for big launches; for thin ones (late bounces) small enough that every wave gets a chunk --
-        // the number of atomics stays <= the number of waves, well under the ~88/us a single address sustains
-        const long long waves = (long long)blocks * (kBlock / 64);
+        // rays per atomic: at most kTraceChunk; the kernel shrinks the chunk for thin launches so that every wave gets one (trace_chunk())
         static const int chunk_max = getenv("GNXR_TRACE_CHUNK") ? std::max(64, atoi(getenv("GNXR_TRACE_CHUNK")) / 64 * 64) : kTraceChunk;   // tuning knob
-        const int chunk = (int)std::min<long long>(chunk_max, std::max<long long>(64, ((total + waves - 1) / waves + 63) / 64 * 64));
+        const int chunk = chunk_max;
 #define GX_TRACE(C, W, S) hipLaunchKernelGGL((k_trace<C, W, S>), dim3(blocks), dim3(kBlock), lds, stream, sc, pa, w, &dctr->cursor, dctr, lds_entries, s->trace_spill.p, chunk)
 #define GX_TRACE4(C, S, P) hipLaunchKernelGGL((k_trace4<C, S, P>), dim3(blocks), dim3(kBlock), lds, stream, sc, pa, w, &dctr->cursor, dctr, lds_entries, s->trace_spill.p, chunk, n_top)
 #define GX_TRACE4_CS(C, S) do { if (spill_needed) GX_TRACE4(C, S, true); else GX_TRACE4(C, S, false); } while (0)
+        static const bool dual = getenv("GNXR_TRACE_DUAL") ? atoi(getenv("GNXR_TRACE_DUAL")) != 0 : false;   // two rays per lane (trace4d_kernel.hip.h)
+        if (wide && dual && !count_wide) {
+            const int dper_cu = GX_T4D_WAVES;   // blocks of 4 waves per CU = waves per SIMD
+            const size_t dfixed = (size_t)(kRayRecDwords + (spheres ? 1 : 0)) * kRqStride * sizeof(int) + (size_t)kTopCacheD * 128 + 128;
+            const int dlds_entries = std::min(std::min(entries, lds_levels_cap), std::max(2, (int)(((160 * 1024) / dper_cu - 1024 - dfixed) / (2 * kBlock * sizeof(int)))));
+            const int dspill_levels = std::max(0, entries - dlds_entries);
+            const size_t dlds = (size_t)2 * dlds_entries * kBlock * sizeof(int) + dfixed;
+            const int dn_top = (int)std::min<size_t>(kTopCacheD, s->cs.root4 >= 0 ? s->cs.nodes4.size() : 0);
+            const int dblocks = (int)std::min<long long>((long long)g_num_cus * dper_cu, (total + 2 * kBlock - 1) / (2 * kBlock));
+#define GX_TRACE4D(S, P) hipLaunchKernelGGL((k_trace4d<S, P>), dim3(std::max(1, dblocks)), dim3(kBlock), dlds, stream, sc, pa, w, &dctr->cursor, dctr, dlds_entries, dspill_levels, s->trace_spill.p, chunk, dn_top)
+            if (spheres) { if (dspill_levels > 0) GX_TRACE4D(true, true); else GX_TRACE4D(true, false); }
+            else { if (dspill_levels > 0) GX_TRACE4D(false, true); else GX_TRACE4D(false, false); }
+#undef GX_TRACE4D
+        } else
         if (wide) {   // the 4-wide walk (trace4_kernel.hip.h); count_wide: its counting variant
             if (spheres) { if (count_wide) GX_TRACE4_CS(true, true); else GX_TRACE4_CS(false, true); }
             else { if (count_wide) GX_TRACE4_CS(true, false); else GX_TRACE4_CS(false, false); }
@@ -763,41 +811,46 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
 #undef GX_TRACE4
 #undef GX_TRACE
         if (timing) timer.end(stream);
-        rays_closest += (unsigned long long)w.n_closest + (unsigned long long)n_mis;
-        rays_any += (unsigned long long)n_sh;
-        rays_mis += (unsigned long long)n_mis;
+        if (count_rays) {
+            rays_closest += (unsigned long long)w.n_closest + (unsigned long long)n_mis;
+            rays_any += (unsigned long long)n_sh;
+            rays_mis += (unsigned long long)n_mis;
+        }
         ++launches;
     };
     // stream compaction (compact_kernel.hip.h): count -> scan -> scatter, no global atomics
-    auto compact = [&](int mode, const int *qin, int nin, const unsigned char *keys, int nout, int nscatter, unsigned int *totals, int *o0, int *o1, int *o2, int *o3 = nullptr, int split = 0) {
+    // (n_dev: the item count lives on the device; `nin` then bounds it and sizes the launch)
+    auto compact = [&](int mode, const int *qin, int nin, const unsigned char *keys, int nout, int nscatter, unsigned int *totals, int *o0, int *o1, int *o2, int *o3 = nullptr, int split = 0,
+                       const unsigned *n_dev = nullptr) {
         int tiles = (nin + kCompactTile - 1) / kCompactTile;
-        int g = std::min(tiles, g_num_cus * 8);
-        // FLAGS with a fifth count: the paths that continue AND live in the lower half of the state arrays (slot < split): how many paths of
-        // each of the two sub-passes in flight are left
-        if (mode == COMPACT_FLAGS && nout == 5) hipLaunchKernelGGL((k_compact_count<COMPACT_FLAGS, 5>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles, (const int *)nullptr, (const unsigned char *)nullptr, (unsigned char *)nullptr, split);
-        else if (mode == COMPACT_FLAGS) hipLaunchKernelGGL((k_compact_count<COMPACT_FLAGS, 4>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles);
+        int g = std::max(1, std::min(tiles, g_num_cus * 8));
+        const int *nohit = nullptr; const unsigned char *nocls = nullptr; unsigned char *nokeys = nullptr;
+        // FLAGS with a fifth count: the paths that continue AND live in the lower half of the state arrays (slot < split)
+        if (mode == COMPACT_FLAGS && nout == 5) hipLaunchKernelGGL((k_compact_count<COMPACT_FLAGS, 5>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles, nohit, nocls, nokeys, split, n_dev);
+        else if (mode == COMPACT_FLAGS) hipLaunchKernelGGL((k_compact_count<COMPACT_FLAGS, 4>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles, nohit, nocls, nokeys, 0, n_dev);
         else if (mode == COMPACT_HITCLASS) {   // class of the triangle a path hit, looked up and left in `keys` for the scatter pass
-            if (nout == 4) hipLaunchKernelGGL((k_compact_count<COMPACT_HITCLASS, 4>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles, (const int *)s->hit.p, (const unsigned char *)s->tri_class.p, s->pclass.p);
-            else hipLaunchKernelGGL((k_compact_count<COMPACT_HITCLASS, 3>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles, (const int *)s->hit.p, (const unsigned char *)s->tri_class.p, s->pclass.p);
+            if (nout == 4) hipLaunchKernelGGL((k_compact_count<COMPACT_HITCLASS, 4>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles, (const int *)s->hit.p, (const unsigned char *)s->tri_class.p, s->pclass.p, 0, n_dev);
+            else hipLaunchKernelGGL((k_compact_count<COMPACT_HITCLASS, 3>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles, (const int *)s->hit.p, (const unsigned char *)s->tri_class.p, s->pclass.p, 0, n_dev);
             mode = COMPACT_CLASS;
         }
-        else if (nout == 4) hipLaunchKernelGGL((k_compact_count<COMPACT_CLASS, 4>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles);
-        else hipLaunchKernelGGL((k_compact_count<COMPACT_CLASS, 3>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles);
-        hipLaunchKernelGGL(k_compact_scan, dim3(nout), dim3(1024), 0, stream, s->tile_counts.p, tiles, totals);
-        if (mode == COMPACT_FLAGS && nscatter == 3) hipLaunchKernelGGL((k_compact_scatter<COMPACT_FLAGS, 3>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, (const unsigned int *)s->tile_counts.p, tiles, o0, o1, o2);
-        else if (mode == COMPACT_FLAGS) hipLaunchKernelGGL((k_compact_scatter<COMPACT_FLAGS, 2>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, (const unsigned int *)s->tile_counts.p, tiles, o0, o1, o2);
-        else if (nscatter == 4) hipLaunchKernelGGL((k_compact_scatter<COMPACT_CLASS, 4>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, (const unsigned int *)s->tile_counts.p, tiles, o0, o1, o2, o3);
-        else hipLaunchKernelGGL((k_compact_scatter<COMPACT_CLASS, 3>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, (const unsigned int *)s->tile_counts.p, tiles, o0, o1, o2);
+        else if (nout == 4) hipLaunchKernelGGL((k_compact_count<COMPACT_CLASS, 4>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles, nohit, nocls, nokeys, 0, n_dev);
+        else hipLaunchKernelGGL((k_compact_count<COMPACT_CLASS, 3>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles, nohit, nocls, nokeys, 0, n_dev);
+        hipLaunchKernelGGL(k_compact_scan, dim3(nout), dim3(1024), 0, stream, s->tile_counts.p, tiles, totals, n_dev);
+        if (mode == COMPACT_FLAGS && nscatter == 3) hipLaunchKernelGGL((k_compact_scatter<COMPACT_FLAGS, 3>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, (const unsigned int *)s->tile_counts.p, tiles, o0, o1, o2, (int *)nullptr, n_dev);
+        else if (mode == COMPACT_FLAGS) hipLaunchKernelGGL((k_compact_scatter<COMPACT_FLAGS, 2>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, (const unsigned int *)s->tile_counts.p, tiles, o0, o1, o2, (int *)nullptr, n_dev);
+        else if (nscatter == 4) hipLaunchKernelGGL((k_compact_scatter<COMPACT_CLASS, 4>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, (const unsigned int *)s->tile_counts.p, tiles, o0, o1, o2, o3, n_dev);
+        else hipLaunchKernelGGL((k_compact_scatter<COMPACT_CLASS, 3>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, (const unsigned int *)s->tile_counts.p, tiles, o0, o1, o2, (int *)nullptr, n_dev);
         launches += 3;
     };
     // ---- PathIntegrator: one vertex of every live path per iteration, two sub-passes in flight.
     // shade_stage: PathIntegrator::Li at the vertices the last trace found (class binning, one k_shade per class, queue compaction), then
     // the counts of what they spawned come back to the host.
-    auto shade_stage = [&](const int *q_in, int n, int *q_out, int split) -> int {
+    // `n` bounds the number of queued paths (it sizes the launches); the count itself is read on the device through n_dev.
+    auto shade_stage = [&](const int *q_in, int n, int *q_out, const unsigned *n_dev) -> int {
     if (timing) timer.begin(2, stream);
     // bin the paths by the shade specialisation of the material they hit (pclass written by k_trace)
     const int n_classes = (class_mask & 8) ? 4 : 3;   // image-textured materials have a shade queue of their own
-    compact(COMPACT_HITCLASS, q_in, n, s->pclass.p, n_classes, n_classes, &dctr->q_class[0], s->queue_c0.p, s->queue_c1.p, s->queue_c2.p, s->queue_c3.p);
+    compact(COMPACT_HITCLASS, q_in, n, s->pclass.p, n_classes, n_classes, &dctr->q_class[0], s->queue_c0.p, s->queue_c1.p, s->queue_c2.p, s->queue_c3.p, 0, n_dev);
     {
         int *qc[4] = {s->queue_c0.p, s->queue_c1.p, s->queue_c2.p, s->queue_c3.p};
         dim3 g(grid_for(n)), b(kBlock);
@@ -843,27 +896,34 @@ else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, slds, stream,
         launches += 1 + ((class_mask & 2) ? 1 : 0) + ((class_mask & 4) ? 1 : 0) + ((class_mask & 8) ? 1 : 0);
     }
     // next-vertex queue + NEE queue from the per-path flags; totals also count shadow and MIS rays
-    compact(COMPACT_FLAGS, q_in, n, s->pflags.p, 5, 2, &dctr->q_next, q_out, s->queue_nee.p, nullptr, nullptr, split);
+    compact(COMPACT_FLAGS, q_in, n, s->pflags.p, 4, 2, &dctr->q_next, q_out, s->queue_nee.p, nullptr, nullptr, 0, n_dev);
     if (timing) timer.end(stream);
-    if (hipMemcpyAsync(s->h_counters, dctr, sizeof(Counters), hipMemcpyDeviceToHost, stream) != hipSuccess) return GNXR_ERR_RUNTIME;
-    if (hipStreamSynchronize(stream) != hipSuccess) return GNXR_ERR_RUNTIME;
         return GNXR_OK;
     };
+    unsigned int loop_iterations = 0;
+    unsigned long long new_paths = 0;   // PathIntegrator: camera rays started (their count is known to the host; the other rays are counted on the device)
     if (!whitted && !volpath) {
-        // A pass's late bounces are thin (Russian roulette, escapes): a few hundred thousand rays cannot fill 327 k lanes, and a launch
-        // then costs the latency of its longest rays (~1 ms per bounce: 6 ms of an otherwise 60 ms pass).  So the samples of a call are
-        // cut into sub-passes of half the pass size, each in its own half of the state arrays, and a new sub-pass starts (k_raygen +
-        // k_queue_merge) when the one in flight has done `cut` vertices: its camera rays and first bounces share launches with the tail
-        // of the older one.  Queues hold slots of both halves in ascending order; results per path do not depend on who shares a
-        // launch, and k_resolve runs per sub-pass in sample order, so images are unchanged bit for bit.
-        struct Sub { int s0, kk, n_paths; size_t base; long long alive; int iters; };
+        // The device-driven path loop.  The samples of a call are cut into sub-passes of `kh` samples per pixel; up to `in_flight` of them
+        // are alive at once, each in its own region of the state arrays, staggered in time: a launch then mixes the camera rays and first
+        // bounces of one sub-pass with the thin late bounces of the others (Russian roulette and escapes leave a few hundred thousand of a
+        // sub-pass's paths after five bounces), so launches stay thick while the resident state is in_flight x kh samples per pixel
+        // instead of two 128-sample passes.  Queues hold slots of all regions in ascending order; results per path do not depend on who
+        // shares a launch, and k_resolve runs per sub-pass in sample order, so images are unchanged bit for bit.
+        //
+        // The host never waits for the iteration it enqueues: every queue count stays on the device (kernels read them there; launches are
+        // sized by upper bounds), and what the host needs for its decisions -- how many paths of each region are left -- it reads from a
+        // ring of pinned copies that lag the GPU by up to `lag` iterations.  A stale zero is still a zero (a region only refills when the
+        // host starts a sub-pass in it), and a stale count is an upper bound.  Reference loop: core/Integrator.cpp:256-293.
+        struct Sub { int s0, kk; };
         std::vector<Sub> subs;
-        for (int s0 = p.spp_begin, i = 0; s0 < p.spp_end; s0 += kh, ++i) {
-            const int kk = std::min(kh, p.spp_end - s0);
-            subs.push_back(Sub{s0, kk, r.npix * kk, in_flight == 2 ? (size_t)(i & 1) * half : 0, 0, 0});
-        }
-        static const int cut_env = getenv("GNXR_PIPE_CUT") ? atoi(getenv("GNXR_PIPE_CUT")) : -1;   // tuning knob
-        const int cut = cut_env >= 0 ? cut_env : (p.max_depth + 2) / 2;
+        for (int s0 = p.spp_begin; s0 < p.spp_end; s0 += kh) subs.push_back(Sub{s0, std::min(kh, p.spp_end - s0)});
+        const int R = in_flight;
+        struct Region { int sub = -1, started = -1; long long paths = 0; } reg[kMaxRegions];
+        static const int cut_env = getenv("GNXR_PIPE_CUT") ? atoi(getenv("GNXR_PIPE_CUT")) : -1;   // tuning knob: iterations between sub-pass starts
+        static const int lag_env = getenv("GNXR_LOOP_LAG") ? atoi(getenv("GNXR_LOOP_LAG")) : -1;   // tuning knob: iterations the host may run ahead
+        const int lag = std::max(1, std::min(gnxr_scene::kRing - 2, lag_env >= 0 ? lag_env : 2));
+        // a sub-pass lives max_depth + 2 iterations (+ the lag until the host sees that it has ended): spread the starts over that time
+        const int stagger = cut_env >= 0 ? cut_env : std::max(1, (p.max_depth + 2 + lag + R - 1) / R);
         auto pa_at = [&](size_t base) {
             PathArrays q = pa;
             q.ray_o += base; q.ray_d += base; q.beta += base; q.L += base; q.meta += base; q.hit += base; q.pflags += base; q.pclass += base;
@@ -871,47 +931,103 @@ else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, slds, stream,
             return q;
         };
         int *qbuf[2] = {s->queue_a.p, s->queue_b.p};
-        int in_idx = 0, n = 0;
-        size_t oldest = 0, next = 0;
-        int guard = 0;
-        while (oldest < subs.size()) {
-            // A. shade what the last trace found; survivors go to the buffer that does not hold the input queue
-            int n_next = 0, n_nee = 0, n_sh = 0, n_mis = 0, n_low = 0, out_idx = 1 - in_idx;
-            if (n > 0) {
-                if ((rc = shade_stage(qbuf[in_idx], n, qbuf[out_idx], (int)half)) != GNXR_OK) { set_error("HIP runtime error in the path loop: %s", hipGetErrorString(hipGetLastError())); return rc; }
-                n_next = (int)s->h_counters->q_next; n_nee = (int)s->h_counters->q_nee;
-                n_sh = (int)s->h_counters->q_shadow; n_mis = (int)s->h_counters->q_mis; n_low = (int)s->h_counters->q_low;
-                for (size_t i = oldest; i < next; ++i) { subs[i].alive = subs[i].base == 0 ? n_low : n_next - n_low; subs[i].iters++; }
+        int in_idx = 0;
+        const unsigned *cnt_ptr = &dctr->n_queue;  // where the count of the queue in flight lives on the device (k_loop_tail / k_queue_merge write it)
+        size_t next_sub = 0, done_subs = 0;
+        int iter = 0, last_start = -(1 << 20), newest_seen = -1;
+        int ring_iter[gnxr_scene::kRing];          // iteration whose counters were copied into each ring slot (-1: none)
+        for (int &v : ring_iter) v = -1;
+        Counters seen;
+        memset(&seen, 0, sizeof(seen));
+        long long guard = 0;
+        while (done_subs < subs.size()) {
+            // 1. the newest copy of the counters that has arrived (never the iteration just enqueued, unless the GPU is already through it)
+            {
+                // at most `lag` iterations ahead of what has been seen: wait for the oldest outstanding copy beyond that
+                int oldest_needed = iter - 1 - lag;
+                for (int j = newest_seen + 1; j <= oldest_needed; ++j) {
+                    const int slot = j % gnxr_scene::kRing;
+                    if (j >= 0 && ring_iter[slot] == j) HIP_TRY(hipEventSynchronize(s->ring_ev[slot]));
+                }
+                for (int j = iter - 1; j > newest_seen; --j) {
+                    const int slot = ((j % gnxr_scene::kRing) + gnxr_scene::kRing) % gnxr_scene::kRing;
+                    if (j < 0 || ring_iter[slot] != j) continue;
+                    if (hipEventQuery(s->ring_ev[slot]) == hipSuccess) { seen = s->h_ring[slot]; newest_seen = j; break; }
+                }
+                (void)hipGetLastError();   // hipEventQuery reports "not ready" as an error
             }
-            // B. start the next sub-pass when its half is free and the one in flight has reached its thin bounces
-            int trace_idx = out_idx, n_trace = n_next;
-            if (next < subs.size() && next - oldest < (size_t)in_flight && (next == oldest || subs[oldest].iters >= cut)) {
-                Sub &nw = subs[next];
-                hipLaunchKernelGGL(k_raygen, dim3(grid_for(nw.n_paths)), dim3(kBlock), 0, stream, sc, r, pa_at(nw.base), nw.n_paths, nw.s0);
-                // survivors of the older sub-pass + every slot of the new one, ascending: into the buffer the shaded queue came from
-                hipLaunchKernelGGL(k_queue_merge, dim3(grid_for((long long)n_next + nw.n_paths)), dim3(kBlock), 0, stream, (const int *)qbuf[out_idx], n_next, (int)nw.base, nw.n_paths,
-                                   nw.base > 0 ? 1 : 0, qbuf[in_idx]);
+            // 2. sub-passes none of whose paths continues are complete once their last light estimates are added (stream order: the
+            //    k_nee_combine of the iteration that produced the zero is already enqueued): colObj += Li in sample order
+            //    -- and in sub-pass order: a sub-pass that ends before an earlier one keeps its region until that one is added
+            for (bool progress = true; progress;) {
+                progress = false;
+                for (int rg = 0; rg < R; ++rg) {
+                    Region &g = reg[rg];
+                    if (g.sub == (int)done_subs && newest_seen > g.started && seen.region_alive[rg] == 0) {
+                        hipLaunchKernelGGL(k_resolve, dim3(grid_for(r.npix)), dim3(kBlock), 0, stream, pa_at((size_t)rg * half), s->accum.p, r.npix, subs[g.sub].kk);
+                        ++launches; ++passes; ++done_subs;
+                        g.sub = -1;
+                        progress = true;
+                    }
+                }
+            }
+            if (done_subs == subs.size()) break;
+            // upper bound of the paths queued for this iteration's shade stage
+            bool any_active = false;
+            long long n_upper = 0;
+            for (int rg = 0; rg < R; ++rg) {
+                const Region &g = reg[rg];
+                if (g.sub < 0) continue;
+                any_active = true;
+                n_upper += newest_seen > g.started ? std::min<long long>(g.paths, seen.region_alive[rg]) : g.paths;
+            }
+            // A. shade what the last trace found; survivors go to the buffer that does not hold the input queue
+            const int out_idx = 1 - in_idx;
+            if (any_active) {
+                if ((rc = shade_stage(qbuf[in_idx], (int)n_upper, qbuf[out_idx], cnt_ptr)) != GNXR_OK) { set_error("HIP runtime error in the path loop: %s", hipGetErrorString(hipGetLastError())); return rc; }
+                hipLaunchKernelGGL(k_loop_tail, dim3(1), dim3(64), 0, stream, (const int *)qbuf[out_idx], dctr, R, (int)half, (unsigned)iter);
+                ++launches;
+                const int slot = iter % gnxr_scene::kRing;
+                HIP_TRY(hipMemcpyAsync(&s->h_ring[slot], dctr, sizeof(Counters), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipEventRecord(s->ring_ev[slot], stream));
+                ring_iter[slot] = iter;
+            }
+            // B. start the next sub-pass in a free region
+            int trace_idx = out_idx;
+            long long n_trace_upper = n_upper;
+            int free_rg = -1;
+            for (int rg = 0; rg < R && free_rg < 0; ++rg) if (reg[rg].sub < 0) free_rg = rg;
+            const bool start = next_sub < subs.size() && free_rg >= 0 && (!any_active || iter - last_start >= stagger);
+            if (start) {
+                const Sub &nw = subs[next_sub];
+                const int n_new = r.npix * nw.kk;
+                const size_t base = (size_t)free_rg * half;
+                hipLaunchKernelGGL(k_raygen, dim3(grid_for(n_new)), dim3(kBlock), 0, stream, sc, r, pa_at(base), n_new, nw.s0);
+                // survivors + every slot of the new sub-pass, ascending: into the buffer the shaded queue came from
+                hipLaunchKernelGGL(k_queue_merge, dim3(grid_for(n_upper + n_new)), dim3(kBlock), 0, stream, (const int *)qbuf[out_idx], dctr, any_active ? 0 : 1, free_rg, (int)base, n_new, qbuf[in_idx]);
                 launches += 2;
-                trace_idx = in_idx; n_trace = n_next + nw.n_paths;
-                nw.alive = nw.n_paths; nw.iters = 0;
-                ++next;
+                trace_idx = in_idx; n_trace_upper = n_upper + n_new;
+                new_paths += (unsigned long long)n_new;
+                reg[free_rg].sub = (int)next_sub; reg[free_rg].started = iter; reg[free_rg].paths = n_new;
+                last_start = iter;
+                ++next_sub;
             }
             // C. continuation rays (and new camera rays), shadow and MIS rays of the vertices just shaded; then their light estimates
-            launch_trace(TraceWork{qbuf[trace_idx], n_trace, s->queue_nee.p, n_nee, nullptr, reinterpret_cast<unsigned char *>(s->nee_vis.p)}, n_sh, n_mis);
-            if (n_nee > 0) {
-                if (timing) timer.begin(1, stream);
-                hipLaunchKernelGGL(k_nee_combine, dim3(grid_for(n_nee)), dim3(kBlock), 0, stream, pa, (const int *)s->queue_nee.p, n_nee, reinterpret_cast<const unsigned char *>(s->nee_vis.p));
-                if (timing) timer.end(stream);
-                ++launches;
+            if (any_active || start) {
+                TraceWork tw{qbuf[trace_idx], (int)n_trace_upper, s->queue_nee.p, any_active ? (int)n_upper : 0, nullptr, reinterpret_cast<unsigned char *>(s->nee_vis.p), cnt_ptr,
+                             any_active ? (const unsigned *)&dctr->q_nee : nullptr};
+                launch_trace(tw, 0, 0, false);
+                if (any_active) {
+                    if (timing) timer.begin(1, stream);
+                    hipLaunchKernelGGL(k_nee_combine, dim3(grid_for(n_upper)), dim3(kBlock), 0, stream, pa, (const int *)s->queue_nee.p, (int)n_upper, reinterpret_cast<const unsigned char *>(s->nee_vis.p),
+                                       (const unsigned *)&dctr->q_nee);
+                    if (timing) timer.end(stream);
+                    ++launches;
+                }
+                in_idx = trace_idx;
             }
-            // D. a sub-pass none of whose paths continues is complete once the estimates above are added: colObj += Li in sample order
-            while (oldest < next && subs[oldest].alive == 0) {
-                const Sub &d = subs[oldest];
-                hipLaunchKernelGGL(k_resolve, dim3(grid_for(r.npix)), dim3(kBlock), 0, stream, pa_at(d.base), s->accum.p, r.npix, d.kk);
-                ++launches; ++passes; ++oldest;
-            }
-            in_idx = trace_idx; n = n_trace;
-            if (++guard > (1 << 16)) { set_error("path loop did not terminate"); return GNXR_ERR_INVALID; }
+            ++iter; ++loop_iterations;
+            if (++guard > (1ll << 24)) { set_error("path loop did not terminate"); return GNXR_ERR_INVALID; }
         }
     } else
     for (int s0 = p.spp_begin; s0 < p.spp_end; s0 += k) {
@@ -1031,6 +1147,11 @@ else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, slds, stream,
     HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
     if (stats) {
         memset(stats, 0, sizeof(*stats));
+        if (!whitted && !volpath) {   // the device-driven loop counts on the device; only the camera rays are known to the host
+            rays_closest = new_paths + s->h_counters->rays_continue + s->h_counters->rays_mis;
+            rays_any = s->h_counters->rays_shadow;
+            rays_mis = s->h_counters->rays_mis;
+        }
         stats->rays_closest = rays_closest + (whitted ? s->h_counters->whitted_mis : 0);
         stats->rays_any = whitted ? s->h_counters->whitted_shadow : rays_any;
         stats->camera_samples = (uint64_t)r.npix * nsamples;
@@ -1040,6 +1161,12 @@ else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, slds, stream,
         stats->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
         stats->kernel_launches = launches;
         stats->passes = passes;
+        stats->passes_in_flight = (uint32_t)in_flight;
+        stats->loop_iterations = loop_iterations;
+        {   // what this render keeps resident per path slot: the float4 / uint2 / int state arrays, the queues and the per-path bytes
+            const unsigned long long per_slot = 11ull * sizeof(float4) + sizeof(uint2) + 8ull * sizeof(int) + 2 + sizeof(unsigned int);
+            stats->state_bytes = (unsigned long long)cap * per_slot + (volpath ? (unsigned long long)cap * (6ull * sizeof(float4) + sizeof(int4) + 1) : 0ull);
+        }
         stats->seconds_closest = timer.seconds[0]; stats->seconds_nee = timer.seconds[1]; stats->seconds_shade = timer.seconds[2];
         stats->seconds_trace = timer.seconds[0] + timer.seconds[1];
         stats->launches_closest = timer.launches[0]; stats->launches_nee = timer.launches[1];
@@ -1070,6 +1197,7 @@ static int render_sharded(gnxr_scene *s, const gnxr_render_params *pin, void *d_
     std::vector<int> rcs(nd, GNXR_OK);
     std::vector<std::string> errs(nd);
     std::vector<gnxr_stats> sts(nd);
+    std::vector<int> staged(nd, 0);   // rows a shard left in its pinned staging buffer (no peer access between its device and the primary)
     hipStream_t caller = (hipStream_t)hip_stream;
     int rc = s->bind();
     if (rc) return rc;
@@ -1086,15 +1214,30 @@ static int render_sharded(gnxr_scene *s, const gnxr_render_params *pin, void *d_
         if (rc_ == GNXR_OK && i > 0) { rc_ = r->shard_out.alloc(npx); dst = r->shard_out.p; }
         if (rc_ == GNXR_OK) rc_ = render_one(r, &p, dst, i == 0 ? hip_stream : nullptr, &sts[i]);
         if (rc_ == GNXR_OK && i > 0 && !reserve_only) {
-            // rows p.shard_index, + p.shard_count, ...: one strided copy into the primary's image (UVA: the runtime routes it over the peer link)
+            // rows p.shard_index, + p.shard_count, ...
             const int first = p.shard_index, step = p.shard_count;
             const int rows = first < base.height ? (base.height - first + step - 1) / step : 0;
             const size_t rowb = (size_t)base.width * sizeof(float4);
-            if (rows > 0) {
+            const bool peer = (size_t)i < g_peer_ok.size() ? g_peer_ok[i] != 0 : r->device == s->device;
+            if (rows > 0 && peer) {
+                // one strided copy into the primary's image (peer access was enabled both ways at init: the runtime routes it over the link)
                 hipError_t e = hipMemcpy2DAsync((char *)d_rgba_out + (size_t)first * rowb, rowb * step, (const char *)dst + (size_t)first * rowb, rowb * step, rowb, rows,
                                                 hipMemcpyDeviceToDevice, nullptr);
                 if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
                 if (e != hipSuccess) { set_error("peer copy from device %d failed: %s", r->device, hipGetErrorString(e)); rc_ = hip_status(e); }
+            } else if (rows > 0) {
+                // no peer access for this pair: the shard's rows go to a pinned host buffer here (packed), and the primary uploads them after the join
+                if (r->h_stage_bytes < rowb * rows) {
+                    if (r->h_stage) (void)hipHostFree(r->h_stage);
+                    r->h_stage = nullptr; r->h_stage_bytes = 0;
+                    if (hipHostMalloc(&r->h_stage, rowb * rows) != hipSuccess) { set_error("hipHostMalloc of the %zu-byte staging buffer for device %d failed", rowb * rows, r->device); rc_ = GNXR_ERR_OOM; }
+                    else r->h_stage_bytes = rowb * rows;
+                }
+                if (rc_ == GNXR_OK) {
+                    hipError_t e = hipMemcpy2D(r->h_stage, rowb, (const char *)dst + (size_t)first * rowb, rowb * step, rowb, rows, hipMemcpyDeviceToHost);
+                    if (e != hipSuccess) { set_error("download of device %d's rows failed: %s", r->device, hipGetErrorString(e)); rc_ = hip_status(e); }
+                    else staged[i] = rows;
+                }
             }
         }
         rcs[i] = rc_;
@@ -1105,6 +1248,14 @@ static int render_sharded(gnxr_scene *s, const gnxr_render_params *pin, void *d_
     worker(0);
     for (auto &t : pool) t.join();
     (void)s->bind();
+    for (int i = 1; i < nd; ++i) {   // host-staged shards: upload their rows into the image on the primary device
+        if (staged[i] <= 0 || rcs[i] != GNXR_OK) continue;
+        gnxr_scene *r = s->replicas[i - 1].get();
+        const int first = base.shard_index + base.shard_count * i, step = base.shard_count * nd;
+        const size_t rowb = (size_t)base.width * sizeof(float4);
+        hipError_t e = hipMemcpy2D((char *)d_rgba_out + (size_t)first * rowb, rowb * step, r->h_stage, rowb, rowb, staged[i], hipMemcpyHostToDevice);
+        if (e != hipSuccess) { rcs[i] = hip_status(e); errs[i] = std::string("upload of the staged rows failed: ") + hipGetErrorString(e); }
+    }
     for (int i = 0; i < nd; ++i) if (rcs[i] != GNXR_OK) { set_error("device %d: %s", i == 0 ? s->device : s->replicas[i - 1]->device, errs[i].c_str()); return rcs[i]; }
     if (stats) {
         *stats = sts[0];

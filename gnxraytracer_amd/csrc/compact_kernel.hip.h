@@ -34,10 +34,14 @@ constexpr int kCompactTile = kCompactBlock * kCompactChunks;
 template <int MODE, int NOUT>
 __global__ void __launch_bounds__(kCompactBlock) k_compact_count(const int *__restrict__ q_in, int n, const unsigned char *__restrict__ keys, unsigned int *tile_counts,
                                                                  int nTiles, const int *__restrict__ hit = nullptr, const unsigned char *__restrict__ tri_class = nullptr,
-                                                                 unsigned char *keys_out = nullptr, int split = 0) {
+                                                                 unsigned char *keys_out = nullptr, int split = 0, const unsigned *n_dev = nullptr) {
     __shared__ unsigned int wsum[NOUT][kCompactBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+    // n_dev: the item count lives on the device (the device-driven path loop); `n` / `nTiles` then bound it, and nTiles stays the row stride
+    // of tile_counts in all three passes
+    if (n_dev) n = (int)*n_dev;
+    const int tilesUsed = n_dev ? (n + kCompactTile - 1) / kCompactTile : nTiles;
+    for (int tile = blockIdx.x; tile < tilesUsed; tile += gridDim.x) {
         unsigned acc[NOUT];
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) acc[o] = 0;
@@ -74,12 +78,13 @@ __global__ void __launch_bounds__(kCompactBlock) k_compact_count(const int *__re
 }
 
 // pass 2: exclusive scan of each predicate's tile counts (one 1024-thread block per predicate), totals[o] = sum
-static __global__ void __launch_bounds__(1024) k_compact_scan(unsigned int *tile_counts, int nTiles, unsigned int *totals) {
+static __global__ void __launch_bounds__(1024) k_compact_scan(unsigned int *tile_counts, int nTiles, unsigned int *totals, const unsigned *n_dev = nullptr) {
     __shared__ unsigned int wtot[16];
     __shared__ unsigned int carry_s;
     unsigned int *c = tile_counts + (size_t)blockIdx.x * nTiles;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_s = 0;
+    if (n_dev) nTiles = ((int)*n_dev + kCompactTile - 1) / kCompactTile;   // tiles in use; `c` keeps the row stride of the launch
     __syncthreads();
     for (int base = 0; base < nTiles; base += 1024) {
         int i = base + threadIdx.x;
@@ -103,11 +108,14 @@ static __global__ void __launch_bounds__(1024) k_compact_scan(unsigned int *tile
 // pass 3: write the survivors of the first NSCATTER predicates at tile_offset + rank-within-tile (chunk by chunk, in order)
 template <int MODE, int NSCATTER>
 __global__ void __launch_bounds__(kCompactBlock) k_compact_scatter(const int *__restrict__ q_in, int n, const unsigned char *__restrict__ keys,
-                                                                   const unsigned int *__restrict__ tile_offsets, int nTiles, int *out0, int *out1, int *out2, int *out3 = nullptr) {
+                                                                   const unsigned int *__restrict__ tile_offsets, int nTiles, int *out0, int *out1, int *out2, int *out3 = nullptr,
+                                                                   const unsigned *n_dev = nullptr) {
     __shared__ unsigned int wsum[NSCATTER][kCompactBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int *outs[4] = {out0, out1, out2, out3};
-    for (int tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+    if (n_dev) n = (int)*n_dev;
+    const int tilesUsed = n_dev ? (n + kCompactTile - 1) / kCompactTile : nTiles;
+    for (int tile = blockIdx.x; tile < tilesUsed; tile += gridDim.x) {
         unsigned base[NSCATTER];
 #pragma unroll
         for (int o = 0; o < NSCATTER; ++o) base[o] = tile_offsets[(size_t)o * nTiles + tile];

@@ -43,6 +43,7 @@ struct PathArrays {
     unsigned int *nee_vis;   // PathIntegrator: per path [0] shadow ray unoccluded, [1] MIS ray found what it expects (bytes written by k_trace), [2] record flags (k_shade)
 };
 
+constexpr int kMaxRegions = 8;   // sub-passes in flight at most (each in its own region of the state arrays)
 struct Counters {
     unsigned long long nodes, tris;
     unsigned int q_next, q_nee, q_shadow, q_mis;   // k_compact_scan totals: paths that continue / have NEE / shadow rays / MIS rays
@@ -54,6 +55,12 @@ struct Counters {
     unsigned long long media_steps;                 // tracking-loop iterations of k_vol_media<COUNT>
     unsigned long long retests;                     // k_trace<COUNT, WIDE>: leaf boxes re-tested against a shrunken tMax (32 B each)
     unsigned long long nodes_global;                // k_trace4<COUNT>: node visits served from global memory (the others come from the LDS copy of the top of the tree)
+    // ---- the device-driven PathIntegrator loop (api.hip): the host never waits for these, it reads lagging copies
+    unsigned int n_queue;                           // entries of the trace queue after k_queue_merge put a new sub-pass in
+    unsigned int iter;                              // stamp: the loop iteration whose shade stage produced the counts above
+    unsigned int region_lb[kMaxRegions + 1];        // position in the survivors' queue of the first slot of each state region (k_loop_tail)
+    unsigned int region_alive[kMaxRegions];         // paths of each region that continue
+    unsigned long long rays_continue, rays_shadow, rays_mis;   // summed over the iterations: continuation rays of surviving paths, shadow rays, MIS rays
 };
 
 struct DScene {
@@ -321,10 +328,16 @@ GX_DEV Spec nee_record_Ld(const PathArrays &pa, size_t rec, float *xw) {
 // ------------------------------------------------------------------------------------------------
 // One specialisation per (lobe set LM, light-type set LT): device_bsdf.h LM_*, device_lights.h LT_*.  `n_dev`
 // points at the fill count of `queue` written by k_compact_scan (device-side, no host round trip).
+#ifndef GX_SHADE_MINWAVES
+#define GX_SHADE_MINWAVES 2
+#endif
 #ifdef GX_SHADE_WAVES
 #define GX_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(GX_SHADE_WAVES, GX_SHADE_WAVES)))
 #else
-#define GX_SHADE_ATTR
+// at least two waves per SIMD: with launch bounds of 256 threads alone the register allocator may take up to 512 registers per lane, and the
+// Disney-class instantiations settled at 257 (256 VGPRs + 1 AGPR) -- one register past the point where a SIMD holds two waves
+// (tests/test_abi.py::test_kernel_register_budgets reads the code-object notes of every kernel)
+#define GX_SHADE_ATTR __attribute__((amdgpu_waves_per_eu(GX_SHADE_MINWAVES)))
 #endif
 // TEX: the queue holds hits on image-textured materials (shade class 3): Kd / Ks are looked up per hit, unfiltered -- PathIntegrator
 // slices the camera RayDifferential (`Ray ray(r)`, PathIntegrator.cpp:67), so ComputeDifferentials always takes its zero branch.
@@ -335,8 +348,21 @@ static __device__ unsigned long long g_shade_stats[16];
 #else
 #define GX_STICK(i) do {} while (0)
 #endif
+// minimum waves per SIMD of each material class (tuning knobs: tools/build_variant.sh -DGX_SHADE_W_DIFFUSE=4 ...).  Measured on cfg 3 /
+// cfg 4 (profiles/README.md, round 3): three waves for the diffuse and the glossy class (168 registers: the glossy kernels spill ~100
+// dwords to scratch and still gain) -- shade -7 % / -15 %; four waves for the diffuse class lose again; the Disney class stays at two.
+#ifndef GX_SHADE_W_DIFFUSE
+#define GX_SHADE_W_DIFFUSE 3
+#endif
+#ifndef GX_SHADE_W_GLOSSY
+#define GX_SHADE_W_GLOSSY 3
+#endif
+#ifndef GX_SHADE_W_ALL
+#define GX_SHADE_W_ALL GX_SHADE_MINWAVES
+#endif
+template <uint32_t LM> constexpr int shade_min_waves() { return LM == LM_DIFFUSE ? GX_SHADE_W_DIFFUSE : (LM == LM_GLOSSY ? GX_SHADE_W_GLOSSY : GX_SHADE_W_ALL); }
 template <uint32_t LM, int LT, bool SPH, bool TEX = false>
-__global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRender r, PathArrays pa, const int *__restrict__ queue, const unsigned int *n_dev, int lds_dims, int lds_nperm, int lds_mats, int lds_lights) {
+__global__ void __launch_bounds__(kBlock, shade_min_waves<LM>()) k_shade(DScene sc, DRender r, PathArrays pa, const int *__restrict__ queue, const unsigned int *n_dev, int lds_dims, int lds_nperm, int lds_mats, int lds_lights) {
     extern __shared__ int shade_smem[];   // the Halton tables of dimensions [0, lds_dims): device_sampler.h LdsSampler | the scene's DMaterial[] | DLight[]
     const int n = (int)*n_dev;
     if (blockIdx.x * blockDim.x >= (unsigned)n) return;   // this block has no item: skip the table fill
@@ -579,15 +605,45 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_shade(DScene sc, DRend
 #endif
 }
 
-// The queue of the next trace when a sub-pass starts: the survivors of the older sub-pass (ascending slots of the other half of the
-// state arrays) and every slot [base, base + n_new) of the new one, merged in ascending order.
-static __global__ void __launch_bounds__(kBlock) k_queue_merge(const int *__restrict__ q_old, int n_old, int base, int n_new, int new_is_upper, int *__restrict__ q_out) {
+// The queue of the next trace when a sub-pass starts in state region `region` = slots [base, base + n_new): the survivors of the
+// sub-passes in flight (ascending slots, none of them inside the region -- it was empty) and every slot of the new one, merged in
+// ascending order.  The survivors' count and the split position (how many of them lie below `base`: k_loop_tail) are read on the device;
+// a launch before any shade stage has run passes first = 1 (no survivors).  The merged count goes to ctr->n_queue.
+static __global__ void __launch_bounds__(kBlock) k_queue_merge(const int *__restrict__ q_old, Counters *ctr, int first, int region, int base, int n_new, int *__restrict__ q_out) {
+    const unsigned n_old = first ? 0u : ctr->q_next, split = first ? 0u : ctr->region_lb[region];
     const long long total = (long long)n_old + n_new;
     for (long long i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         int v;
-        if (new_is_upper) v = i < n_old ? q_old[i] : base + (int)(i - n_old);
-        else v = i < n_new ? base + (int)i : q_old[i - n_new];
+        if (i < split) v = q_old[i];
+        else if (i < (long long)split + n_new) v = base + (int)(i - split);
+        else v = q_old[i - n_new];
         q_out[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctr->n_queue = (unsigned)total;
+}
+
+// After the flags compaction of a shade stage: where each state region starts in the survivors' queue (binary search: the queue is
+// ascending), how many paths of each region are left, the ray totals of the next trace, and the iteration stamp the host's lagging copy
+// is recognised by.
+static __global__ void __launch_bounds__(64) k_loop_tail(const int *__restrict__ q_next, Counters *ctr, int n_regions, int region_size, unsigned iter) {
+    __shared__ unsigned lb[kMaxRegions + 1];
+    const unsigned n = ctr->q_next;
+    const int r = threadIdx.x;
+    if (r <= n_regions) {
+        const long long key = (long long)r * region_size;
+        unsigned lo = 0, hi = n;
+        while (lo < hi) { const unsigned mid = (lo + hi) >> 1; if ((long long)q_next[mid] < key) lo = mid + 1; else hi = mid; }
+        lb[r] = lo;
+        ctr->region_lb[r] = lo;
+    }
+    __syncthreads();
+    if (r < n_regions) ctr->region_alive[r] = lb[r + 1] - lb[r];
+    if (r == 0) {
+        ctr->rays_continue += n; ctr->rays_shadow += ctr->q_shadow; ctr->rays_mis += ctr->q_mis;
+        // the count of the queue the next trace and the next shade stage work on lives in n_queue (k_queue_merge adds a new sub-pass to
+        // it): q_next is rewritten by the next stage's own compaction while its kernels still read the input count
+        ctr->n_queue = n;
+        ctr->iter = iter;
     }
 }
 

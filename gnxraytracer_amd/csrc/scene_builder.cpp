@@ -639,9 +639,13 @@ int gnxr_builder_add_volume_file(gnxr_builder *b, const char *path, float g, flo
     struct { const char *name; float *v; } rows[4] = {{"p0", p0}, {"p1", p1}, {"sigma_a", sa}, {"sigma_s", ss}};
     for (auto &r : rows)
         if (fscanf(fp, "%31s %f %f %f", key, &r.v[0], &r.v[1], &r.v[2]) != 4 || strcmp(key, r.name) != 0) return fail("bad .volume header (p0 / p1 / sigma_a / sigma_s)");
-    const size_t count = (size_t)n[0] * n[1] * n[2];
+    // untrusted sizes: each dimension is bounded before the product is formed (three ints near INT_MAX would wrap a 64-bit product),
+    // and an allocation failure comes back as a status, never as an exception through the C boundary
+    for (int i = 0; i < 3; ++i) if (n[i] > 4096) return fail("density grid dimension above 4096");
+    const size_t count = (size_t)n[0] * (size_t)n[1] * (size_t)n[2];
     if (count >= (1ull << 31)) return fail("density grid too large");
-    std::vector<float> dens(count);
+    std::vector<float> dens;
+    try { dens.resize(count); } catch (const std::bad_alloc &) { fclose(fp); set_error("%s: out of memory for %zu densities", path, count); return GNXR_ERR_OOM; }
     for (size_t i = 0; i < count; ++i)
         if (fscanf(fp, "%f", &dens[i]) != 1) return fail("truncated density data");
     fclose(fp);

@@ -73,7 +73,10 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
     const int spillStride = (int)gridDim.x * kBlock;
     const int lane = __lane_id();
     lds_int *const rq = (lds_int *)&smem[lds_entries * kBlock + (threadIdx.x >> 6) * kRayQueue];   // this wave's records: rq[field * kRqStride + slot]
+    trace_work_counts(w);
     const unsigned total = (unsigned)w.n_closest + 2u * (unsigned)w.n_nee;
+    chunk = trace_chunk(total, chunk);
+    const ChunkPlan plan = chunk_plan(total, (unsigned)chunk);
     const DTri *__restrict__ tris = sc.tris;
     const char *__restrict__ nb = reinterpret_cast<const char *>(sc.nodes4);
     typedef float f4v __attribute__((ext_vector_type(4)));
@@ -180,11 +183,10 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
         if (needMask) {
             if (rqCount == 0) {
                 if (poolCount == 0 && !exhausted) {
-                    unsigned base = 0;
-                    if (lane == 0) base = atomicAdd(cursor, (unsigned)chunk);
-                    base = __shfl(base, 0);
-                    if (base >= total) exhausted = true;
-                    else { poolBase = base; poolCount = min((unsigned)chunk, total - base); }
+                    unsigned v = 0;
+                    if (lane == 0) v = atomicAdd(cursor, 1u);   // the cursor counts chunks (chunk_plan / chunk_range, trace_kernel.hip.h)
+                    v = __shfl(v, 0);
+                    if (!chunk_range(plan, v, total, &poolBase, &poolCount)) { exhausted = true; poolCount = 0; }
                 }
                 if (poolCount > 0) {
                     // ---- batch set-up: every lane prepares one work item (the ray-only part of Bounds3::IntersectP and Triangle::Intersect)

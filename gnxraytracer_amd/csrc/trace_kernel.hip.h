@@ -31,7 +31,53 @@ struct TraceWork {
     unsigned char *vis;                    // nullptr: visibility results go to sh_o[path].w / mis_o[path].w (float 1 / 0).  Otherwise 4 bytes per path:
                                            // [0] shadow ray unoccluded, [1] MIS ray found what the light sample expects (written here), [2] the record's
                                            // flags (written by k_shade) -- k_nee_combine then reads one word instead of three float4
+    const unsigned *n_closest_dev, *n_nee_dev;   // nullptr, or where the two counts live on the device (the device-driven path loop: the host never reads
+                                           // them; n_closest / n_nee then only bound the launch)
 };
+// the counts a traversal kernel works on: the device-side ones when the launch carries them
+GX_DEV void trace_work_counts(TraceWork &w) {
+    if (w.n_closest_dev) { w.n_closest = (int)*w.n_closest_dev; w.n_nee = w.n_nee_dev ? (int)*w.n_nee_dev : 0; }
+}
+// rays a wave takes per global atomic: `chunk_max` for big launches; for thin ones (late bounces) small enough that every wave gets a chunk --
+// the number of atomics stays <= the number of waves, well under the ~88/us a single address sustains
+GX_DEV int trace_chunk(unsigned total, int chunk_max) {
+    const unsigned waves = gridDim.x * (blockDim.x / 64u);
+    const unsigned per = ((total + waves - 1u) / waves + 63u) / 64u * 64u;
+    return (int)min((unsigned)chunk_max, max(64u, per));
+}
+
+// Hand-out schedule of a launch's work items (k_trace4 / k_trace4d).  The global cursor counts CHUNKS, one atomic per fetch, and chunk v
+// maps to a range of items by position: `c`-item chunks (512, or a wave's even share when the launch is thin) for most of the launch,
+// then 128-item and finally 64-item chunks for the last ~1.5 chunks' worth of work per wave -- so the waves of a launch finish within a
+// 64-ray batch of each other instead of within a 512-ray chunk (~0.15 ms per launch: nothing for a 265 M-ray launch, 3 - 4 % of the 25 M-ray
+// launches of small sub-passes).  Sizing the request from a fresh read of the cursor was tried first and lost badly (trace +67 %: the extra
+// load of the contended line); this form costs no memory operation beyond the one atomic.
+struct ChunkPlan { unsigned c, big, k1, mid_end, k2; };
+GX_DEV ChunkPlan chunk_plan(unsigned total, unsigned c) {
+    const unsigned waves = gridDim.x * (blockDim.x / 64u);
+    ChunkPlan p;
+    p.c = c;
+    const unsigned tail = waves * 384u;
+    p.big = (c > 128u && total > tail) ? (total - tail) / c * c : 0u;
+    p.k1 = p.big / c;
+    const unsigned mid = min(total - p.big, waves * 256u) / 128u * 128u;
+    p.mid_end = p.big + mid;
+    p.k2 = mid / 128u;
+    return p;
+}
+GX_DEV bool chunk_range(const ChunkPlan &p, unsigned v, unsigned total, unsigned *base, unsigned *count) {
+    unsigned b, n;
+    if (v < p.k1) { b = v * p.c; n = p.c; }
+    else if (v < p.k1 + p.k2) { b = p.big + (v - p.k1) * 128u; n = 128u; }
+    else {
+        const unsigned long long bb = (unsigned long long)p.mid_end + (unsigned long long)(v - p.k1 - p.k2) * 64ull;
+        if (bb >= total) return false;
+        b = (unsigned)bb; n = 64u;
+    }
+    if (b >= total) return false;
+    *base = b; *count = min(n, total - b);
+    return true;
+}
 
 constexpr int kTraceChunk = 512;   // most rays a wave takes per global atomic (the host shrinks the chunk for thin launches so that every wave gets one)
 #ifndef GX_TRACE_LEAVE_MUL
@@ -152,7 +198,9 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
     stack.stride = (int)gridDim.x * kBlock;
     stack.spill = (global_int *)(spill + (size_t)blockIdx.x * kBlock + threadIdx.x);
     const int lane = __lane_id();
+    trace_work_counts(w);
     const unsigned total = (unsigned)w.n_closest + 2u * (unsigned)w.n_nee;
+    chunk = trace_chunk(total, chunk);
     const float4 *__restrict__ nodes = sc.nodes;
     const DTri *__restrict__ tris = sc.tris;
 
@@ -416,7 +464,8 @@ static __global__ void __launch_bounds__(kBlock) k_trace_keys(PathArrays pa, Tra
 // two visibility results of the vertex are known.  Pure streaming: per NEE vertex one word of flags + results (TraceWork::vis), X, Y when
 // the vertex has a MIS ray, beta and L (72 B read, 16 B written; the first version read the three float4 that carried flags and results
 // in their w lanes: 128 B).
-static __global__ void __launch_bounds__(kBlock) k_nee_combine(PathArrays pa, const int *__restrict__ queue, int n, const unsigned char *__restrict__ vis) {
+static __global__ void __launch_bounds__(kBlock) k_nee_combine(PathArrays pa, const int *__restrict__ queue, int n, const unsigned char *__restrict__ vis, const unsigned *n_dev = nullptr) {
+    if (n_dev) n = (int)*n_dev;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         int path = queue[i];
         const unsigned v = reinterpret_cast<const unsigned *>(vis)[path];

@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt
 // VolPathIntegrator.cpp:30) until the ray is replaced (pass-through, medium or surface scattering all assign a plain SpawnRay), so
 // a surface vertex reached by the camera ray itself filters its textures with the camera differentials (vs.w).
 template <uint32_t LM, int LT, int ST, bool TEX = false>
-__global__ void __launch_bounds__(kBlock) k_vol_step(DScene sc, DMediaTables mt, DRender r, PathArrays pa, VolArrays va, const int *__restrict__ queue, const unsigned int *n_dev, int lds_mats, int lds_lights) {
+__global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_vol_step(DScene sc, DMediaTables mt, DRender r, PathArrays pa, VolArrays va, const int *__restrict__ queue, const unsigned int *n_dev, int lds_mats, int lds_lights) {
     extern __shared__ int vstep_smem[];   // the scene's DMaterial[] | DLight[] when they are small (as in k_shade: dependent gathers along the BSDF code become LDS reads)
     const int n = (int)*n_dev;
     if (blockIdx.x * blockDim.x >= (unsigned)n) return;

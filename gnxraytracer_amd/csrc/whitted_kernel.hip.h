@@ -93,7 +93,7 @@ static __global__ void __launch_bounds__(kBlock) k_whitted_expand(const int *__r
 // TEX: the scene has image-textured materials -- the frames carry ray differentials (WhittedIntegrator / DirectLightingIntegrator
 // take the camera RayDifferential and SpecularReflect / SpecularTransmit derive the children's), textures are filtered with them.
 template <int MODE, int LT, bool SPH, bool TEX = false>
-__global__ void __launch_bounds__(kBlock) k_whitted_step(DScene sc, DRender r, PathArrays pa, WhittedArrays wa, const int *__restrict__ queue, int n,
+__global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_whitted_step(DScene sc, DRender r, PathArrays pa, WhittedArrays wa, const int *__restrict__ queue, int n,
                                                          unsigned long long *ray_counts) {
     unsigned long long nShadow = 0, nMis = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GNXR_ABI_VERSION 4
+#define GNXR_ABI_VERSION 5
 
 typedef enum gnxr_status {
     GNXR_OK = 0,
@@ -263,11 +263,13 @@ typedef struct gnxr_render_params {
     int32_t integrator;         /* gnxr_integrator                                           */
     int32_t light_strategy;     /* gnxr_light_strategy                                       */
     int32_t shard_index, shard_count, shard_rows;
-    int32_t samples_per_pass;   /* 0 = auto; samples of one pixel rendered per pass.  GNXR_INTEGRATOR_PATH keeps two
-                                   passes in flight when the call covers more than one (twice the path state): a pass's thin
-                                   late bounces share kernel launches with the first bounces of the next; the image does not
-                                   depend on the pass size */
+    int32_t samples_per_pass;   /* 0 = auto; samples of one pixel rendered per (sub-)pass.  The image does not depend on it */
     int32_t direct_strategy;    /* gnxr_direct_strategy (GNXR_INTEGRATOR_DIRECT only)        */
+    int32_t passes_in_flight;   /* GNXR_INTEGRATOR_PATH: sub-passes alive at once, each in its own region of the path state
+                                   (resident state = passes_in_flight x samples_per_pass samples per pixel); staggered in time,
+                                   so that a launch mixes the first bounces of one sub-pass with the thin late bounces of the
+                                   others.  0 = auto (4, fewer if the call is short or memory is tight), at most 8.  The image
+                                   does not depend on it.  Reference loop: core/Integrator.cpp:256-293 */
 } gnxr_render_params;
 
 typedef struct gnxr_stats {
@@ -290,6 +292,9 @@ typedef struct gnxr_stats {
     uint64_t media_steps;       /* VolPath: tracking-loop iterations of those segments (filled by the counting run, profiling bit 2) */
     uint64_t leaf_retests;      /* counting run, bit 2: leaf boxes re-tested against a shrunken tMax by the 4-wide walk (32 B each)  */
     uint64_t nodes_from_memory; /* counting run, bit 2: 4-wide node visits that read global memory (the rest hit the kernel's LDS copy of the top of the tree) */
+    uint32_t passes_in_flight;  /* sub-passes the path loop kept alive at once (1 for the other integrators)                          */
+    uint32_t loop_iterations;   /* iterations of the path loop (one trace + one shade stage each)                                     */
+    uint64_t state_bytes;       /* path state resident on the device for this render (per-path arrays and queues)                      */
 } gnxr_stats;
 
 typedef struct gnxr_ray { float o[3]; float tmax; float d[3]; float _pad; } gnxr_ray;
@@ -308,10 +313,12 @@ int gnxr_init(int device_id);          /* binds the calling process to one HIP d
 /* One process, several devices (`gnxr_init(int n_devices, const int *device_ids)`): scenes created afterwards are
  * replicated on every listed device and gnxr_render / gnxr_render_device deal the image rows round-robin over them, render the
  * shards concurrently (one host thread + stream per device, no exchange during rendering) and assemble the FrameBuffer on
- * device_ids[0] with one strided peer copy per device -- what the reference's single `integrator->Render(scene)` call
+ * device_ids[0] -- one strided peer copy per device where peer access could be enabled both ways (recorded per pair at init), a
+ * pinned host buffer otherwise; GNXR_NO_PEER=1 forces the staged route -- what the reference's single `integrator->Render(scene)` call
  * (ui/RenderThread.cpp:175, core/Integrator.h:17-23) needs to use a whole node.  Results are bit-identical to one device's
  * (pixels are independent).  The same id may be listed more than once (two shards sharing a device: how this path is tested on
- * a one-GPU box).  Batched trace calls and probes run on device_ids[0].  gnxr_init(d) == gnxr_init_devices(1, &d).            */
+ * a one-GPU box; on DISTINCT devices the path has not run yet: parity unpinned there, the pool hands out one-GPU boxes only).
+ * Batched trace calls and probes run on device_ids[0].  gnxr_init(d) == gnxr_init_devices(1, &d).                              */
 int gnxr_init_devices(int32_t n_devices, const int32_t *device_ids);
 void gnxr_shutdown(void);
 const char *gnxr_last_error(void);
@@ -435,7 +442,9 @@ int gnxr_builder_add_medium(gnxr_builder *b, const gnxr_medium *m, const float *
 /* GridDensityMedium from a `.volume` text file (the format of the reference's Resources/density_render.70.volume: `nx N ny N nz N`,
  * `p0 x y z`, `p1 x y z`, `sigma_a r g b`, `sigma_s r g b`, then nx*ny*nz densities): sigma_a / sigma_s of the header times
  * sigma_scale, Henyey-Greenstein g, MediumToWorld = medium_to_world16 or, when NULL, Translate(p0) * Scale(p1 - p0) of the header.
- * Returns the medium index.                                                                                                      */
+ * The reference ships the file but no reader for it, so the file semantics (x fastest, the p0 / p1 placement) are THIS project's
+ * definition -- parity unpinned for the loader, pinned for the medium it builds.  Each dimension <= 4096, at most 2^31 - 1 values;
+ * GNXR_ERR_IO for a malformed file, GNXR_ERR_OOM when the values do not fit in memory.  Returns the medium index.                  */
 int gnxr_builder_add_volume_file(gnxr_builder *b, const char *path, float g, float sigma_scale, const float *medium_to_world16);
 /* ImageTexture: `t` carries the mapping / filter parameters (width, height, texel_offset are filled in); returns the texture
  * index.  _file decodes a Radiance .hdr like stbi_loadf; other formats (the reference's awesomeface.jpg) must be decoded by the

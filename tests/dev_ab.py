@@ -8,6 +8,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     import numpy as np, torch
     import gnxraytracer_amd as gx, scenes
     spp, workload, passes = int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
+    spp = int(os.environ.get("GNXR_AB_SPP", spp)); passes = int(os.environ.get("GNXR_AB_PASSES", passes))   # per-variant overrides
     gx.init(0)
     b = scenes.dragon_cornell(100000, "glass+metal") if workload == "cfg3" else scenes.dragon_cornell(100000, "zoo", env=scenes.synthetic_env_path(1000, 500))
     scene = gx.Scene(b); integ = gx.PathIntegrator(8, 1.0, "spatial")
@@ -20,7 +21,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     rays = best["rays_closest"] + best["rays_any"]
     print(json.dumps({"variant": os.environ.get("GNXR_AB_NAME", "default"), "ms": round(best["seconds_render"] * 1e3, 3), "Mrays/s": round(rays / best["seconds_render"] / 1e6, 1),
                       "trace_ms": round(best["seconds_closest"] * 1e3, 3), "shade_ms": round(best["seconds_shade"] * 1e3, 3), "combine_ms": round(best["seconds_nee"] * 1e3, 3),
-                      "checksum": float(out.double().sum().item())}))
+                      "checksum": float(out.double().sum().item()), "in_flight": best.get("passes_in_flight"), "iters": best.get("loop_iterations"),
+                      "state_GB": round(best.get("state_bytes", 0) / 1e9, 1), "spp": spp, "passes": passes}))
 else:
     args = sys.argv[1:]
     spp, workload, passes = 32, "cfg3", 1

@@ -68,3 +68,21 @@ def test_c_caller_builds_and_fails_loudly_without_a_device(gx):
         pytest.skip("a GPU is present: the failure path cannot be observed")
     r = subprocess.run([cli, "--out", "/tmp/gnxr_cli_should_not_exist.png"], capture_output=True, text=True)
     assert r.returncode == 3 and "no HIP device" in r.stderr and not os.path.exists("/tmp/gnxr_cli_should_not_exist.png")
+
+
+def test_kernel_register_budgets(gx):
+    """Reads the code-object notes of every kernel in libgnxr.so (tools/kernel_regs.py): no kernel may need more than 256 registers
+    (VGPRs + AGPRs: 257 halve the occupancy to one wave per SIMD -- round 2 shipped the Disney-class k_shade at exactly 257), the
+    traversal kernel keeps its five waves per SIMD without spilling, and the shade kernels of the headline path hold the three waves per
+    SIMD they were measured to want (the glossy class pays for them with ~100 spilled dwords of scratch: bounded here)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_regs
+    ks = kernel_regs.kernels(gx.LIB_PATH)
+    assert len(ks) > 100, len(ks)
+    over = [(k["name"], k["vgpr"]) for k in ks if k["vgpr"] > 256]
+    assert not over, over
+    t4 = [k for k in ks if "k_trace4<false, false" in k["name"]]
+    assert t4 and all(k["waves_per_simd"] >= 5 and k["vgpr_spill"] == 0 for k in t4), t4
+    head = [k for k in ks if ("k_shade<458879u, 1, false, false>" in k["name"] or "k_shade<3u, 1, false, false>" in k["name"])]
+    assert len(head) == 2 and all(k["scratch"] <= 256 and k["waves_per_simd"] >= 3 for k in head), head

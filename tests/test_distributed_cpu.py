@@ -19,7 +19,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, shard_rows, out_path):
+def _worker(rank, world, port, shard_rows, out_path, H=37):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, os.path.dirname(here))
@@ -32,7 +32,7 @@ def _worker(rank, world, port, shard_rows, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     b = scenes.cornell()
     integ = gx.PathIntegrator(8, 1.0, "spatial")
-    W, H, spp = 40, 37, 4          # odd height: unequal shard sizes
+    W, spp = 40, 4                 # H: odd heights give unequal shard sizes
     img, st = ol.OracleScene(b).render(integ, W, H, spp, threads=2, shard_index=rank, shard_count=world, shard_rows=shard_rows)
     full = gather_framebuffer(torch.from_numpy(img), rank, world, shard_rows, dst=0)
     rays = torch.tensor([st["rays_closest"] + st["rays_any"]], dtype=torch.int64)
@@ -50,5 +50,16 @@ def test_two_rank_gather_reassembles_the_framebuffer(tmp_path, shard_rows):
     out = str(tmp_path / "out.npz")
     mp.spawn(_worker, args=(2, _free_port(), shard_rows, out), nprocs=2, join=True)
     r = np.load(out)
+    assert (r["full"].view(np.uint32) == r["ref"].view(np.uint32)).all()
+    assert int(r["rays"][0]) == int(r["ref_rays"])
+
+
+def test_four_rank_gather_with_a_height_not_divisible_by_four(tmp_path):
+    """world 4, 38 rows: ranks 0 and 1 own ten rows, ranks 2 and 3 nine -- the padded equal-size gather must drop the padding of the
+    short shards and the ray totals of the four shards must add up to the unsharded render's."""
+    out = str(tmp_path / "out4.npz")
+    mp.spawn(_worker, args=(4, _free_port(), 1, out, 38), nprocs=4, join=True)
+    r = np.load(out)
+    assert r["full"].shape[0] == 38
     assert (r["full"].view(np.uint32) == r["ref"].view(np.uint32)).all()
     assert int(r["rays"][0]) == int(r["ref_rays"])

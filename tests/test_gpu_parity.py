@@ -690,6 +690,24 @@ def test_multi_device_render_behind_the_abi(gpu, devices):
         gpu.init(0)
 
 
+def test_multi_device_assembly_without_peer_access(gpu, monkeypatch):
+    """A device pair for which peer access cannot be enabled assembles its rows through a pinned host buffer instead of a peer copy
+    (gnxr_init_devices records the outcome per pair; GNXR_NO_PEER=1 forces that route, here with device 0 listed three times).  Same
+    bits as one device, ragged height included."""
+    b = scenes.dragon_cornell(2000, "zoo", env=os.path.join(GOLDEN, "env_100x50.hdr"), mesh_path=os.path.join(GOLDEN, "mesh_2k.3d"))
+    integ, (W, H, spp) = gpu.PathIntegrator(8, 1.0, "spatial"), (97, 61, 6)
+    ref, rst = integ.Render(gpu.Scene(b), W, H, spp)
+    monkeypatch.setenv("GNXR_NO_PEER", "1")
+    try:
+        gpu.init_devices([0, 0, 0])
+        img, st = integ.Render(gpu.Scene(b), W, H, spp)
+        assert (st["rays_closest"], st["rays_any"]) == (rst["rays_closest"], rst["rays_any"])
+        assert (img.view(np.uint32) == ref.view(np.uint32)).all()
+    finally:
+        monkeypatch.delenv("GNXR_NO_PEER")
+        gpu.init(0)
+
+
 def test_light_grid_with_many_lights(gpu):
     """More lights than the unrolled k_light_grid handles (16): the general kernel uses the voxel's table slice as scratch and must
     produce the host restatement's bits; the render (spatial light selection over 22 lights) matches the oracle."""

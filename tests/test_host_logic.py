@@ -200,6 +200,16 @@ def test_bench_spawns_its_own_ranks(tmp_path, monkeypatch):
     assert rc == 7 and cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd and "--nnodes=1" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "2", "--steps", "4"]
     assert cmd[-5] == os.path.abspath(bench.__file__) and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # the whole-node case the driver may ask for: `python bench.py --gpus 8 --steps K --warmup W` with no launcher around it
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--gpus", "8", "--steps", "8", "--warmup", "2"])
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    cmd = seen["cmd"]
+    assert ex.value.code == 7   # the child's exit code is this process's
+    assert cmd[0] == bench.sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[cmd.index(os.path.abspath(bench.__file__)) + 1:] == ["--gpus", "8", "--steps", "8", "--warmup", "2"]
 
 
 def test_radiance_writer_round_trips_through_the_builder(gx, tmp_path):

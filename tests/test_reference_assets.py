@@ -86,3 +86,44 @@ def test_volume_reader_on_the_reference_density_file(gx):
     assert list(md.sigma_a) == [10.0] * 3 and list(md.sigma_s) == [90.0] * 3
     got = np.ctypeslib.as_array(d.grid_density, shape=(100 * 100 * 40,))
     assert (got.view(np.uint32) == g["density"].reshape(-1).astype(np.float32).view(np.uint32)).all()
+
+
+def _ref_render(b, args, W, H):
+    with tempfile.TemporaryDirectory() as td:
+        sp = os.path.join(td, "scene.bin")
+        ol.write_scene_file(b, sp)
+        raw = ol.run_ref(sp, "render", None, args)
+    img = np.frombuffer(raw[:W * H * 16], np.float32).reshape(H, W, 4)
+    cnt = np.frombuffer(raw[W * H * 16:W * H * 16 + 16], np.uint64)
+    return img, (int(cnt[0]), int(cnt[1]))
+
+
+@needs_ref
+def test_volpath_at_config_size_oracle_equals_reference_classes(gx):
+    """cfg 5's geometry at cfg 5's image size (512 x 512; 2 spp of HaltonSampler(2), sigma scaled by 0.05 so that no sample passes
+    Halton dimension 1000, where the reference is undefined): the two restatements of VolPathIntegrator::Li
+    (integrators/VolPathIntegrator.cpp:24-159) -- the oracle's and ref_driver.cpp's on the reference's own GridDensityMedium /
+    HomogeneousMedium / HenyeyGreenstein / BVH / light classes -- agree bit for bit, ray counts included.  The 64 x 64 fixture
+    (render_vol.npz) pins the same pair at fixture size; this closes the gap up to the configuration's own size."""
+    b = scenes.volume_cornell_cfg5(0.05, golden_dir=GOLDEN)
+    W, H, spp, depth = 512, 512, 2, 8
+    ol.olib().gnxo_max_dimension(1)
+    oimg, ost = ol.OracleScene(b).render(gx.VolPathIntegrator(depth, 1.0, "spatial"), W, H, spp, threads=8)
+    assert ol.olib().gnxo_max_dimension(1) < 1000
+    rimg, rrays = _ref_render(b, [W, H, spp, depth, 1.0, 0, 8, 1], W, H)
+    assert rrays == (ost["rays_closest"], ost["rays_any"])
+    assert (oimg[..., :3].view(np.uint32) == rimg[..., :3].view(np.uint32)).all()
+    assert rrays[0] > 2 * W * H   # media segments make several closest-hit rays per camera sample
+
+
+@needs_ref
+def test_direct_lighting_all_at_256_oracle_equals_reference_classes(gx):
+    """DirectLightingIntegrator, UniformSampleAll, on the one-of-each-material scene at 256 x 256 (integrators/
+    DirectLightingIntegrator.cpp:30-64 + the sample arrays of core/Sampler.cpp:52-72): oracle == the restatement on the reference's
+    Sampler / BSDF / light / BVH classes, bit for bit -- four times the linear size of the render_direct.npz fixture."""
+    b = scenes.material_zoo()
+    W, H, spp, depth = 256, 256, 4, 5
+    oimg, ost = ol.OracleScene(b).render(gx.DirectLightingIntegrator("all", depth), W, H, spp, threads=8)
+    rimg, rrays = _ref_render(b, [W, H, spp, depth, 1.0, 0, 8, 3, 0], W, H)
+    assert rrays == (ost["rays_closest"], ost["rays_any"])
+    assert (oimg[..., :3].view(np.uint32) == rimg[..., :3].view(np.uint32)).all()
