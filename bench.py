@@ -12,8 +12,10 @@ The mesh is the seeded SYNTHETIC stand-in for the reference's dragon.3d, which i
 
 A step = one pass of the hot path over one batch: `--spp-per-step` (default 128) consecutive Halton samples of every pixel.
 The default --steps 8 renders the full 1024 spp image, so `wall_to_1024spp_s` is measured, not extrapolated.  The steps of a
-contiguous sample range are submitted as one library call; the library renders them pass by pass with two passes in flight
-(the thin late bounces of a pass share kernel launches with the first bounces of the next).
+contiguous sample range are submitted as one library call; the library cuts the range into sub-passes (its own choice: ~64 M
+paths each, four alive at once in regions of the state arrays, staggered so that a launch mixes the first bounces of one with the
+thin late bounces of the others) and drives them with a device-side loop -- queue counts never come back to the host.
+After the default (cfg3) run, two-step runs of cfg4 and cfg5 are appended under "also".
 
 --gpus N > 1: one rank per GPU.  When no launcher has set WORLD_SIZE, bench.py starts its own ranks
 (`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process, before anything touches the GPU),
@@ -49,7 +51,7 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--spp-per-step", type=int, default=128,
-                    help="samples of every pixel rendered by one step = one pass; 128 at 1080p is 265 M paths, and two passes are in flight (118 GB of the 288 GB)")
+                    help="samples of every pixel rendered by one step; how a call's samples are cut into sub-passes is the library's business (--spp-per-pass)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=1024, help="HaltonSampler samplesPerPixel")
@@ -426,10 +428,9 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     sps = args.spp_per_step
 
-    # With N ranks a rank owns 1/N of the rows, so one step is an N times thinner pass; a rank therefore submits up to N
-    # consecutive steps to the library as ONE pass (same samples, same pixels, same results -- only the batching differs),
-    # which keeps its kernel launches as thick as the single-GPU ones.  Exactly `steps` x `spp_per_step` samples of every
-    # pixel are rendered inside the timed region either way.
+    # With N ranks a rank owns 1/N of the rows.  The library sizes its sub-passes in PATHS (~64 M), so a rank's sub-pass simply covers N
+    # times as many samples per pixel and its launches stay as thick as a single GPU's -- nothing to special-case here (cfg 5, one
+    # pass per call, still fuses N steps).  Exactly `steps` x `spp_per_step` samples of every pixel are rendered inside the timed region.
     fuse = args.fuse_steps if args.fuse_steps > 0 else world
     # How a call's samples are cut into sub-passes is the library's business (gnxr_render_params.samples_per_pass = 0: sub-passes of ~16 M
     # paths, four in flight; csrc/api.hip); --spp-per-pass / --passes-in-flight override it.  VolPath (cfg 5) renders a call as one pass.
@@ -447,9 +448,7 @@ def main():
 
     def run_steps(i0, nsteps):
         """steps i0 .. i0+nsteps-1 = samples [i0*sps, (i0+nsteps)*sps) of every pixel (mod the Halton range --spp), submitted as ONE library
-        call per contiguous sample range with samples_per_pass = fuse x sps: the library renders a call's passes two at a time -- the thin
-        late bounces of one pass share launches with the camera rays and first bounces of the next (csrc/api.hip, pipelined path loop).
-        Returns the summed stats."""
+        call per contiguous sample range (csrc/api.hip, the device-driven path loop).  Returns the summed stats."""
         agg = {}
         for s0, s1, m in calls_of(i0, nsteps):
             st = integ.RenderDevice(scene, out.data_ptr(), W, H, args.spp, stream=stream, spp_begin=s0, spp_end=s1, **pass_args(s0, s1), **shard)

@@ -12,12 +12,16 @@
 #include <thread>
 #include <vector>
 
-#include <hipcub/hipcub.hpp>
-
 #include "host_scene.h"
 #include "kernels.hip.h"
 #include "trace4_kernel.hip.h"
+#ifndef GX_WITH_TRACE4D
+#define GX_WITH_TRACE4D 0   // the two-rays-per-lane traversal kernel: a measured negative result (profiles/README.md, round 3), built only on request
+#endif
+#if GX_WITH_TRACE4D
 #include "trace4d_kernel.hip.h"
+#endif
+#include "hlbvh_build.hip.h"
 #include "kernel_instances.h"
 
 using namespace gnxr;
@@ -165,8 +169,6 @@ struct gnxr_scene {
     DevBuf<unsigned int> nee_vis;
     DevBuf<unsigned int> tile_counts;
     DevBuf<int> trace_spill;   // global part of k_trace's per-lane traversal stacks
-    DevBuf<unsigned> sort_keys_a, sort_keys_b, sort_items_a, sort_items_b;   // ray binning (GNXR_SORT_RAYS)
-    DevBuf<unsigned char> sort_tmp;
     DevBuf<float4> vol_n1, vol_f, vol_Li, vol_Tr, vol_Ld, vol_mres;   // VolPath light-estimate records (vol_kernel.hip.h)
     DevBuf<int4> vol_vs;
     DevBuf<unsigned char> vol_state;
@@ -280,43 +282,114 @@ struct gnxr_scene {
     }
 };
 
-// ---- HLBVH, the device stage (BVHAccel.cpp:377-397): Morton codes of the centroids and the stable radix sort by code.
-// Bounds3::Offset (Geometry.h), `centroidOffset * mortonScale`, EncodeMorton3 / LeftShift3 (BVHAccel.cpp:68-100).
+// ---- HLBVH on the device (hlbvh_build.hip.h): Morton codes, own LSD radix sort, the treelets' LBVHs and the SAH over their roots.  The host
+// gets the finished build tree back (scene_compile.cpp flattens it and derives the 4-wide layout as for the other split methods).
 namespace {
-__device__ __forceinline__ uint32_t left_shift3(uint32_t x) {
-    if (x == (1u << 10)) --x;
-    x = (x | (x << 16)) & 0x30000ffu;
-    x = (x | (x << 8)) & 0x300f00fu;
-    x = (x | (x << 4)) & 0x30c30c3u;
-    x = (x | (x << 2)) & 0x9249249u;
-    return x;
-}
-__global__ void __launch_bounds__(kBlock) k_morton_codes(const float *__restrict__ cen, int n, float lx, float ly, float lz, float hx, float hy, float hz,
-                                                         uint32_t *__restrict__ codes, uint32_t *__restrict__ prims) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        float ox = cen[3 * (size_t)i] - lx, oy = cen[3 * (size_t)i + 1] - ly, oz = cen[3 * (size_t)i + 2] - lz;
-        if (hx > lx) ox /= hx - lx;
-        if (hy > ly) oy /= hy - ly;
-        if (hz > lz) oz /= hz - lz;
-        const float sc = (float)(1 << 10);   // mortonScale
-        codes[i] = (left_shift3((uint32_t)(oz * sc)) << 2) | (left_shift3((uint32_t)(oy * sc)) << 1) | left_shift3((uint32_t)(ox * sc));
-        prims[i] = (uint32_t)i;
-    }
-}
-bool device_morton_sort(const float *centroids3, int n, const float lo[3], const float hi[3], uint32_t *codes_sorted, uint32_t *prims_sorted) {
+bool device_hlbvh_build(const float *prim_bounds6, const float *centroids3, int n, const float lo[3], const float hi[3], std::vector<HlbvhNode> *nodes_out, int *root_out,
+                        uint32_t *prims_sorted) {
+    using namespace hlbvh;
     if (ensure_device() != GNXR_OK) return false;
-    DevBuf<float> d_cen;
-    DevBuf<uint32_t> k_in, k_out, v_in, v_out;
-    DevBuf<unsigned char> tmp;
-    if (d_cen.upload(centroids3, 3 * (size_t)n) || k_in.alloc(n) || k_out.alloc(n) || v_in.alloc(n) || v_out.alloc(n)) return false;
-    hipLaunchKernelGGL(k_morton_codes, dim3(grid_for(n)), dim3(kBlock), 0, 0, (const float *)d_cen.p, n, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], k_in.p, v_in.p);
-    size_t bytes = 0;   // RadixSort sorts the 30 Morton bits, least significant digit first: a stable sort by the code (BVHAccel.cpp:102-141)
-    if (hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k_in.p, k_out.p, v_in.p, v_out.p, n, 0, 30) != hipSuccess) return false;
-    if (tmp.alloc(bytes)) return false;
-    if (hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes, k_in.p, k_out.p, v_in.p, v_out.p, n, 0, 30) != hipSuccess) return false;
-    if (hipMemcpy(codes_sorted, k_out.p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
-    if (hipMemcpy(prims_sorted, v_out.p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
-    return true;
+    if (n <= 0) { set_error("HLBVH: no primitives"); return false; }
+    DevBuf<float> d_cen, d_pb;
+    DevBuf<uint32_t> k_a, k_b, v_a, v_b, hist, sums, head, ukey, ustart, thead, total;
+    DevBuf<int> parent, roots, tmp, flags;
+    DevBuf<unsigned int> arrived;
+    DevBuf<HlbvhNode> d_nodes;
+    const int n_tiles = (n + kTile - 1) / kTile;
+    const auto fail = [&](const char *what) { set_error("HLBVH device build: %s", what); return false; };
+    if (d_cen.upload(centroids3, 3 * (size_t)n) || d_pb.upload(prim_bounds6, 6 * (size_t)n) || k_a.alloc(n) || k_b.alloc(n) || v_a.alloc(n) || v_b.alloc(n) ||
+        hist.alloc((size_t)64 * n_tiles) || sums.alloc((size_t)std::max(n_tiles, (64 * n_tiles + kTile - 1) / kTile) + 1) || head.alloc(n) || ukey.alloc(n) || ustart.alloc(n) ||
+        thead.alloc(n) || total.alloc(2) || flags.alloc(2))
+        return fail("out of device memory");
+    if (hipMemset(flags.p, 0, 2 * sizeof(int)) != hipSuccess) return fail("memset");
+    const bool verbose = getenv("GNXR_VERBOSE") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto stage = [&](const char *name) {
+        if (!verbose) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[gnxr] hlbvh %-10s %7.2f ms\n", name, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
+    stage("alloc");
+    const int g = grid_for(n);
+    hipLaunchKernelGGL(hlbvh::k_morton_codes, dim3(g), dim3(kB), 0, 0, (const float *)d_cen.p, n, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], k_a.p, v_a.p);
+    // exclusive scan helper (in place); total (optional) lands in *d_total
+    auto scan = [&](uint32_t *v, int m, uint32_t *d_total) {
+        const int tiles = (m + kTile - 1) / kTile;
+        hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kB), 0, 0, v, m, sums.p);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, 0, sums.p, tiles, d_total);
+        hipLaunchKernelGGL(k_scan_add, dim3(tiles), dim3(kB), 0, 0, v, m, (const uint32_t *)sums.p);
+    };
+    // RadixSort (BVHAccel.cpp:102-141): 30 bits, 6 per pass, least significant first, stable
+    uint32_t *kin = k_a.p, *kout = k_b.p, *vin = v_a.p, *vout = v_b.p;
+    for (int pass = 0; pass < 5; ++pass) {
+        hipLaunchKernelGGL(k_rs_hist, dim3(n_tiles), dim3(kB), 0, 0, (const uint32_t *)kin, n, 6 * pass, n_tiles, hist.p);
+        scan(hist.p, 64 * n_tiles, nullptr);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(n_tiles), dim3(kB), 0, 0, (const uint32_t *)kin, (const uint32_t *)vin, n, 6 * pass, n_tiles, (const uint32_t *)hist.p, kout, vout);
+        std::swap(kin, kout); std::swap(vin, vout);
+    }
+    const uint32_t *codes = kin, *prims = vin;   // sorted
+    stage("sort");
+    // leaves = runs of equal codes
+    hipLaunchKernelGGL(k_hl_flags, dim3(g), dim3(kB), 0, 0, codes, n, head.p);
+    scan(head.p, n, total.p);
+    hipLaunchKernelGGL(k_hl_runs, dim3(g), dim3(kB), 0, 0, codes, (const uint32_t *)head.p, n, ukey.p, ustart.p);
+    uint32_t U = 0;
+    if (hipMemcpy(&U, total.p, sizeof(U), hipMemcpyDeviceToHost) != hipSuccess || U == 0 || U > (uint32_t)n) return fail("run count");
+    // treelets = runs of equal top 12 bits
+    const int gu = grid_for(U);
+    hipLaunchKernelGGL(k_hl_tflags, dim3(gu), dim3(kB), 0, 0, (const uint32_t *)ukey.p, (int)U, thead.p);
+    scan(thead.p, (int)U, total.p + 1);
+    uint32_t T = 0;
+    if (hipMemcpy(&T, total.p + 1, sizeof(T), hipMemcpyDeviceToHost) != hipSuccess || T == 0 || T > 4096u) return fail("treelet count");
+    const size_t cap = (size_t)2 * U + T;
+    if (d_nodes.alloc(cap) || parent.alloc(cap) || arrived.alloc(cap) || roots.alloc(T) || tmp.alloc(T)) return fail("out of device memory");
+    if (hipMemset(d_nodes.p, 0, cap * sizeof(HlbvhNode)) != hipSuccess || hipMemset(parent.p, 0xff, cap * sizeof(int)) != hipSuccess ||
+        hipMemset(arrived.p, 0, cap * sizeof(unsigned int)) != hipSuccess)
+        return fail("memset");
+    hipLaunchKernelGGL(k_hl_leaves, dim3(gu), dim3(kB), 0, 0, (const uint32_t *)ustart.p, (int)U, n, prims, (const float *)d_pb.p, d_nodes.p, flags.p);
+    if (U > 1) {
+        hipLaunchKernelGGL(k_hl_internal, dim3(gu), dim3(kB), 0, 0, (const uint32_t *)ukey.p, (int)U, d_nodes.p, parent.p);
+        hipLaunchKernelGGL(k_hl_fit, dim3(gu), dim3(kB), 0, 0, (int)U, d_nodes.p, (const int *)parent.p, arrived.p);
+    }
+    hipLaunchKernelGGL(k_hl_roots, dim3(gu), dim3(kB), 0, 0, (const uint32_t *)ukey.p, (const uint32_t *)thead.p, (int)U, roots.p);
+    stage("treelets");
+    // buildUpperSAH level by level: the ranges of a level are split by one wave each
+    int h_flags[2] = {0, -1};
+    if (T == 1) {
+        if (hipMemcpy(flags.p + 1, roots.p, sizeof(int), hipMemcpyDeviceToDevice) != hipSuccess) return fail("copy");
+    } else {
+        DevBuf<UpRange> q_a, q_b;
+        DevBuf<int> counters;   // [0] ranges of the next level, [1] upper nodes allocated
+        if (q_a.alloc(T) || q_b.alloc(T) || counters.alloc(2) || hipMemset(counters.p, 0, 2 * sizeof(int)) != hipSuccess) return fail("out of device memory");
+        UpRange first{0, (int)T, -1};
+        if (hipMemcpy(q_a.p, &first, sizeof(first), hipMemcpyHostToDevice) != hipSuccess) return fail("upload");
+        UpRange *qin = q_a.p, *qout = q_b.p;
+        int n_in = 1;
+        for (int level = 0; n_in > 0; ++level) {
+            if (level > (int)T) return fail("upper SAH did not terminate");
+            const int blocks = std::max(1, std::min((n_in * 64 + kB - 1) / kB, g_num_cus * 8));
+            hipLaunchKernelGGL(k_hl_upper_level, dim3(blocks), dim3(kB), 0, 0, (const UpRange *)qin, n_in, qout, counters.p, roots.p, tmp.p, d_nodes.p, (int)(2 * U), counters.p + 1,
+                               flags.p + 1, flags.p);
+            if (hipMemcpy(&n_in, counters.p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail("level count");
+            if (hipMemset(counters.p, 0, sizeof(int)) != hipSuccess) return fail("memset");
+            std::swap(qin, qout);
+        }
+    }
+    stage("upper");
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return fail(hipGetErrorString(hipGetLastError()));
+    if (hipMemcpy(h_flags, flags.p, sizeof(h_flags), hipMemcpyDeviceToHost) != hipSuccess) return fail("download");
+    if (h_flags[0]) {
+        set_error("HLBVH: the reference's build does not terminate on this input (coincident treelet centroids) or a leaf exceeds 65535 primitives");
+        return false;
+    }
+    nodes_out->resize(cap);
+    if (hipMemcpy(nodes_out->data(), d_nodes.p, cap * sizeof(HlbvhNode), hipMemcpyDeviceToHost) != hipSuccess) return fail("download");
+    if (hipMemcpy(prims_sorted, prims, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail("download");
+    stage("download");
+    *root_out = h_flags[1];
+    return *root_out >= 0 && (size_t)*root_out < cap;
 }
 }  // namespace
 
@@ -520,7 +593,7 @@ int gnxr_scene_create(const gnxr_scene_desc *desc, gnxr_scene **out) {
     gnxr_scene *s = new (std::nothrow) gnxr_scene();
     if (!s) return GNXR_ERR_OOM;
     s->device = g_device;
-    if (!compile_scene(desc, &s->cs, device_morton_sort)) { delete s; return GNXR_ERR_INVALID; }
+    if (!compile_scene(desc, &s->cs, device_hlbvh_build)) { delete s; return GNXR_ERR_INVALID; }
     if ((rc = upload_scene(s)) != GNXR_OK) { delete s; return rc; }
     // gnxr_init_devices: the same tables on every other device of the list (the host-side compilation is shared)
     for (size_t i = 1; i < g_devices.size(); ++i) {
@@ -623,8 +696,10 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
     int k = p.samples_per_pass;
     const bool path_int = !whitted && !volpath;
     if (k <= 0) {
-        // auto.  PathIntegrator: sub-passes of ~16 M paths, several of them in flight (below) -- launches stay thick because they mix
-        // the bounces of different sub-passes, not because a sub-pass is large.  VolPath / Whitted / DirectLighting render one pass at a
+        // auto.  PathIntegrator: sub-passes of ~64 M paths, four of them in flight (below) -- launches stay thick because they mix the
+        // bounces of different sub-passes.  Measured at 1080p on cfg 3 (1024 spp per call, profiles/README.md round 3): 4 x 32 spp
+        // (59 GB of state) renders as fast as round 2's two 128-spp passes (118 GB); 4 x 16 spp (29.5 GB) costs 2 % -- every launch of
+        // the persistent traversal kernel pays a ramp and a drain of ~0.3 ms, and the number of launches grows as the resident state shrinks.  VolPath / Whitted / DirectLighting render one pass at a
         // time: big passes keep their thin late rounds from under-filling the GPU, so take up to a quarter of the free HBM for path state
         // (~230 B per path), at most 256 M paths; Whitted / DirectLighting keep max_depth frames and n_records NEE records per path
         long long target = 32ll << 20;
@@ -632,7 +707,7 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) target = std::max<long long>(target, std::min<long long>(256ll << 20, (long long)(free_b / 4 / 230)));
         if (volpath) target = std::min<long long>(target, 64ll << 20);   // + 8 float4 of VolPath state per path
         if (whitted) target = (4ll << 20) / std::max(1, n_records / 4);
-        if (path_int) target = 16ll << 20;
+        if (path_int) target = 64ll << 20;
         k = (int)std::max<long long>(1, std::min<long long>(nsamples, target / r.npix));
     }
     k = std::min(k, nsamples);
@@ -742,25 +817,9 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
         long long total = (long long)w.n_closest + 2ll * w.n_nee;
         if (total <= 0) return;
         w.order = nullptr;
-        static const int sort_rays = getenv("GNXR_SORT_RAYS") ? atoi(getenv("GNXR_SORT_RAYS")) : 0;   // experiment: bin the rays of a launch by kind / octant / origin cell
-        if (sort_rays > 0 && total >= (1 << 16)) {
-            // (an experiment switch: any failure -- buffers, the library sort -- leaves the launch UNSORTED, it never skips the trace)
-            bool sorted = !(s->sort_keys_a.alloc(3 * cap) || s->sort_keys_b.alloc(3 * cap) || s->sort_items_a.alloc(3 * cap) || s->sort_items_b.alloc(3 * cap));
-            if (sorted) {
-                const Box3 &wb = s->cs.world_bound;
-                const float3 lo = make_float3(wb.lo.x, wb.lo.y, wb.lo.z);
-                const float3 scale = make_float3(32.f / std::max(1e-20f, wb.hi.x - wb.lo.x), 32.f / std::max(1e-20f, wb.hi.y - wb.lo.y), 32.f / std::max(1e-20f, wb.hi.z - wb.lo.z));
-                if (timing) timer.begin(1, stream);
-                hipLaunchKernelGGL(k_trace_keys, dim3(grid_for(total)), dim3(kBlock), 0, stream, pa, w, lo, scale, s->sort_keys_a.p, s->sort_items_a.p);
-                size_t bytes = 0;
-                const int b0 = sort_rays >= 2 ? 0 : 15, b1 = kTraceKeyBits;   // 1: kind + octant only; 2: + origin cell
-                sorted = hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, s->sort_keys_a.p, s->sort_keys_b.p, s->sort_items_a.p, s->sort_items_b.p, (int)total, b0, b1, stream) == hipSuccess &&
-                         s->sort_tmp.alloc(bytes) == GNXR_OK &&
-                         hipcub::DeviceRadixSort::SortPairs(s->sort_tmp.p, bytes, s->sort_keys_a.p, s->sort_keys_b.p, s->sort_items_a.p, s->sort_items_b.p, (int)total, b0, b1, stream) == hipSuccess;
-                if (timing) timer.end(stream);
-            }
-            w.order = sorted ? s->sort_items_b.p : nullptr;
-        }
+        // (binning the rays of a launch by kind / octant / origin cell with a radix sort was measured in round 2 and lost -- 57.6 - 62.0 ms against
+        // 51.7 ms per pass without counting the sort: slot order is already coherent in origin and sorting breaks the coalescing of the state
+        // reads; the switch and its library sort are gone, `order` stays in TraceWork for callers that bring their own permutation)
         (void)hipMemsetAsync(&dctr->cursor, 0, sizeof(unsigned int), stream);
         // LDS traversal stack: one column per lane, depth from the BVH (binary walk: depth + 1; 4-wide walk: stack4_need)
         const bool wide = s->wide_ok && !counting;
@@ -785,6 +844,7 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
 #define GX_TRACE(C, W, S) hipLaunchKernelGGL((k_trace<C, W, S>), dim3(blocks), dim3(kBlock), lds, stream, sc, pa, w, &dctr->cursor, dctr, lds_entries, s->trace_spill.p, chunk)
 #define GX_TRACE4(C, S, P) hipLaunchKernelGGL((k_trace4<C, S, P>), dim3(blocks), dim3(kBlock), lds, stream, sc, pa, w, &dctr->cursor, dctr, lds_entries, s->trace_spill.p, chunk, n_top)
 #define GX_TRACE4_CS(C, S) do { if (spill_needed) GX_TRACE4(C, S, true); else GX_TRACE4(C, S, false); } while (0)
+#if GX_WITH_TRACE4D
         static const bool dual = getenv("GNXR_TRACE_DUAL") ? atoi(getenv("GNXR_TRACE_DUAL")) != 0 : false;   // two rays per lane (trace4d_kernel.hip.h)
         if (wide && dual && !count_wide) {
             const int dper_cu = GX_T4D_WAVES;   // blocks of 4 waves per CU = waves per SIMD
@@ -799,6 +859,7 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
             else { if (dspill_levels > 0) GX_TRACE4D(false, true); else GX_TRACE4D(false, false); }
 #undef GX_TRACE4D
         } else
+#endif
         if (wide) {   // the 4-wide walk (trace4_kernel.hip.h); count_wide: its counting variant
             if (spheres) { if (count_wide) GX_TRACE4_CS(true, true); else GX_TRACE4_CS(false, true); }
             else { if (count_wide) GX_TRACE4_CS(true, false); else GX_TRACE4_CS(false, false); }

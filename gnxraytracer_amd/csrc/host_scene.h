@@ -93,10 +93,13 @@ struct CompiledScene {
     std::vector<gnxr_light> desc_lights;
 };
 
-// HLBVH (GNXR_BVH_HLBVH): Morton codes of the primitive centroids inside [lo, hi] (BVHAccel.cpp:378-394) and the stable radix sort
-// of (code, primitive) pairs by code (:397, RadixSort :102-141) are the caller's (api.hip: on the device); n entries each.
-typedef bool (*MortonSortFn)(const float *centroids3, int n, const float lo[3], const float hi[3], uint32_t *codes_sorted, uint32_t *prims_sorted);
-bool compile_scene(const gnxr_scene_desc *d, CompiledScene *out, MortonSortFn morton_sort = nullptr);
+// HLBVH (GNXR_BVH_HLBVH, BVHAccel.cpp:369-626) is built by the caller's device stage (api.hip + hlbvh_build.hip.h): Morton codes, radix
+// sort, one LBVH per treelet and the SAH over the treelet roots.  It returns the build tree -- leaves index the sorted primitive array
+// (`first`, `n`), interior nodes carry their two children and the split axis -- its root, and the sorted primitive order.
+struct HlbvhNode { float b[6]; int32_t child[2]; int32_t axis, first, n; };   // bounds lo.xyz hi.xyz
+typedef bool (*HlbvhBuildFn)(const float *prim_bounds6, const float *centroids3, int n, const float lo[3], const float hi[3],
+                             std::vector<HlbvhNode> *nodes, int *root, uint32_t *prims_sorted);
+bool compile_scene(const gnxr_scene_desc *d, CompiledScene *out, HlbvhBuildFn hlbvh_build = nullptr);
 DCamera make_camera(const gnxr_camera &c, int W, int H, int medium);      // camera/Perspective.cpp:114-135, core/Camera.h:54-75
 DHalton make_halton(int W, int H);                                          // samplers/HaltonSampler.cpp:33-60
 // light-selection table: dense restatement of core/LightDistribution.cpp (uniform / power / spatial)

@@ -95,107 +95,34 @@ struct BvhBuilder {
         return me;
     }
 
-    // ---- HLBVHBuild, accelerator/BVHAccel.cpp:369-460 (maxPrimsInNode = 1).  `info` stays in primitive order here.
-    std::vector<uint32_t> codes, sorted_prims;
-    bool failed = false;
-    int interior(int axis, int c0, int c1, int me) {
-        nodes[me].child[0] = c0; nodes[me].child[1] = c1;
-        Box3 u = nodes[c0].b; u.grow(nodes[c1].b);
-        nodes[me].b = u; nodes[me].axis = axis; nodes[me].n = 0; nodes[me].first = 0;
-        return me;
-    }
-    // emitLBVH, BVHAccel.cpp:462-524: `first` / `count` index the sorted Morton array; leaves only when the bits run out, and their
-    // primitives keep the sorted order (the treelets are emitted one after the other, so orderedPrims == the sorted order)
-    int emit_lbvh(int first, int count, int bitIndex) {
-        if (bitIndex == -1) {
-            int me = (int)nodes.size();
-            nodes.push_back(BuildNode());
-            Box3 b;
-            for (int i = 0; i < count; ++i) b.grow(info[sorted_prims[first + i]].b);
-            nodes[me].b = b; nodes[me].first = first; nodes[me].n = count; nodes[me].child[0] = nodes[me].child[1] = -1; nodes[me].axis = 0;
-            if (count > 0xffff) failed = true;   // LinearBVHNode::nPrimitives is a uint16_t
-            return me;
-        }
-        const uint32_t mask = 1u << bitIndex;
-        if ((codes[first] & mask) == (codes[first + count - 1] & mask)) return emit_lbvh(first, count, bitIndex - 1);
-        int searchStart = 0, searchEnd = count - 1;
-        while (searchStart + 1 != searchEnd) {
-            int mid = (searchStart + searchEnd) / 2;
-            if ((codes[first + searchStart] & mask) == (codes[first + mid] & mask)) searchStart = mid;
-            else searchEnd = mid;
-        }
-        const int splitOffset = searchEnd;
-        int me = (int)nodes.size();
-        nodes.push_back(BuildNode());
-        int c0 = emit_lbvh(first, splitOffset, bitIndex - 1);
-        int c1 = emit_lbvh(first + splitOffset, count - splitOffset, bitIndex - 1);
-        return interior(bitIndex % 3, c0, c1, me);
-    }
-    // buildUpperSAH, BVHAccel.cpp:526-626
-    int upper_sah(std::vector<int> &roots, int start, int end) {
-        if (end - start == 1) return roots[start];
-        int me = (int)nodes.size();
-        nodes.push_back(BuildNode());
-        Box3 bounds, cb;
-        for (int i = start; i < end; ++i) bounds.grow(nodes[roots[i]].b);
-        for (int i = start; i < end; ++i) cb.grow((nodes[roots[i]].b.lo + nodes[roots[i]].b.hi) * 0.5f);
-        const int dim = cb.max_extent();
-        constexpr int NB = 12;
-        int count[NB] = {0};
-        Box3 bb[NB];
-        auto bucket = [&](int node) {
-            float centroid = (nodes[node].b.lo[dim] + nodes[node].b.hi[dim]) * 0.5f;
-            int b = NB * ((centroid - cb.lo[dim]) / (cb.hi[dim] - cb.lo[dim]));
-            if (b == NB) b = NB - 1;
-            return b;
-        };
-        if (!(cb.hi[dim] > cb.lo[dim])) { failed = true; return me; }   // CHECK_NE in the reference: the bucket index would be NaN
-        for (int i = start; i < end; ++i) {
-            int b = bucket(roots[i]);
-            if (b < 0 || b >= NB) { failed = true; return me; }
-            count[b]++;
-            bb[b].grow(nodes[roots[i]].b);
-        }
-        float cost[NB - 1];
-        for (int i = 0; i < NB - 1; ++i) {
-            Box3 b0, b1;
-            int c0 = 0, c1 = 0;
-            for (int j = 0; j <= i; ++j) { b0.grow(bb[j]); c0 += count[j]; }
-            for (int j = i + 1; j < NB; ++j) { b1.grow(bb[j]); c1 += count[j]; }
-            cost[i] = .125f + (c0 * b0.area() + c1 * b1.area()) / bounds.area();
-        }
-        float minCost = cost[0];
-        int split = 0;
-        for (int i = 1; i < NB - 1; ++i) if (cost[i] < minCost) { minCost = cost[i]; split = i; }
-        int *pmid = std::partition(&roots[start], &roots[end - 1] + 1, [&](int node) { return bucket(node) <= split; });
-        int mid = (int)(pmid - &roots[0]);
-        if (mid <= start || mid >= end) { failed = true; return me; }   // CHECK_GT / CHECK_LT: the reference would not terminate
-        int c0 = upper_sah(roots, start, mid);
-        int c1 = upper_sah(roots, mid, end);
-        return interior(dim, c0, c1, me);
-    }
-    // returns the root node or -1 (error set)
-    int build_hlbvh(MortonSortFn morton_sort) {
+    // ---- HLBVHBuild, accelerator/BVHAccel.cpp:369-626 (maxPrimsInNode = 1): built on the device (hlbvh_build.hip.h); `info` stays in
+    // primitive order here.  Where the reference's CHECKs would fire (coincident treelet centroids: its recursion would not terminate)
+    // or a leaf exceeds LinearBVHNode's 16-bit primitive count the device stage reports failure.
+    int build_hlbvh(HlbvhBuildFn device_build) {
         const int n = (int)info.size();
         Box3 cb;   // bounds of the centroids, BVHAccel.cpp:372-375
-        std::vector<float> cen(3 * (size_t)n);
-        for (int i = 0; i < n; ++i) { cb.grow(info[i].c); cen[3 * (size_t)i] = info[i].c.x; cen[3 * (size_t)i + 1] = info[i].c.y; cen[3 * (size_t)i + 2] = info[i].c.z; }
-        codes.resize(n); sorted_prims.resize(n);
-        if (!morton_sort || !morton_sort(cen.data(), n, &cb.lo.x, &cb.hi.x, codes.data(), sorted_prims.data())) {
-            set_error("HLBVH: the Morton sort stage (device) is not available");
+        std::vector<float> cen(3 * (size_t)n), pb(6 * (size_t)n);
+        for (int i = 0; i < n; ++i) {
+            cb.grow(info[i].c);
+            cen[3 * (size_t)i] = info[i].c.x; cen[3 * (size_t)i + 1] = info[i].c.y; cen[3 * (size_t)i + 2] = info[i].c.z;
+            const Box3 &b = info[i].b;
+            float *q = &pb[6 * (size_t)i];
+            q[0] = b.lo.x; q[1] = b.lo.y; q[2] = b.lo.z; q[3] = b.hi.x; q[4] = b.hi.y; q[5] = b.hi.z;
+        }
+        std::vector<HlbvhNode> hn;
+        std::vector<uint32_t> sorted_prims(n);
+        int root = -1;
+        if (!device_build || !device_build(pb.data(), cen.data(), n, &cb.lo.x, &cb.hi.x, &hn, &root, sorted_prims.data())) {
+            if (!device_build) set_error("HLBVH: the device build stage is not available");
             return -1;
         }
         ordered.assign(sorted_prims.begin(), sorted_prims.end());
-        std::vector<int> roots;   // one LBVH treelet per run of equal top 12 Morton bits, BVHAccel.cpp:402-421
-        for (int start = 0, end = 1; end <= n; ++end) {
-            const uint32_t mask = 0x3ffc0000u;
-            if (end == n || ((codes[start] & mask) != (codes[end] & mask))) {
-                roots.push_back(emit_lbvh(start, end - start, 29 - 12));
-                start = end;
-            }
+        nodes.resize(hn.size());
+        for (size_t i = 0; i < hn.size(); ++i) {
+            BuildNode &o = nodes[i];
+            o.b.lo = {hn[i].b[0], hn[i].b[1], hn[i].b[2]}; o.b.hi = {hn[i].b[3], hn[i].b[4], hn[i].b[5]};
+            o.child[0] = hn[i].child[0]; o.child[1] = hn[i].child[1]; o.axis = hn[i].axis; o.first = hn[i].first; o.n = hn[i].n;
         }
-        int root = upper_sah(roots, 0, (int)roots.size());
-        if (failed) { set_error("HLBVH: the reference's build does not terminate on this input (coincident treelet centroids) or a leaf exceeds 65535 primitives"); return -1; }
         return root;
     }
 };
@@ -901,7 +828,7 @@ static bool build_textures(const gnxr_scene_desc *d, CompiledScene *cs) {
 }
 
 // ------------------------------------------------------------------ compile
-bool compile_scene(const gnxr_scene_desc *d, CompiledScene *cs, MortonSortFn morton_sort) {
+bool compile_scene(const gnxr_scene_desc *d, CompiledScene *cs, HlbvhBuildFn hlbvh_build) {
     if (!d || d->abi_version != GNXR_ABI_VERSION) { set_error("scene description ABI version mismatch"); return false; }
     if (d->n_triangles <= 0 || d->n_vertices <= 0 || !d->vertices || !d->indices || !d->tri_material || !d->tri_light) {
         set_error("scene description has no geometry");
@@ -943,7 +870,7 @@ bool compile_scene(const gnxr_scene_desc *d, CompiledScene *cs, MortonSortFn mor
     bb.ordered.reserve(d->n_triangles);
     if (d->bvh_split_method < GNXR_BVH_SAH || d->bvh_split_method > GNXR_BVH_EQUAL_COUNTS) { set_error("unknown BVH split method %d", d->bvh_split_method); return false; }
     bb.method = d->bvh_split_method;
-    int root = d->bvh_split_method == GNXR_BVH_HLBVH ? bb.build_hlbvh(morton_sort) : bb.build(0, d->n_triangles);
+    int root = d->bvh_split_method == GNXR_BVH_HLBVH ? bb.build_hlbvh(hlbvh_build) : bb.build(0, d->n_triangles);
     if (root < 0) return false;
     cs->nodes.clear();
     cs->nodes.reserve(bb.nodes.size());

@@ -77,6 +77,8 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
     const unsigned total = (unsigned)w.n_closest + 2u * (unsigned)w.n_nee;
     chunk = trace_chunk(total, chunk);
     const ChunkPlan plan = chunk_plan(total, (unsigned)chunk);
+    const unsigned nWaves = gridDim.x * (kBlock / 64u), waveId = blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6);
+    bool firstFetch = true;   // wave-uniform
     const DTri *__restrict__ tris = sc.tris;
     const char *__restrict__ nb = reinterpret_cast<const char *>(sc.nodes4);
     typedef float f4v __attribute__((ext_vector_type(4)));
@@ -183,9 +185,14 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
         if (needMask) {
             if (rqCount == 0) {
                 if (poolCount == 0 && !exhausted) {
-                    unsigned v = 0;
-                    if (lane == 0) v = atomicAdd(cursor, 1u);   // the cursor counts chunks (chunk_plan / chunk_range, trace_kernel.hip.h)
-                    v = __shfl(v, 0);
+                    // the cursor counts chunks (chunk_plan / chunk_range, trace_kernel.hip.h); a wave's FIRST chunk is its own number -- no
+                    // atomic: 5120 waves asking at once at the start of a launch queue up behind one address for ~60 us
+                    unsigned v = waveId;
+                    if (!firstFetch) {
+                        if (lane == 0) v = nWaves + atomicAdd(cursor, 1u);
+                        v = __shfl(v, 0);
+                    }
+                    firstFetch = false;
                     if (!chunk_range(plan, v, total, &poolBase, &poolCount)) { exhausted = true; poolCount = 0; }
                 }
                 if (poolCount > 0) {

@@ -23,6 +23,17 @@ namespace gnxr {
 #ifndef GX_T4D_CACHE
 #define GX_T4D_CACHE 32
 #endif
+// phase policy (tuning knobs): leave the node phase when the lanes with a ray that looks for its first leaf are <= MUL / DIV of the live
+// lanes; run a second triangle trip right away when at least GX_T4D_B2 lanes still hold a staged leaf (0: never)
+#ifndef GX_T4D_LEAVE_MUL
+#define GX_T4D_LEAVE_MUL 1
+#endif
+#ifndef GX_T4D_LEAVE_DIV
+#define GX_T4D_LEAVE_DIV 2
+#endif
+#ifndef GX_T4D_B2
+#define GX_T4D_B2 0
+#endif
 constexpr int kTopCacheD = GX_T4D_CACHE;   // DNode4[0 .. kTopCacheD) are served from LDS
 
 struct Ray4 {            // the registers of one ray of a lane
@@ -49,6 +60,8 @@ __global__ void __launch_bounds__(kBlock, GX_T4D_WAVES) k_trace4d(DScene sc, Pat
     const unsigned total = (unsigned)w.n_closest + 2u * (unsigned)w.n_nee;
     chunk = trace_chunk(total, chunk);
     const ChunkPlan plan = chunk_plan(total, (unsigned)chunk);
+    const unsigned nWaves = gridDim.x * (kBlock / 64u), waveId = blockIdx.x * (kBlock / 64u) + (threadIdx.x >> 6);
+    bool firstFetch = true;   // wave-uniform
     const DTri *__restrict__ tris = sc.tris;
     const char *__restrict__ nb = reinterpret_cast<const char *>(sc.nodes4);
     typedef float f4v __attribute__((ext_vector_type(4)));
@@ -125,9 +138,14 @@ __global__ void __launch_bounds__(kBlock, GX_T4D_WAVES) k_trace4d(DScene sc, Pat
         if (need0 | need1) {
             if (rqCount == 0) {
                 if (poolCount == 0 && !exhausted) {
-                    unsigned v = 0;
-                    if (lane == 0) v = atomicAdd(cursor, 1u);   // the cursor counts chunks (chunk_plan / chunk_range, trace_kernel.hip.h)
-                    v = __shfl(v, 0);
+                    // the cursor counts chunks (chunk_plan / chunk_range, trace_kernel.hip.h); a wave's FIRST chunk is its own number -- no
+                    // atomic: 5120 waves asking at once at the start of a launch queue up behind one address for ~60 us
+                    unsigned v = waveId;
+                    if (!firstFetch) {
+                        if (lane == 0) v = nWaves + atomicAdd(cursor, 1u);
+                        v = __shfl(v, 0);
+                    }
+                    firstFetch = false;
                     if (!chunk_range(plan, v, total, &poolBase, &poolCount)) { exhausted = true; poolCount = 0; }
                 }
                 if (poolCount > 0) {
@@ -229,7 +247,7 @@ __global__ void __launch_bounds__(kBlock, GX_T4D_WAVES) k_trace4d(DScene sc, Pat
             const bool s0 = R0.path >= 0 && R0.cur >= 0 && (kSpeculate || R0.leaf == 0), s1 = R1.path >= 0 && R1.cur >= 0 && (kSpeculate || R1.leaf == 0);
             const bool h0 = s0 && R0.leaf == 0, h1 = s1 && R1.leaf == 0;
             const int nHungry = __popcll(__ballot(h0 || h1));
-            if (nHungry * kTraceLeaveDiv <= nLive * kTraceLeaveMul && (nHungry == 0 || nHungry < nLive)) break;
+            if (nHungry * GX_T4D_LEAVE_DIV <= nLive * GX_T4D_LEAVE_MUL && (nHungry == 0 || nHungry < nLive)) break;
             // a ray that looks for its first leaf goes before one that walks on speculatively
             const bool one = h0 ? false : (h1 ? true : !s0);
             if (s0 || s1) {
@@ -306,7 +324,8 @@ __global__ void __launch_bounds__(kBlock, GX_T4D_WAVES) k_trace4d(DScene sc, Pat
             }
         }
         // ---------------- phase B: one staged leaf per lane, of whichever ray holds one ----------------
-        {
+        for (int trip = 0; trip < (GX_T4D_B2 > 0 ? 2 : 1); ++trip) {
+            if (trip == 1 && __popcll(__ballot((R0.path >= 0 && R0.leaf != 0) || (R1.path >= 0 && R1.leaf != 0))) < GX_T4D_B2) break;
             const bool l0 = R0.path >= 0 && R0.leaf != 0, l1 = R1.path >= 0 && R1.leaf != 0;
             if (l0 || l1) {
                 const bool one = !l0;

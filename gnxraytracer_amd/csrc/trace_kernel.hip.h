@@ -27,7 +27,7 @@ namespace gnxr {
 struct TraceWork {
     const int *q_closest; int n_closest;   // path slots (nullptr == identity)
     const int *q_nee; int n_nee;           // paths with an NEE record: two work items each (shadow ray, MIS ray)
-    const unsigned *order;                 // nullptr, or a permutation of the work items: position in the launch -> work item (ray binning, k_trace_keys)
+    const unsigned *order;                 // nullptr, or a permutation of the work items: position in the launch -> work item (a caller-supplied ordering; unused by the library itself)
     unsigned char *vis;                    // nullptr: visibility results go to sh_o[path].w / mis_o[path].w (float 1 / 0).  Otherwise 4 bytes per path:
                                            // [0] shadow ray unoccluded, [1] MIS ray found what the light sample expects (written here), [2] the record's
                                            // flags (written by k_shade) -- k_nee_combine then reads one word instead of three float4
@@ -416,47 +416,6 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
         atomicAdd(&ctr->nodes, (unsigned long long)cntNodes);
         atomicAdd(&ctr->tris, (unsigned long long)cntTris);
         atomicAdd(&ctr->retests, (unsigned long long)cntRetests);
-    }
-}
-
-// Ray binning: one key per work item of a k_trace launch -- ray kind, direction octant (the 4-wide nodes tabulate their child order
-// per octant) and the Morton code of the origin's cell in a 32^3 grid over the scene bounds -- so that, after a sort by key, a wave's
-// chunk holds rays that start close to each other and head the same way.  Items without a ray (an NEE record that spawned no shadow /
-// MIS ray) get the largest key and gather at the end.  Results do not depend on the order (every item writes its own slot).
-GX_DEV unsigned morton_spread5(unsigned x) {   // 5 bits -> every third bit
-    x &= 31u;
-    x = (x | (x << 8)) & 0x100fu;
-    x = (x | (x << 4)) & 0x10c3u;
-    x = (x | (x << 2)) & 0x1249u;
-    return x;
-}
-constexpr int kTraceKeyBits = 20;
-static __global__ void __launch_bounds__(kBlock) k_trace_keys(PathArrays pa, TraceWork w, float3 lo, float3 scale, unsigned *__restrict__ keys, unsigned *__restrict__ items) {
-    const unsigned total = (unsigned)w.n_closest + 2u * (unsigned)w.n_nee;
-    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        float4 o4, d4;
-        unsigned kind = 0;
-        bool valid = true;
-        if (i < (unsigned)w.n_closest) {
-            const int path = w.q_closest ? w.q_closest[i] : (int)i;
-            o4 = pa.ray_o[path]; d4 = pa.ray_d[path];
-        } else {
-            const unsigned e = i - (unsigned)w.n_closest;
-            const bool isShadow = e < (unsigned)w.n_nee;
-            const int path = w.q_nee[isShadow ? e : e - (unsigned)w.n_nee];
-            const int nflags = __float_as_int(pa.sh_d[path].w);
-            kind = isShadow ? 1u : 2u;
-            valid = (nflags & (isShadow ? 1 : 2)) != 0;
-            if (valid) { o4 = isShadow ? pa.sh_o[path] : pa.mis_o[path]; d4 = isShadow ? pa.sh_d[path] : pa.mis_d[path]; }
-        }
-        unsigned key = (1u << kTraceKeyBits) - 1u;
-        if (valid) {
-            const int cx = min(31, max(0, (int)((o4.x - lo.x) * scale.x))), cy = min(31, max(0, (int)((o4.y - lo.y) * scale.y))), cz = min(31, max(0, (int)((o4.z - lo.z) * scale.z)));
-            const unsigned oct = (d4.x < 0 ? 1u : 0u) | (d4.y < 0 ? 2u : 0u) | (d4.z < 0 ? 4u : 0u);
-            key = (kind << 18) | (oct << 15) | morton_spread5((unsigned)cx) | (morton_spread5((unsigned)cy) << 1) | (morton_spread5((unsigned)cz) << 2);
-        }
-        keys[i] = key;
-        items[i] = i;
     }
 }
 
