@@ -172,6 +172,11 @@ struct gnxr_scene {
     DevBuf<float4> vol_n1, vol_f, vol_Li, vol_Tr, vol_Ld, vol_mres;   // VolPath light-estimate records (vol_kernel.hip.h)
     DevBuf<int4> vol_vs;
     DevBuf<unsigned char> vol_state;
+    // VolPath packing (k_vol_pack): the second set of the state arrays, the original slot of every path, the renumbering map and the results
+    DevBuf<float4> vol_alt[kVolPackF4], vol_Lout;
+    DevBuf<uint2> vol_alt_meta;
+    DevBuf<unsigned char> vol_alt_state;
+    DevBuf<int> vol_orig, vol_alt_orig, vol_newslot;
     DevBuf<float4> wh_o, wh_d, wh_L, wh_w;   // Whitted recursion frames (whitted_kernel.hip.h)
     DevBuf<float4> wh_rxo, wh_rxd, wh_ryo, wh_ryd;   // their ray differentials (scenes with image textures)
     DevBuf<float> wh_pdf;
@@ -758,6 +763,8 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
     if (volpath) {
 #define AL(f) if ((rc = s->f.alloc(cap)) != GNXR_OK) return rc;
         AL(vol_n1) AL(vol_f) AL(vol_Li) AL(vol_Tr) AL(vol_Ld) AL(vol_mres) AL(vol_vs) AL(vol_state)
+        AL(vol_Lout) AL(vol_alt_meta) AL(vol_alt_state) AL(vol_orig) AL(vol_alt_orig) AL(vol_newslot)
+        for (int i = 0; i < kVolPackF4; ++i) AL(vol_alt[i])
 #undef AL
     }
     {   // global part of k_trace's traversal stacks (the deepest walk either BVH layout can need), sized for a full grid
@@ -773,6 +780,7 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
     VolArrays va;
     va.vs = s->vol_vs.p; va.sv_o = s->sh_o.p; va.sv_d = s->sh_d.p; va.p1 = s->sh_X.p; va.p1e = s->nbeta.p; va.n1 = s->vol_n1.p; va.f = s->vol_f.p;
     va.Li = s->vol_Li.p; va.Tr = s->vol_Tr.p; va.Ld = s->vol_Ld.p; va.mis_o = s->mis_o.p; va.mis_d = s->mis_d.p; va.mis_Y = s->mis_Y.p; va.mres = s->vol_mres.p; va.state = s->vol_state.p;
+    va.orig = s->vol_orig.p; va.Lout = s->vol_Lout.p;
     DMediaTables mt = s->media_tables();
     WhittedArrays wa;
     wa.ws = s->vol_vs.p; wa.fr_o = s->wh_o.p; wa.fr_d = s->wh_d.p; wa.fr_L = s->wh_L.p; wa.fr_w = s->wh_w.p; wa.fr_pdf = s->wh_pdf.p;
@@ -1144,6 +1152,30 @@ else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, slds, stream,
             ++launches;
             int n_media = r.cam.medium >= 0 ? n : 0;      // paths whose ray in flight travels inside a medium
             const int *q_media = nullptr;
+            // packing (k_vol_pack, vol_kernel.hip.h): the two sets of the per-path arrays that carry state across rounds
+            static const bool vol_pack = getenv("GNXR_VOL_PACK") ? atoi(getenv("GNXR_VOL_PACK")) != 0 : true;   // experiment switch
+            auto pack_set = [&](bool alt) {
+                VolPackSet ps;
+                if (!alt) {
+                    float4 *a[kVolPackF4] = {s->ray_o.p, s->ray_d.p, s->beta.p, s->L.p, reinterpret_cast<float4 *>(s->vol_vs.p), s->sh_o.p, s->sh_d.p, s->sh_X.p, s->nbeta.p, s->vol_n1.p, s->vol_f.p,
+                                             s->vol_Li.p, s->vol_Tr.p, s->vol_Ld.p, s->mis_o.p, s->mis_d.p, s->mis_Y.p};
+                    for (int i = 0; i < kVolPackF4; ++i) ps.f4[i] = a[i];
+                    ps.meta = s->meta.p; ps.state = s->vol_state.p; ps.orig = s->vol_orig.p;
+                } else {
+                    for (int i = 0; i < kVolPackF4; ++i) ps.f4[i] = s->vol_alt[i].p;
+                    ps.meta = s->vol_alt_meta.p; ps.state = s->vol_alt_state.p; ps.orig = s->vol_alt_orig.p;
+                }
+                return ps;
+            };
+            auto bind_set = [&](const VolPackSet &ps) {   // point the kernels' views at a set
+                pa.ray_o = ps.f4[0]; pa.ray_d = ps.f4[1]; pa.beta = ps.f4[2]; pa.L = ps.f4[3]; va.vs = reinterpret_cast<int4 *>(ps.f4[4]); va.sv_o = ps.f4[5]; va.sv_d = ps.f4[6];
+                va.p1 = ps.f4[7]; va.p1e = ps.f4[8]; va.n1 = ps.f4[9]; va.f = ps.f4[10]; va.Li = ps.f4[11]; va.Tr = ps.f4[12]; va.Ld = ps.f4[13];
+                va.mis_o = ps.f4[14]; va.mis_d = ps.f4[15]; va.mis_Y = ps.f4[16];
+                pa.meta = ps.meta; va.state = ps.state; va.orig = ps.orig;
+            };
+            bool in_alt = false;
+            long long span = n_paths;     // the live paths lie in slots [0, span)
+            bind_set(pack_set(false));
             while (n > 0) {
                 launch_trace(TraceWork{q_in, n, nullptr, 0}, 0, 0);
                 if (n_media > 0) {
@@ -1160,7 +1192,7 @@ else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, slds, stream,
                 }
                 if (timing) timer.begin(2, stream);
 // bin the live paths by state (main ray / shadow-ray segment / scattering-ray segment), one k_vol_step instantiation per bin
-                compact(COMPACT_CLASS, q_in, n, s->vol_state.p, 3, 3, &dctr->q_class[0], s->queue_c0.p, s->queue_c1.p, s->queue_c2.p);
+                compact(COMPACT_CLASS, q_in, n, va.state, 3, 3, &dctr->q_class[0], s->queue_c0.p, s->queue_c1.p, s->queue_c2.p);
                 {
                     int *qc[3] = {s->queue_c0.p, s->queue_c1.p, s->queue_c2.p};
                     // the scene's material and light tables go to LDS when they are small (as for k_shade)
@@ -1189,10 +1221,26 @@ else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, slds, stream,
                 q_media = s->queue_nee.p;
                 q_in = q_cur;
                 std::swap(q_cur, q_other);
+                if (vol_pack && n >= (1 << 16) && 2ll * n <= span) {
+                    // the survivors fill at most half of the span they are spread over: move them to the front of the other set
+                    const VolPackSet from = pack_set(in_alt), to = pack_set(!in_alt);
+                    hipLaunchKernelGGL(k_vol_pack, dim3(grid_for(n)), dim3(kBlock), 0, stream, q_in, n, from, to, s->vol_newslot.p);
+                    if (n_media > 0) hipLaunchKernelGGL(k_vol_remap, dim3(grid_for(n_media)), dim3(kBlock), 0, stream, s->queue_nee.p, n_media, (const int *)s->vol_newslot.p);
+                    launches += 2;
+                    in_alt = !in_alt;
+                    bind_set(to);
+                    q_in = nullptr;   // the queue is the identity again
+                    span = n;
+                }
                 if (++guard > (1 << 20)) { set_error("path loop did not terminate"); return GNXR_ERR_INVALID; }
             }
+            if (in_alt) bind_set(pack_set(false));   // the next pass's k_raygen writes the primary set again
         }
-        hipLaunchKernelGGL(k_resolve, dim3(grid_for(r.npix)), dim3(kBlock), 0, stream, pa, s->accum.p, r.npix, kk);
+        {
+            PathArrays pr = pa;
+            if (volpath) pr.L = s->vol_Lout.p;   // VolPath: results sit at the paths' original slots (packing moves the working state)
+            hipLaunchKernelGGL(k_resolve, dim3(grid_for(r.npix)), dim3(kBlock), 0, stream, pr, s->accum.p, r.npix, kk);
+        }
         ++launches;
         ++passes;
         if (timing) { HIP_TRY(hipStreamSynchronize(stream)); timer.collect(); }

@@ -50,7 +50,7 @@ GX_DEV int trace4_lds_dwords_per_thread(bool sph) { return kRayRecDwords + (sph 
 
 // COUNT: count node steps / triangle tests / leaf re-tests.  SPH: the scene has spheres.  SPILL: the traversal stack may outgrow its LDS part.
 // Tuning switches (tools/build_variant.sh + tests/dev_ab.py; the A/B table is in profiles/README.md).  Defaults = the fastest measured:
-// 5 waves per SIMD (96 VGPRs), scalar slab arithmetic (the packed form needs 124 VGPRs -> 4 waves), 64-ray set-up batches, 64 cached nodes.
+// 5 waves per SIMD (96 VGPRs), scalar slab arithmetic (the packed-fp32 forms measured in round 2 -- 124 VGPRs, 4 waves -- are gone), 64-ray set-up batches, 64 cached nodes.
 #ifndef GX_T4_WAVES
 #define GX_T4_WAVES 5
 #endif
@@ -58,9 +58,6 @@ GX_DEV int trace4_lds_dwords_per_thread(bool sph) { return kRayRecDwords + (sph 
 #define GX_T4_BOUNDS __launch_bounds__(kBlock, GX_T4_WAVES)
 #else
 #define GX_T4_BOUNDS __launch_bounds__(kBlock)
-#endif
-#ifndef GX_T4_PACKED
-#define GX_T4_PACKED 0
 #endif
 template <bool COUNT, bool SPH, bool SPILL>
 __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, unsigned int *cursor, Counters *ctr, int lds_entries, int *spill, int chunk, int n_top) {
@@ -356,32 +353,6 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
                 if (!(pk & 32)) {
                     // finite 1 / d: no product is NaN, and the pairwise tests of Geometry.h:1389-1403 hold exactly when the merged
                     // interval [max of the three entries, min of the three (k-scaled) exits] is non-empty and overlaps (0, tMax)
-#if GX_T4_PACKED
-                    // (plane - o) * (1 / d) for the four children at once: packed fp32 (v_pk_add_f32 / v_pk_mul_f32), same operations per value
-                    const f4v tnx = (nX - ro.x) * inv.x, tny = (nY - ro.y) * inv.y, tnz = (nZ - ro.z) * inv.z;
-                    const f4v tfx = ((fX - ro.x) * inv.x) * k, tfy = ((fY - ro.y) * inv.y) * k, tfz = ((fZ - ro.z) * inv.z) * k;
-#define GX_SLAB3(C, BIT)                                                                  \
-    {                                                                                     \
-        const float e = fmaxf(fmaxf(tnx.C, tny.C), tnz.C);                                \
-        const float x = fminf(fminf(tfx.C, tfy.C), tfz.C);                                \
-        hitMask |= (e <= x && e < tMax && x > 0.f) ? (BIT) : 0u;                          \
-    }
-#elif GX_T4_PACKED == 2
-                    // two children at a time (packed fp32 on .xy, then on .zw): half the live temporaries of the four-at-once form
-                    typedef float f2v __attribute__((ext_vector_type(2)));
-#define GX_SLAB2(H, C0, C1, B0, B1)                                                                            \
-    {                                                                                                          \
-        const f2v tnx = (nX.H - ro.x) * inv.x, tny = (nY.H - ro.y) * inv.y, tnz = (nZ.H - ro.z) * inv.z;        \
-        const f2v tfx = ((fX.H - ro.x) * inv.x) * k, tfy = ((fY.H - ro.y) * inv.y) * k, tfz = ((fZ.H - ro.z) * inv.z) * k; \
-        const float e0 = fmaxf(fmaxf(tnx.x, tny.x), tnz.x), x0 = fminf(fminf(tfx.x, tfy.x), tfz.x);             \
-        const float e1 = fmaxf(fmaxf(tnx.y, tny.y), tnz.y), x1 = fminf(fminf(tfx.y, tfy.y), tfz.y);             \
-        hitMask |= (e0 <= x0 && e0 < tMax && x0 > 0.f) ? (B0) : 0u;                                             \
-        hitMask |= (e1 <= x1 && e1 < tMax && x1 > 0.f) ? (B1) : 0u;                                             \
-    }
-                    GX_SLAB2(xy, x, y, 1u, 2u) GX_SLAB2(zw, z, w, 4u, 8u)
-#undef GX_SLAB2
-#define GX_SLAB3(C, BIT)
-#else
 // (rounding is monotone and k > 0, so the smallest of the three k-scaled exits is the k-scaled smallest exit: one multiply instead of three)
 #define GX_SLAB3(C, BIT)                                                                                       \
     {                                                                                                          \
@@ -389,7 +360,6 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
         const float x = fminf(fminf((fX.C - ro.x) * inv.x, (fY.C - ro.y) * inv.y), (fZ.C - ro.z) * inv.z) * k;  \
         hitMask |= (e <= x && e < tMax && x > 0.f) ? (BIT) : 0u;                                                \
     }
-#endif
                     GX_SLAB3(x, 1u) GX_SLAB3(y, 2u) GX_SLAB3(z, 4u) GX_SLAB3(w, 8u)
 #undef GX_SLAB3
                 } else {

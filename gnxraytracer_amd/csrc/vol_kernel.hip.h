@@ -46,6 +46,8 @@ struct VolArrays {
     float4 *mis_Y;   // f * Li2
     unsigned char *state;   // copy of vs.x for the live paths: key of the per-state binning before k_vol_step
     float4 *mres;    // k_vol_media result for the ray in flight: Medium::Sample weight / Medium::Tr (rgb), w: t of the sampled interaction or -1
+    int *orig;       // the slot (sample j * npix + pixel) a path started in: packing (k_vol_pack) moves the live paths to the front of the state arrays
+    float4 *Lout;    // final radiance of a path, written once when it ends, at its ORIGINAL slot: what k_resolve sums in sample order
 };
 
 static __global__ void __launch_bounds__(kBlock) k_vol_init(PathArrays pa, VolArrays va, int n_paths) {
@@ -53,6 +55,7 @@ static __global__ void __launch_bounds__(kBlock) k_vol_init(PathArrays pa, VolAr
         uint2 m = pa.meta[slot];
         va.vs[slot] = make_int4(VS_MAIN, (int)m.y, -1, 1);
         va.state[slot] = (unsigned char)VS_MAIN;
+        va.orig[slot] = slot;
         pa.meta[slot] = make_uint2(m.x, 0u);   // y: bounces << 16 | specularBounce << 31
     }
 }
@@ -311,6 +314,7 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_vol_step(DScene sc, DM
         }
     }
     __syncthreads();
+    // (fetching the queue entry two iterations and the hit one iteration ahead, as k_shade does, was measured here and lost: +7 % step time)
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int path = queue[i];
         int4 vs = va.vs[path];
@@ -472,7 +476,7 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_vol_step(DScene sc, DM
                 } else vertexNew = true;
             }
             if (!alive) {
-                pa.L[path] = make_float4(L.r, L.g, L.b, 0.f);
+                va.Lout[va.orig[path]] = make_float4(L.r, L.g, L.b, 0.f);
                 pa.pflags[path] = 0;
                 continue;
             }
@@ -516,7 +520,7 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_vol_step(DScene sc, DM
                     rdf.has = false;
                     if (vs.w & 1) {
                         int px, py;
-                        local_pixel(r, path % r.npix, &px, &py);
+                        local_pixel(r, va.orig[path] % r.npix, &px, &py);
                         rdf = camera_ray_diff(r.cam, sc.st, px, py, pa.meta[path].x, r.spp);
                     }
                     textured_material(tex_tables(sc.materials), *mat, tu, tv, compute_differentials(rdf, sp.p, sp.n, dpdu, dpdv), &tm);
@@ -683,9 +687,37 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_vol_step(DScene sc, DM
                 }
             }
         }
-        pa.L[path] = make_float4(L.r, L.g, L.b, 0.f);
+        if (survive) pa.L[path] = make_float4(L.r, L.g, L.b, 0.f);
+        else va.Lout[va.orig[path]] = make_float4(L.r, L.g, L.b, 0.f);
         pa.pflags[path] = (unsigned char)(survive ? (1 | (nextMedium >= 0 ? 2 : 0)) : 0);
     }
+}
+
+// ---- packing.  A VolPath pass runs ~60 rounds over a population that thins out all the time (cfg 5: on average 15 % of the slots hold a
+// live path), and every per-path array is then read one 16-byte element per 64-byte line: 470 - 740 B of HBM traffic per path and round
+// against ~210 B of state (profiles/traffic_latest_cfg5.json, round 2).  When the survivors have dropped to half the span they are spread
+// over, their state is copied to the front of a second set of arrays (queue order == slot order is kept, so everything stays sorted and
+// coalesced), the queues are renumbered, and the rounds go on densely.  A path's results go to its ORIGINAL slot (`orig`, `Lout`).
+constexpr int kVolPackF4 = 17;   // float4-sized per-path arrays that carry state from round to round
+struct VolPackSet {
+    float4 *f4[kVolPackF4];      // ray_o ray_d beta L | vs sv_o sv_d p1 p1e n1 f Li Tr Ld mis_o mis_d mis_Y
+    uint2 *meta;
+    unsigned char *state;
+    int *orig;
+};
+static __global__ void __launch_bounds__(kBlock) k_vol_pack(const int *__restrict__ queue, int n, VolPackSet src, VolPackSet dst, int *__restrict__ newslot) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int p = queue ? queue[i] : i;
+#pragma unroll
+        for (int k = 0; k < kVolPackF4; ++k) dst.f4[k][i] = src.f4[k][p];
+        dst.meta[i] = src.meta[p];
+        dst.state[i] = src.state[p];
+        dst.orig[i] = src.orig[p];
+        newslot[p] = i;
+    }
+}
+static __global__ void __launch_bounds__(kBlock) k_vol_remap(int *__restrict__ queue, int n, const int *__restrict__ newslot) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) queue[i] = newslot[queue[i]];
 }
 
 }  // namespace gnxr

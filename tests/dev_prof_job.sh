@@ -21,7 +21,7 @@ fi
 if has stats; then
 for W in cfg3 cfg4 cfg5; do
   S=4; if [ $W = cfg5 ]; then S=1; fi
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$W -- python3 bench.py --workload $W --steps $S --warmup 1 --no-cpu-baseline > $O/stats_$W.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$W -- python3 bench.py --workload $W --steps $S --warmup 1 --no-cpu-baseline --no-also > $O/stats_$W.log 2>&1
   echo "stats $W done"
 done
 find $O -name "*kernel_stats.csv" | head
