@@ -240,6 +240,31 @@ def git_head():
             return None
 
 
+def kernel_source_id():
+    """Identifies the KERNELS a counter file was measured on: a hash over csrc/ and the compile flags (a commit that only touches documents
+    or tests leaves it alone, so committed counter files do not go stale with every commit)."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "gnxraytracer_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip", ".cpp")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    try:
+        import __graft_entry__ as ge
+        h.update(" ".join(ge.HIPCC_FLAGS).encode())
+    except Exception:
+        pass
+    return h.hexdigest()[:12]
+
+
+def counters_stale(tj):
+    """True when a profiles/ counter file was measured on other kernels than the ones in this tree (no source id in the file: compare commits)."""
+    on = tj.get("_measured_on", {})
+    if on.get("source_id"):
+        return on["source_id"] != kernel_source_id()
+    return on.get("commit") != git_head()
+
+
 def load_profile_json(name, args, sps, world):
     """profiles/<name>: counter figures per launch, valid only for the launch size they were measured on (`_measured_on`)."""
     path = os.path.join(ROOT, "profiles", name.replace(".json", f"_{args.workload}.json"))   # one file per workload
@@ -291,7 +316,7 @@ def roofline(kernel, secs, launches, units, unit_name, bytes_per_unit, byte_term
                     # (documented for wide streaming reads; node gathers are not that, so the x2 figure is an upper bound)
                     "bytes_per_launch_raw": raw, "bytes_per_launch_fetch_x2": traffic,
                     "achieved_raw": (raw / avg_s / 1e9) if raw else None, "frac_raw": (raw / avg_s / 1e9 / HBM_PEAK_GBS) if raw else None,
-                    "stale_counters": tj.get("_measured_on", {}).get("commit") != git_head(),
+                    "stale_counters": counters_stale(tj),
                     "traffic_source": {"file": f"profiles/traffic_latest_{args.workload}.json", "commit": tj.get("_measured_on", {}).get("commit"),
                                        "raw_bytes_per_step": tj[kernel].get("hbm_bytes_per_step_uncorrected"), "steps_profiled": tj.get("_measured_on", {}).get("steps_profiled"),
                                        "correction": "FETCH_SIZE x 2 (gfx950, MI355X_MICROARCH.md) + WRITE_SIZE"}})
@@ -307,7 +332,7 @@ def roofline(kernel, secs, launches, units, unit_name, bytes_per_unit, byte_term
                 "peak_spec": VALU_SPEC_GWIPS, "frac_of_spec": ach / VALU_SPEC_GWIPS,
                 "probe_clock_GHz": peaks["valu"] * 2.0 / VALU_SPEC_SIMDS,   # a saturating v_fma_f32 loop issues one wave64 instruction per SIMD every 2 cycles
                 "useful_lane_frac": (ach / VALU_SPEC_GWIPS * lane) if lane else None,   # issue slots x lanes that do work, of the spec peak
-                "stale_counters": pj.get("_measured_on", {}).get("commit") != git_head(),
+                "stale_counters": counters_stale(pj),
                 "wave_insts_per_" + one: vpl / upl, "lane_util": k.get("lane_util"), "valu_busy_pmc": k.get("valu_busy"),
                 "wait_frac": k.get("wait_frac"), "waves_per_simd": k.get("waves_per_simd"),
                 "source": {"file": f"profiles/pmc_latest_{args.workload}.json", "commit": pj.get("_measured_on", {}).get("commit")},

@@ -23,7 +23,13 @@ if commit is None:
     except Exception:
         try: commit = open(os.path.join(ROOT, ".build_commit")).read().strip()
         except Exception: commit = None
-on = {"steps_profiled": a.steps_profiled, "workload": a.workload, "spp_per_step": a.spp_per_step, "width": a.width, "height": a.height, "commit": commit,
+sys.path.insert(0, ROOT)
+try:
+    import bench
+    source_id = bench.kernel_source_id()
+except Exception:
+    source_id = None
+on = {"source_id": source_id, "steps_profiled": a.steps_profiled, "workload": a.workload, "spp_per_step": a.spp_per_step, "width": a.width, "height": a.height, "commit": commit,
       "command": f"rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --workload {a.workload} --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing"}
 
 def short(name):

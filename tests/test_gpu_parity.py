@@ -531,9 +531,9 @@ def test_randomised_sweep_against_oracle(gpu):
 
 @pytest.mark.parametrize("name", ["cornell", "mesh2k"])
 def test_pipelined_passes_equal_one_pass(gpu, name):
-    """The pipelined path loop (csrc/api.hip: two passes in flight, the late bounces of one sharing launches with the first bounces of the
-    next, k_queue_merge) against the same samples rendered as ONE pass and against the oracle: images and ray counts bit for bit, for
-    pass sizes that divide the sample range, that do not, and for a sample sub-range."""
+    """The device-driven path loop (csrc/api.hip: up to eight sub-passes alive at once in regions of the state arrays, queue counts on the
+    device, k_queue_merge / k_loop_tail) against the same samples rendered as ONE pass and against the oracle: images and ray counts bit for
+    bit, for sub-pass sizes that divide the sample range, that do not, for every number of sub-passes in flight, and for a sample sub-range."""
     b = scenes.cornell() if name == "cornell" else _scene("mesh2k")
     scene = gpu.Scene(b)
     integ = gpu.PathIntegrator(8, 1.0, "spatial")
@@ -546,6 +546,11 @@ def test_pipelined_passes_equal_one_pass(gpu, name):
         assert st["passes"] == (spp + k - 1) // k
         assert (st["rays_closest"], st["rays_any"]) == (st1["rays_closest"], st1["rays_any"]), k
         assert biteq(img, one), k
+    for inflight in (1, 2, 3, 5, 8):
+        img, st = integ.Render(scene, W, H, spp, samples_per_pass=1, passes_in_flight=inflight)
+        assert st["passes_in_flight"] == min(inflight, spp) and st["passes"] == spp and st["state_bytes"] > 0
+        assert (st["rays_closest"], st["rays_any"]) == (st1["rays_closest"], st1["rays_any"]), inflight
+        assert biteq(img, one), inflight
     a, sa = integ.Render(scene, W, H, spp, spp_begin=2, spp_end=6, samples_per_pass=1)
     c, sc_ = integ.Render(scene, W, H, spp, spp_begin=2, spp_end=6, samples_per_pass=4)
     assert biteq(a, c) and (sa["rays_closest"], sa["rays_any"]) == (sc_["rays_closest"], sc_["rays_any"])
