@@ -218,6 +218,7 @@ struct gnxr_scene {
         d.spheres = spheres.p;
         d.n_spheres = cs.n_spheres;
         d.materials = materials.p + 1;   // [0] carries the texture tables
+        d.escape_class = 0;              // render_one: 3 for the PathIntegrator in a scene without image-textured materials
         d.lt.lights = lights.p;
         d.lt.n_lights = (int)cs.desc_lights.size();
         d.lt.infinite = infinite.p;
@@ -735,6 +736,9 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
             const bool idx_ok = want < (1ull << 31) && want * 3ull < (1ull << 32);
             bool mem_ok = true;
             if (want > held && have_mem) mem_ok = (want - held) * 230ull < (unsigned long long)(0.45 * (double)free_b);
+            // (and never beyond ~150 GB of path state: a 177 GB configuration -- 6 x 64 spp at 1080p -- rendered three times SLOWER than the
+            // 118 GB one on the 288 GB card, profiles/r03_shard_efficiency.log)
+            if (want * 230ull > 150ull * 1000 * 1000 * 1000) mem_ok = false;
             if (idx_ok && mem_ok) break;
         }
     }
@@ -812,6 +816,9 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
     int class_mask = 0;
     for (const DMaterial &m : s->cs.materials) class_mask |= 1 << m.shade_class;
     const bool textured = (class_mask & 8) != 0;
+    // escaped continuation rays of a scene with infinite lights get shade queue 3 to themselves when no image-textured material claims it
+    const bool escape_queue = !whitted && !volpath && !textured && !s->cs.infinite_lights.empty() && getenv("GNXR_NO_ESCAPE_QUEUE") == nullptr;
+    sc.escape_class = escape_queue ? 3 : 0;
     bool area_only = true, area_env_only = true;
     for (const gnxr_light &l : s->cs.desc_lights) {
         if (l.type != GNXR_LIGHT_AREA_TRI) area_only = false;
@@ -918,7 +925,7 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
     auto shade_stage = [&](const int *q_in, int n, int *q_out, const unsigned *n_dev) -> int {
     if (timing) timer.begin(2, stream);
     // bin the paths by the shade specialisation of the material they hit (pclass written by k_trace)
-    const int n_classes = (class_mask & 8) ? 4 : 3;   // image-textured materials have a shade queue of their own
+    const int n_classes = ((class_mask & 8) || escape_queue) ? 4 : 3;   // image-textured materials -- or, without them, escaped rays -- have a shade queue of their own
     compact(COMPACT_HITCLASS, q_in, n, s->pclass.p, n_classes, n_classes, &dctr->q_class[0], s->queue_c0.p, s->queue_c1.p, s->queue_c2.p, s->queue_c3.p, 0, n_dev);
     {
         int *qc[4] = {s->queue_c0.p, s->queue_c1.p, s->queue_c2.p, s->queue_c3.p};
@@ -962,6 +969,11 @@ else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, slds, stream,
             if (class_mask & 8) GX_SHADE_TEX(LT_ALL);
         }
 #undef GX_SHADE
+        if (escape_queue) {
+            if (area_env_only) hipLaunchKernelGGL((k_shade_escape<LT_AREA | LT_ENV>), g, b, 0, stream, sc, pa, (const int *)qc[3], (const unsigned int *)&dctr->q_class[3]);
+            else hipLaunchKernelGGL((k_shade_escape<LT_ALL>), g, b, 0, stream, sc, pa, (const int *)qc[3], (const unsigned int *)&dctr->q_class[3]);
+            ++launches;
+        }
         launches += 1 + ((class_mask & 2) ? 1 : 0) + ((class_mask & 4) ? 1 : 0) + ((class_mask & 8) ? 1 : 0);
     }
     // next-vertex queue + NEE queue from the per-path flags; totals also count shadow and MIS rays

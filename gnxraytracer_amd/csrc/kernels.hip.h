@@ -73,6 +73,8 @@ struct DScene {
     int leaf1_from_verts;     // every one-triangle leaf's bounds equal the min / max of its vertices (checked by the scene compiler): no table read for them
     const DSphere *spheres;   // tested before the BVH; hit code -2 - index
     int n_spheres;
+    int escape_class;         // shade queue of a continuation ray that hits nothing in a scene WITH infinite lights (it still has to collect their Le):
+                              // 3 = a queue of its own (k_shade_escape) when the scene has no image-textured materials, else 0 (the diffuse queue, as before)
     const DMaterial *materials;   // materials[-1] holds the DTexTables of the scene (tex_tables(), device_texture.h)
     DLightTables lt;
     DSamplerTables st;
@@ -603,6 +605,30 @@ __global__ void __launch_bounds__(kBlock, shade_min_waves<LM>()) k_shade(DScene 
 #ifdef GX_SHADE_STATS
     if ((threadIdx.x & 63) == 0) for (int k = 0; k < 16; ++k) if (sst_[k]) atomicAdd(&g_shade_stats[k], sst_[k]);
 #endif
+}
+
+// PathIntegrator.cpp:107-108 for the paths whose continuation ray escaped a scene with infinite lights: `L += beta * light->Le(ray)` for every
+// infinite light when the vertex before was the camera or specular, and the path ends.  Binned as a class of their own (DScene::escape_class)
+// these paths no longer sit idle in the lanes of the diffuse shade kernel (cfg 4: one continuation ray in six leaves through the open
+// front of the box).  Same arithmetic, same order as the miss branch of k_shade.
+template <int LT>
+__global__ void __launch_bounds__(kBlock) k_shade_escape(DScene sc, PathArrays pa, const int *__restrict__ queue, const unsigned int *n_dev) {
+    const int n = (int)*n_dev;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int path = queue[i];
+        const uint2 m = pa.meta[path];
+        const int bounces = (int)((m.y >> 16) & 0xffu);
+        const bool specularBounce = (m.y >> 31) != 0;
+        if (bounces == 0 || specularBounce) {
+            const float4 o4 = pa.ray_o[path], d4 = pa.ray_d[path], b4 = pa.beta[path], L4 = pa.L[path];
+            const V3 ro(o4.x, o4.y, o4.z), rd(d4.x, d4.y, d4.z);
+            const Spec beta(b4.x, b4.y, b4.z);
+            Spec L(L4.x, L4.y, L4.z);
+            for (int k = 0; k < sc.lt.n_infinite; ++k) L = L + beta * light_Le<LT>(sc.lt, sc.lt.infinite[k], ro, rd);
+            pa.L[path] = make_float4(L.r, L.g, L.b, 0.f);
+        }
+        pa.pflags[path] = 0;
+    }
 }
 
 // The queue of the next trace when a sub-pass starts in state region `region` = slots [base, base + n_new): the survivors of the

@@ -145,7 +145,7 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
             // The shade class of a triangle hit is looked up from `hit` by the binning pass (k_compact_count<COMPACT_HITCLASS>: tri_class[hit]) --
             // a dependent gather here would stall the whole wave once per retire.  Only hits without a triangle get their class here.
             if (hitLeaf < 0) {
-                int cls = 0;   // misses that still have to collect an infinite light use the code of class 0
+                int cls = sc.escape_class;   // misses that still have to collect an infinite light: a queue of their own, or the code of class 0
                 if (SPH && hitLeaf != -1) { const int mat = sc.spheres[-2 - hitLeaf].material; if (mat >= 0) cls = sc.materials[mat].shade_class; }
                 else if (sc.lt.n_infinite == 0) {
                     // a ray that escapes a scene without infinite lights adds nothing and ends its path (PathIntegrator.cpp:101-113):

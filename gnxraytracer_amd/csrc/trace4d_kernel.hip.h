@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(kBlock, GX_T4D_WAVES) k_trace4d(DScene sc, Pat
         if (kind == 0) {
             pa.hit[path] = hitLeaf;
             if (hitLeaf < 0) {
-                int cls = 0;
+                int cls = sc.escape_class;
                 if (SPH && hitLeaf != -1) { const int mat = sc.spheres[-2 - hitLeaf].material; if (mat >= 0) cls = sc.materials[mat].shade_class; }
                 else if (sc.lt.n_infinite == 0) { cls = 4; pa.pflags[path] = 0; }
                 pa.pclass[path] = (unsigned char)cls;

@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
             if (kind == 0) {
                 pa.hit[path] = hitLeaf;
                 if (hitLeaf < 0) {   // triangle hits: the binning pass looks the class up from `hit` (k_compact_count<COMPACT_HITCLASS>)
-                    int cls = 0;     // misses that still have to collect an infinite light use the code of class 0
+                    int cls = sc.escape_class;   // misses that still have to collect an infinite light: a queue of their own, or the code of class 0
                     if (SPH && hitLeaf != -1) { const int mat = sc.spheres[-2 - hitLeaf].material; if (mat >= 0) cls = sc.materials[mat].shade_class; }
                     else if (sc.lt.n_infinite == 0) {
                         // a ray that escapes a scene without infinite lights adds nothing and ends its path (PathIntegrator.cpp:101-113):
