@@ -59,6 +59,7 @@ std::vector<int> g_devices;        // gnxr_init_devices: every scene is replicat
 std::vector<char> g_peer_ok;       // per entry of g_devices: the primary device and this one can address each other's memory (peer access enabled both ways)
 int g_num_cus = 256;
 int g_profiling = 0;
+int g_grid_bpc = 8;   // blocks per CU that cap the grid of a grid-stride kernel (GNXR_GRID_BLOCKS_PER_CU: tuning knob)
 int g_trace_blocks_per_cu = 5;   // persistent blocks of the traversal kernel per CU (5 waves per SIMD at its 96 VGPRs, 32 KB of LDS each); GNXR_TRACE_BLOCKS_PER_CU overrides (tuning)
 
 // Per-kernel timing with HIP events on the render stream.  Events are recycled from a pool and resolved
@@ -102,6 +103,7 @@ int ensure_device() {
     g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     g_device = dev;
     if (const char *e = getenv("GNXR_TRACE_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) g_trace_blocks_per_cu = v; }
+    if (const char *e = getenv("GNXR_GRID_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 4096) g_grid_bpc = v; }
     return GNXR_OK;
 }
 
@@ -128,7 +130,8 @@ struct DevBuf {
     template <typename V> int upload(const V &v) { return upload(v.data(), v.size()); }
 };
 
-int grid_for(long long n, int blocks_per_cu = 8) {
+int grid_for(long long n, int blocks_per_cu = 0) {
+    if (blocks_per_cu <= 0) blocks_per_cu = g_grid_bpc;
     long long need = (n + kBlock - 1) / kBlock;
     long long cap = (long long)g_num_cus * blocks_per_cu;
     return (int)std::max<long long>(1, std::min(need, cap));
@@ -899,7 +902,7 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
     auto compact = [&](int mode, const int *qin, int nin, const unsigned char *keys, int nout, int nscatter, unsigned int *totals, int *o0, int *o1, int *o2, int *o3 = nullptr, int split = 0,
                        const unsigned *n_dev = nullptr) {
         int tiles = (nin + kCompactTile - 1) / kCompactTile;
-        int g = std::max(1, std::min(tiles, g_num_cus * 8));
+        int g = std::max(1, std::min(tiles, g_num_cus * g_grid_bpc));
         const int *nohit = nullptr; const unsigned char *nocls = nullptr; unsigned char *nokeys = nullptr;
         // FLAGS with a fifth count: the paths that continue AND live in the lower half of the state arrays (slot < split)
         if (mode == COMPACT_FLAGS && nout == 5) hipLaunchKernelGGL((k_compact_count<COMPACT_FLAGS, 5>), dim3(g), dim3(kCompactBlock), 0, stream, qin, nin, keys, s->tile_counts.p, tiles, nohit, nocls, nokeys, split, n_dev);
@@ -929,7 +932,11 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
     compact(COMPACT_HITCLASS, q_in, n, s->pclass.p, n_classes, n_classes, &dctr->q_class[0], s->queue_c0.p, s->queue_c1.p, s->queue_c2.p, s->queue_c3.p, 0, n_dev);
     {
         int *qc[4] = {s->queue_c0.p, s->queue_c1.p, s->queue_c2.p, s->queue_c3.p};
-        dim3 g(grid_for(n)), b(kBlock);
+        // 32 blocks per CU: of a k_shade grid only 2 - 3 blocks per CU are resident at a time (168 - 256 registers), and many short blocks
+        // balance the end of the launch better than few long ones (8 / 16 / 32 / 64 / 128 / 1024 per CU: shade 171.4 / 167.1 / 165.7 / 165.4 /
+        // 168.4 / 176.4 ms on cfg 3, profiles/r03_ab_shade_grid_cfg3.log; each block refills its LDS tables, which is what the large grids pay)
+        static const int shade_bpc = getenv("GNXR_SHADE_BLOCKS_PER_CU") ? std::max(1, atoi(getenv("GNXR_SHADE_BLOCKS_PER_CU"))) : 32;   // tuning knob
+        dim3 g(grid_for(n, shade_bpc)), b(kBlock);
         // the Halton tables of the first dimensions go to LDS (device_sampler.h LdsSampler): 64 dimensions (the camera sample + 6 path vertices:
         // 18.8 KB per block; deeper vertices read global memory).  A/B on cfg 3: shade -3 % at 64 / 88 dimensions, +4 % at 112 (occupancy)
         static const int shade_lds_dims = getenv("GNXR_SHADE_LDS_DIMS") ? std::max(0, std::min(128, atoi(getenv("GNXR_SHADE_LDS_DIMS")))) : 64;   // tuning knob
@@ -1204,15 +1211,16 @@ else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, slds, stream,
                 }
                 if (timing) timer.begin(2, stream);
 // bin the live paths by state (main ray / shadow-ray segment / scattering-ray segment), one k_vol_step instantiation per bin
+// (32 blocks per CU for the step kernels, as for k_shade: many short blocks balance the end of a launch better; cfg 5 -2 %)
                 compact(COMPACT_CLASS, q_in, n, va.state, 3, 3, &dctr->q_class[0], s->queue_c0.p, s->queue_c1.p, s->queue_c2.p);
                 {
                     int *qc[3] = {s->queue_c0.p, s->queue_c1.p, s->queue_c2.p};
                     // the scene's material and light tables go to LDS when they are small (as for k_shade)
                     const int vmats = s->cs.materials.size() <= 12 ? (int)s->cs.materials.size() : 0, vlights = (nL > 0 && nL <= 16) ? nL : 0;
                     const size_t vlds = (size_t)vmats * sizeof(DMaterial) + (size_t)vlights * sizeof(DLight);
-#define GX_VS1(LMV, LTV, ST) hipLaunchKernelGGL((k_vol_step<LMV, LTV, ST>), dim3(grid_for(n)), dim3(kBlock), vlds, stream, sc, mt, r, pa, va, (const int *)qc[ST], (const unsigned int *)&dctr->q_class[ST], vmats, vlights)
+#define GX_VS1(LMV, LTV, ST) hipLaunchKernelGGL((k_vol_step<LMV, LTV, ST>), dim3(grid_for(n, 32)), dim3(kBlock), vlds, stream, sc, mt, r, pa, va, (const int *)qc[ST], (const unsigned int *)&dctr->q_class[ST], vmats, vlights)
 #define GX_VS(LMV, LTV) do { GX_VS1(LMV, LTV, VS_MAIN); GX_VS1(LMV, LTV, VS_SHADOW); GX_VS1(LMV, LTV, VS_MIS); } while (0)
-#define GX_VST1(LTV, ST) hipLaunchKernelGGL((k_vol_step<LM_ALL, LTV, ST, true>), dim3(grid_for(n)), dim3(kBlock), vlds, stream, sc, mt, r, pa, va, (const int *)qc[ST], (const unsigned int *)&dctr->q_class[ST], vmats, vlights)
+#define GX_VST1(LTV, ST) hipLaunchKernelGGL((k_vol_step<LM_ALL, LTV, ST, true>), dim3(grid_for(n, 32)), dim3(kBlock), vlds, stream, sc, mt, r, pa, va, (const int *)qc[ST], (const unsigned int *)&dctr->q_class[ST], vmats, vlights)
 #define GX_VST(LTV) do { GX_VST1(LTV, VS_MAIN); GX_VST1(LTV, VS_SHADOW); GX_VST1(LTV, VS_MIS); } while (0)
                     if (textured) { if (area_only) GX_VST(LT_AREA); else GX_VST(LT_ALL); }
                     else if (area_only) { if (class_mask <= 1) GX_VS(LM_DIFFUSE, LT_AREA); else if (class_mask <= 3) GX_VS(LM_GLOSSY, LT_AREA); else GX_VS(LM_ALL, LT_AREA); }
