@@ -188,6 +188,9 @@ struct gnxr_scene {
     Counters *h_counters = nullptr;  // pinned
     // the device-driven PathIntegrator loop: lagging copies of the counters (pinned ring, one event per slot) -- the host reads them
     // without ever waiting for the iteration it has just enqueued
+    // k_shade runs one kernel per material class; the classes are independent, so they go to different streams and fill each other's ends
+    hipStream_t aux_stream[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     static constexpr int kRing = 8;
     Counters *h_ring = nullptr;      // pinned, kRing entries
     hipEvent_t ring_ev[kRing] = {};
@@ -206,6 +209,9 @@ struct gnxr_scene {
         if (h_ring) (void)hipHostFree(h_ring);
         if (h_stage) (void)hipHostFree(h_stage);
         for (hipEvent_t e : ring_ev) if (e) (void)hipEventDestroy(e);
+        for (hipStream_t a : aux_stream) if (a) (void)hipStreamDestroy(a);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        for (hipEvent_t e : ev_join) if (e) (void)hipEventDestroy(e);
     }
 
     DScene device_scene(int W, int H) {
@@ -592,6 +598,9 @@ static int upload_scene(gnxr_scene *s) {
     if (hipHostMalloc((void **)&s->h_counters, sizeof(Counters)) != hipSuccess) { set_error("hipHostMalloc failed"); return GNXR_ERR_OOM; }
     if (hipHostMalloc((void **)&s->h_ring, sizeof(Counters) * gnxr_scene::kRing) != hipSuccess) { set_error("hipHostMalloc failed"); return GNXR_ERR_OOM; }
     for (hipEvent_t &e : s->ring_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (hipStream_t &a : s->aux_stream) HIP_TRY(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+    for (hipEvent_t &e : s->ev_join) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return GNXR_OK;
 }
 
@@ -947,15 +956,29 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
         const int lmats = (shade_lds_tabs && s->cs.materials.size() <= 12) ? (int)s->cs.materials.size() : 0;
         const int llights = (shade_lds_tabs && nL > 0 && nL <= 16) ? nL : 0;
         const size_t slds = (sdims > 0 ? ((((size_t)snperm * 2 + 15) & ~(size_t)15) + (size_t)sdims * 32) : 0) + (size_t)lmats * sizeof(DMaterial) + (size_t)llights * sizeof(DLight);
+        // the class kernels work on disjoint paths: with three or more of them (cfg 4: diffuse, glossy, Disney, escaped rays) classes 1 - 3 run on
+        // two auxiliary streams beside class 0, so that the blocks of one fill the thinning end of another (fork / join with events): cfg 4 shade
+        // -4 %; with two kernels of similar size (cfg 3) the same costs 1.5 %, so they stay in line (profiles/r03_ab_shade_streams_*.log;
+        // GNXR_SHADE_STREAMS = 0 / 1 forces either)
+        static const int shade_streams = getenv("GNXR_SHADE_STREAMS") ? atoi(getenv("GNXR_SHADE_STREAMS")) : -1;
+        const int n_class_kernels = 1 + ((class_mask & 2) ? 1 : 0) + ((class_mask & 4) ? 1 : 0) + (((class_mask & 8) || escape_queue) ? 1 : 0);
+        const bool fork = (shade_streams < 0 ? n_class_kernels >= 3 : (shade_streams != 0 && n_class_kernels >= 2)) && s->aux_stream[0] && s->aux_stream[1];
+        hipStream_t cst[4] = {stream, stream, stream, stream};
+        if (fork) {
+            (void)hipEventRecord(s->ev_fork, stream);
+            (void)hipStreamWaitEvent(s->aux_stream[0], s->ev_fork, 0);
+            (void)hipStreamWaitEvent(s->aux_stream[1], s->ev_fork, 0);
+            cst[1] = s->aux_stream[0]; cst[2] = s->aux_stream[1]; cst[3] = s->aux_stream[1];
+        }
 #define GX_SHADE(LMV, LTV, C)                                                                                                                        \
     do {                                                                                                                                             \
-if (spheres) hipLaunchKernelGGL((k_shade<LMV, LTV, true>), g, b, slds, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C], sdims, snperm, lmats, llights); \
-else hipLaunchKernelGGL((k_shade<LMV, LTV, false>), g, b, slds, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C], sdims, snperm, lmats, llights);       \
+if (spheres) hipLaunchKernelGGL((k_shade<LMV, LTV, true>), g, b, slds, cst[C], sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C], sdims, snperm, lmats, llights); \
+else hipLaunchKernelGGL((k_shade<LMV, LTV, false>), g, b, slds, cst[C], sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C], sdims, snperm, lmats, llights);       \
     } while (0)
 #define GX_SHADE_TEX(LTV)                                                                                                                            \
     do {                                                                                                                                             \
-if (spheres) hipLaunchKernelGGL((k_shade<LM_ALL, LTV, true, true>), g, b, slds, stream, sc, r, pa, (const int *)qc[3], (const unsigned int *)&dctr->q_class[3], sdims, snperm, lmats, llights); \
-else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, slds, stream, sc, r, pa, (const int *)qc[3], (const unsigned int *)&dctr->q_class[3], sdims, snperm, lmats, llights);       \
+if (spheres) hipLaunchKernelGGL((k_shade<LM_ALL, LTV, true, true>), g, b, slds, cst[3], sc, r, pa, (const int *)qc[3], (const unsigned int *)&dctr->q_class[3], sdims, snperm, lmats, llights); \
+else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, slds, cst[3], sc, r, pa, (const int *)qc[3], (const unsigned int *)&dctr->q_class[3], sdims, snperm, lmats, llights);       \
     } while (0)
         if (area_only) {
             GX_SHADE(LM_DIFFUSE, LT_AREA, 0);
@@ -964,7 +987,7 @@ else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, slds, stream,
             if (class_mask & 8) GX_SHADE_TEX(LT_AREA);
         } else if (area_env_only && !spheres && !(class_mask & 8)) {
             // BASELINE config 4's light set (area lights + one InfiniteAreaLight): without the delta-light and sky-box code
-#define GX_SHADE_AE(LMV, C) hipLaunchKernelGGL((k_shade<LMV, LT_AREA | LT_ENV, false>), g, b, slds, stream, sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C], sdims, snperm, lmats, llights)
+#define GX_SHADE_AE(LMV, C) hipLaunchKernelGGL((k_shade<LMV, LT_AREA | LT_ENV, false>), g, b, slds, cst[C], sc, r, pa, (const int *)qc[C], (const unsigned int *)&dctr->q_class[C], sdims, snperm, lmats, llights)
             GX_SHADE_AE(LM_DIFFUSE, 0);
             if (class_mask & 2) GX_SHADE_AE(LM_GLOSSY, 1);
             if (class_mask & 4) GX_SHADE_AE(LM_ALL, 2);
@@ -977,9 +1000,15 @@ else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, slds, stream,
         }
 #undef GX_SHADE
         if (escape_queue) {
-            if (area_env_only) hipLaunchKernelGGL((k_shade_escape<LT_AREA | LT_ENV>), g, b, 0, stream, sc, pa, (const int *)qc[3], (const unsigned int *)&dctr->q_class[3]);
-            else hipLaunchKernelGGL((k_shade_escape<LT_ALL>), g, b, 0, stream, sc, pa, (const int *)qc[3], (const unsigned int *)&dctr->q_class[3]);
+            if (area_env_only) hipLaunchKernelGGL((k_shade_escape<LT_AREA | LT_ENV>), g, b, 0, cst[3], sc, pa, (const int *)qc[3], (const unsigned int *)&dctr->q_class[3]);
+            else hipLaunchKernelGGL((k_shade_escape<LT_ALL>), g, b, 0, cst[3], sc, pa, (const int *)qc[3], (const unsigned int *)&dctr->q_class[3]);
             ++launches;
+        }
+        if (fork) {
+            (void)hipEventRecord(s->ev_join[0], s->aux_stream[0]);
+            (void)hipEventRecord(s->ev_join[1], s->aux_stream[1]);
+            (void)hipStreamWaitEvent(stream, s->ev_join[0], 0);
+            (void)hipStreamWaitEvent(stream, s->ev_join[1], 0);
         }
         launches += 1 + ((class_mask & 2) ? 1 : 0) + ((class_mask & 4) ? 1 : 0) + ((class_mask & 8) ? 1 : 0);
     }
