@@ -1,5 +1,5 @@
 """Randomised device-vs-oracle sweep (dev tool): scenes x integrators x odd image sizes x depths x rr thresholds x light
-strategies x sample ranges x shards.  Every case must match the oracle bit for bit (images and ray counts)."""
+strategies x sample ranges x shards x sub-pass sizes x sub-passes in flight.  Every case must match the oracle bit for bit (images and ray counts)."""
 import os, sys, json, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -37,18 +37,18 @@ def run_sweep(seed=1, ncase=40, verbose=True):
         W, H = int(rng.integers(17, 90)), int(rng.integers(17, 90)); spp = int(rng.choice([4, 8, 16, 64]))
         s0 = int(rng.integers(0, spp)); s1 = int(rng.integers(s0 + 1, spp + 1))
         shards = int(rng.choice([1, 1, 2, 3])); sr = int(rng.choice([1, 2, 5])); si = int(rng.integers(0, shards))
-        spp_pass = int(rng.choice([0, 1, 3]))
+        spp_pass = int(rng.choice([0, 1, 3])); in_flight = int(rng.choice([0, 1, 2, 3, 8]))
         if kind == "whitted": integ = gx.WhittedIntegrator(min(depth, 6))
         elif kind == "direct": integ = gx.DirectLightingIntegrator(str(rng.choice(["all", "one"])), min(depth, 6)); kind = "direct-" + {0: "all", 1: "one"}[integ.directStrategy]
         elif kind == "volpath": integ = gx.VolPathIntegrator(depth, rr, strat)
         else: integ = gx.PathIntegrator(depth, rr, strat)
         kw = dict(spp_begin=s0, spp_end=s1, shard_index=si, shard_count=shards, shard_rows=sr)
         t0 = time.time()
-        img, st = integ.Render(gx.Scene(b), W, H, spp, samples_per_pass=spp_pass, **kw)
+        img, st = integ.Render(gx.Scene(b), W, H, spp, samples_per_pass=spp_pass, passes_in_flight=in_flight, **kw)
         oimg, ost = ol.OracleScene(b).render(integ, W, H, spp, **kw)
         same = img[..., :3].view(np.uint32) == oimg[..., :3].view(np.uint32)
         ok = bool(same.all()) and (st["rays_closest"], st["rays_any"]) == (ost["rays_closest"], ost["rays_any"])
-        desc = (f"{name:15s} {kind:10s} depth {depth:2d} rr {rr:4.2f} {strat:8s} {W}x{H} spp {spp} [{s0},{s1}) shard {si}/{shards}x{sr} pass {spp_pass}  identical {same.mean()*100:.3f}% "
+        desc = (f"{name:15s} {kind:10s} depth {depth:2d} rr {rr:4.2f} {strat:8s} {W}x{H} spp {spp} [{s0},{s1}) shard {si}/{shards}x{sr} pass {spp_pass}x{in_flight}  identical {same.mean()*100:.3f}% "
                 f"rays {st['rays_closest']}/{st['rays_any']} vs {ost['rays_closest']}/{ost['rays_any']}")
         if not ok: bad.append(desc)
         if verbose: print(("ok  " if ok else "BAD ") + desc + f"  {time.time()-t0:.1f}s", flush=True)
