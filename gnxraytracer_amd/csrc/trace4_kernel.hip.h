@@ -111,7 +111,7 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
 
     // per-lane ray state
     bool live = false;
-    int pk = 0, path = -1;   // pk: kind (bits 0-1: 0 continuation, 1 shadow, 2 MIS) | kz << 2 (Triangle.cpp:91) | done << 4 | exact << 5 | first hit ends the walk << 6
+    int pk = 0, path = -1;   // pk: kind (bits 0-1: 0 continuation, 1 shadow, 2 MIS) | kz << 2 (Triangle.cpp:91) | done << 4 | exact << 5 | first hit ends the walk << 6 | the staged leaf is in progress (its box is decided) << 7
     V3 ro, inv;
     float Sx = 0, Sy = 0, tMax = 0;
     unsigned oNX = 0, oNY = 16, oNZ = 32;   // byte offset of the near plane of each axis inside a DNode4 (far = 48 | 80 | 112 - near ... see below)
@@ -420,7 +420,14 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
             // the leaf's own bounds -- exact ties (t == tMax on flat, axis-aligned boxes such as the Cornell walls) then resolve as in the
             // reference.  The bounds of a one-triangle leaf are the componentwise min / max of its vertices (Triangle::WorldBound, exact),
             // which this phase loads anyway; only larger leaves read the floats of their LinearBVHNode (leaf_box, addressed by the first triangle).
-            const bool retest = SPH ? hitLeaf != -1 : hitLeaf >= 0;
+            //
+            // ONE triangle per lane and trip.  A leaf of several triangles (the reference keys its build on the centroid of a primitive's BOUNDS,
+            // so the two triangles of an axis-aligned quad -- every Cornell wall -- share a leaf, and almost every ray ends on a wall) stays staged
+            // with its next triangle: looping over it here kept the whole wave for a second round with a handful of lanes on in more than half
+            // of all trips (tests/dev_stats.py: 1.55 rounds per trip).  Its box is tested once, at its first triangle (pk bit 7 remembers);
+            // the triangles are still tested in order, each against the tMax the previous ones left.
+            const bool first = (pk & 128) == 0;
+            const bool retest = first && (SPH ? hitLeaf != -1 : hitLeaf >= 0);
             const bool fromVerts = retest && leafN == 1 && sc.leaf1_from_verts;
             int neg[3] = {inv.x < 0, inv.y < 0, inv.z < 0};
             if (retest && !fromVerts) {
@@ -428,29 +435,31 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
                 if (COUNT) cntRetests++;
                 visit = slab_test(b0, b1, ro, inv, neg, tMax);
             }
+            bool more = false;   // the leaf has further triangles to test
             if (visit) {
                 RayShear shear;
                 const int kz = (pk >> 2) & 3;
                 shear.kz = kz; shear.kx = kz == 2 ? 0 : kz + 1; shear.ky = shear.kx == 2 ? 0 : shear.kx + 1;
                 shear.Sx = Sx; shear.Sy = Sy; shear.Sz = kz == 0 ? inv.x : (kz == 1 ? inv.y : inv.z);
-                for (int i = 0; i < leafN; ++i) {
-                    V3 p0, p1, p2;
-                    load_tri(tris, leafOff + i, &p0, &p1, &p2);
-                    if (COUNT) cntTris++;
-                    if (fromVerts) {
-                        const float4 b0 = make_float4(fminf(fminf(p0.x, p1.x), p2.x), fminf(fminf(p0.y, p1.y), p2.y), fminf(fminf(p0.z, p1.z), p2.z), fmaxf(fmaxf(p0.x, p1.x), p2.x));
-                        const float4 b1 = make_float4(fmaxf(fmaxf(p0.y, p1.y), p2.y), fmaxf(fmaxf(p0.z, p1.z), p2.z), 0.f, 0.f);
-                        if (!slab_test(b0, b1, ro, inv, neg, tMax)) break;
-                    }
-                    TriHit h;
-                    if (tri_test_sheared(p0, p1, p2, ro, shear, tMax, &h)) {
-                        hitLeaf = leafOff + i;
-                        if (pk & 64) { cur = -1; break; }        // IntersectP returns at the first hit (and so may a MIS ray that expects a miss)
-                        tMax = h.t;                            // GeometricPrimitive::Intersect shrinks ray.tMax
-                    }
+                V3 p0, p1, p2;
+                load_tri(tris, leafOff, &p0, &p1, &p2);
+                if (COUNT) cntTris++;
+                bool inBox = true;
+                if (fromVerts) {
+                    const float4 b0 = make_float4(fminf(fminf(p0.x, p1.x), p2.x), fminf(fminf(p0.y, p1.y), p2.y), fminf(fminf(p0.z, p1.z), p2.z), fmaxf(fmaxf(p0.x, p1.x), p2.x));
+                    const float4 b1 = make_float4(fmaxf(fmaxf(p0.y, p1.y), p2.y), fmaxf(fmaxf(p0.z, p1.z), p2.z), 0.f, 0.f);
+                    inBox = slab_test(b0, b1, ro, inv, neg, tMax);
+                }
+                more = leafN > 1;
+                TriHit h;
+                if (inBox && tri_test_sheared(p0, p1, p2, ro, shear, tMax, &h)) {
+                    hitLeaf = leafOff;
+                    if (pk & 64) { cur = -1; more = false; }   // IntersectP returns at the first hit (and so may a MIS ray that expects a miss)
+                    else tMax = h.t;                            // GeometricPrimitive::Intersect shrinks ray.tMax
                 }
             }
-            leafN = 0;
+            if (more) { leafOff += 1; leafN -= 1; pk |= 128; }
+            else { leafN = 0; pk &= ~128; }
         }
         GX_TICK(13);
         // ---------------- phase C: retire finished rays ----------------
