@@ -321,7 +321,8 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
             const int nSearching = __popcll(__ballot(hungry));
             if (nSearching * kTraceLeaveDiv <= nLive * kTraceLeaveMul && (nSearching == 0 || nSearching < nLive)) break;
 #ifdef GX_TRACE_STATS
-            { const int ns = __popcll(__ballot(searching)); GX_STAT(1, 1); GX_STAT(2, ns);
+            { const int ns = __popcll(__ballot(searching)); GX_STAT(1, 1); GX_STAT(2, ns); const int nh_ = __popcll(__ballot(live && leafN > 0 && !searching)), nf_ = __popcll(__ballot(live && cur == -1 && leafN == 0)), nsp_ = __popcll(__ballot(searching && leafN > 0));
+              GX_STAT(20, nLive); GX_STAT(21, nh_); GX_STAT(22, nf_); GX_STAT(23, nsp_);
               const int n16 = __popcll(__ballot(searching && cur < 16)), n64 = __popcll(__ballot(searching && cur < 64)), n256 = __popcll(__ballot(searching && cur < 256)), n1k = __popcll(__ballot(searching && cur < 1024));
               GX_STAT(16, n16); GX_STAT(17, n64); GX_STAT(18, n256); GX_STAT(19, n1k); }
 #endif

@@ -10,9 +10,9 @@ scene = gx.Scene(b); integ = gx.PathIntegrator(8, 1.0, "spatial")
 out = torch.zeros((1080, 1920, 4), device="cuda")
 lib = C.CDLL(gx.LIB_PATH)
 buf = (C.c_ulonglong * 24)()
-integ.RenderDevice(scene, out.data_ptr(), 1920, 1080, 1024, spp_begin=0, spp_end=8, samples_per_pass=8)
+integ.RenderDevice(scene, out.data_ptr(), 1920, 1080, 1024, spp_begin=0, spp_end=64, samples_per_pass=32)
 lib.gnxr_debug_trace_stats(buf, 1)
-st = integ.RenderDevice(scene, out.data_ptr(), 1920, 1080, 1024, spp_begin=8, spp_end=16, samples_per_pass=8)
+st = integ.RenderDevice(scene, out.data_ptr(), 1920, 1080, 1024, spp_begin=64, spp_end=128, samples_per_pass=32)
 lib.gnxr_debug_trace_stats(buf, 1)
 v = list(buf)
 rays = st["rays_closest"] + st["rays_any"]
@@ -29,6 +29,7 @@ d["A_lane_iters_per_ray"] = v[2] / rays
 d["B_wave_tri_iters_per_ray"] = v[5] * 64 / rays
 d["B_lane_tris_per_ray"] = v[6] / rays
 d["refill_events_per_ray_x64"] = v[7] * 64 / rays
+d["A_live_frac"] = v[20] / max(1, v[1]) / 64; d["A_holding_leaf_frac"] = v[21] / max(1, v[1]) / 64; d["A_finished_frac"] = v[22] / max(1, v[1]) / 64; d["A_speculating_frac"] = v[23] / max(1, v[1]) / 64
 d["A_visits_below"] = {"16": v[16] / max(1, v[2]), "64": v[17] / max(1, v[2]), "256": v[18] / max(1, v[2]), "1024": v[19] / max(1, v[2])}
 tt = sum(v[i] for i in (11, 12, 13, 15)) or 1
 d["time_share"] = {"refill": v[11] / tt, "A": v[12] / tt, "B": v[13] / tt, "retire": v[15] / tt}
