@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GNXR_ABI_VERSION 5
+#define GNXR_ABI_VERSION 5   /* 5: gnxr_render_params::passes_in_flight; gnxr_stats::passes_in_flight / loop_iterations / state_bytes */
 
 typedef enum gnxr_status {
     GNXR_OK = 0,
