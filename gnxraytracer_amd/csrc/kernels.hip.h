@@ -557,7 +557,10 @@ __global__ void __launch_bounds__(kBlock, shade_min_waves<LM>()) k_shade(DScene 
                                     pa.mis_Y[path] = make_float4(Y.r, Y.g, Y.b, 0.f);
                                 }
                                 pa.nbeta[path] = make_float4(beta.r, beta.g, beta.b, 0.f);
-                                pa.nee_vis[path] = (unsigned)nflags << 16;
+                                // byte 2: the record's flags; bit 7 of it: beta is not finite (k_nee_combine may then not skip a vertex whose rays both failed:
+                                // the reference's L += beta * 0 would poison the pixel, and so must this)
+                                const bool betaFinite = __builtin_isfinite(beta.r) && __builtin_isfinite(beta.g) && __builtin_isfinite(beta.b);
+                                pa.nee_vis[path] = ((unsigned)nflags | (betaFinite ? 0u : 0x80u)) << 16;
                                 wantNee = true;
                                 wantShadow = (nflags & 1) != 0;
                                 wantMis = (nflags & 2) != 0;

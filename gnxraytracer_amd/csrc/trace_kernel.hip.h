@@ -429,6 +429,10 @@ static __global__ void __launch_bounds__(kBlock) k_nee_combine(PathArrays pa, co
         int path = queue[i];
         const unsigned v = reinterpret_cast<const unsigned *>(vis)[path];
         const int flags = (int)((v >> 16) & 0xffu);
+        // neither ray arrived (the light sample is occluded and the BSDF sample missed the light): Ld = 0, and L + beta * (0 / pdf) == L bit
+        // for bit when beta is finite (k_shade says so in bit 7 of the flags; pdf > 0) -- a third to a half of the vertices; their three
+        // records and L are not touched
+        if (!(flags & 0x80) && !(((flags & 1) && (v & 0xffu)) || ((flags & 2) && ((v >> 8) & 0xffu)))) continue;
         float4 X4 = pa.sh_X[path];
         Spec Ld(0.f);
         if ((flags & 1) && (v & 0xffu)) Ld = Ld + Spec(X4.x, X4.y, X4.z);
