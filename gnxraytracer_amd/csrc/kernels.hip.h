@@ -415,9 +415,9 @@ __global__ void __launch_bounds__(kBlock, shade_min_waves<LM>()) k_shade(DScene 
             uint32_t index = m.x;
             int dim = (int)(m.y & 0xffffu), bounces = (int)((m.y >> 16) & 0xffu);
             bool specularBounce = (m.y >> 31) != 0;
-            float4 o4 = pa.ray_o[path], d4 = pa.ray_d[path], b4 = pa.beta[path], L4 = pa.L[path];
+            float4 o4 = pa.ray_o[path], d4 = pa.ray_d[path], b4 = pa.beta[path];
             V3 ro(o4.x, o4.y, o4.z), rd(d4.x, d4.y, d4.z);
-            Spec beta(b4.x, b4.y, b4.z), L(L4.x, L4.y, L4.z);
+            Spec beta(b4.x, b4.y, b4.z);
             float etaScale = b4.w;
             int leaf = leafCur_;
             bool found = leaf != -1;
@@ -449,12 +449,14 @@ __global__ void __launch_bounds__(kBlock, shade_min_waves<LM>()) k_shade(DScene 
             }
             GX_STICK(0);   // state + triangle loads, tri_test, surface_point
             // PathIntegrator.cpp:101-111: emitted light at the vertex / from the environment
-            if (bounces == 0 || specularBounce) {
-                if (found) {
-                    if (triLight >= 0) L = L + beta * area_L(ltab.lights[triLight], sp.n, -rd);
-                } else {
-                    for (int k = 0; k < ltab.n_infinite; ++k) L = L + beta * light_Le<LT>(ltab, ltab.infinite[k], ro, rd);
-                }
+            // (L is read and written only by the vertices that add to it here -- the camera vertex or a vertex after a specular bounce, on a light
+            // or out in the infinite lights; k_nee_combine owns the other additions: 32 B of state traffic less for every other vertex)
+            if ((bounces == 0 || specularBounce) && (found ? triLight >= 0 : ltab.n_infinite > 0)) {
+                const float4 L4 = pa.L[path];
+                Spec L(L4.x, L4.y, L4.z);
+                if (found) L = L + beta * area_L(ltab.lights[triLight], sp.n, -rd);
+                else for (int k = 0; k < ltab.n_infinite; ++k) L = L + beta * light_Le<LT>(ltab, ltab.infinite[k], ro, rd);
+                pa.L[path] = make_float4(L.r, L.g, L.b, 0.f);
             }
             GX_STICK(1);   // Le
             if (found && bounces < r.max_depth) {
@@ -600,7 +602,6 @@ __global__ void __launch_bounds__(kBlock, shade_min_waves<LM>()) k_shade(DScene 
                 }
             }
             GX_STICK(10);  // continuation: 2 Halton values, BSDF sample_f, Russian roulette, state stores
-            pa.L[path] = make_float4(L.r, L.g, L.b, 0.f);
         }
         pa.pflags[path] = (unsigned char)((survive ? 1 : 0) | (wantNee ? 2 : 0) | (wantShadow ? 4 : 0) | (wantMis ? 8 : 0));
         pathCur_ = pathNext_; leafCur_ = leafNext_; pathNext_ = pathNext2_;
