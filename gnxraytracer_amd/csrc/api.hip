@@ -165,8 +165,9 @@ struct gnxr_scene {
     DLightGrid grid;
     int grid_strategy = -1;
     // per-render state (grown on demand)
-    DevBuf<float4> ray_o, ray_d, beta, L, sh_o, sh_d, sh_X, mis_o, mis_d, mis_Y, nbeta, accum, out;
-    DevBuf<uint2> meta;
+    DevBuf<float4> rec[kRecGroups], mis_Y;   // the record groups of the path slots (PathArrays, kernels.hip.h)
+    static void record_ptrs(DevBuf<float4> *b, float4 *g[kRecGroups]) { for (int i = 0; i < kRecGroups; ++i) g[i] = b[i].p; }
+    DevBuf<float4> L, accum, out;
     DevBuf<int> hit, queue_a, queue_b, queue_nee, queue_c0, queue_c1, queue_c2, queue_c3;
     DevBuf<unsigned char> pflags, pclass;
     DevBuf<unsigned int> nee_vis;
@@ -176,8 +177,7 @@ struct gnxr_scene {
     DevBuf<int4> vol_vs;
     DevBuf<unsigned char> vol_state;
     // VolPath packing (k_vol_pack): the second set of the state arrays, the original slot of every path, the renumbering map and the results
-    DevBuf<float4> vol_alt[kVolPackF4], vol_Lout;
-    DevBuf<uint2> vol_alt_meta;
+    DevBuf<float4> vol_alt[kVolPackF4], vol_alt_rec[kRecGroups], vol_Lout;
     DevBuf<unsigned char> vol_alt_state;
     DevBuf<int> vol_orig, vol_alt_orig, vol_newslot;
     DevBuf<float4> wh_o, wh_d, wh_L, wh_w;   // Whitted recursion frames (whitted_kernel.hip.h)
@@ -744,13 +744,13 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
         size_t free_b = 0, total_b = 0;
         const bool have_mem = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
         for (; in_flight > 1; --in_flight) {
-            const unsigned long long want = (unsigned long long)in_flight * half, held = (unsigned long long)s->ray_o.n;
+            const unsigned long long want = (unsigned long long)in_flight * half, held = (unsigned long long)s->L.n;
             const bool idx_ok = want < (1ull << 31) && want * 3ull < (1ull << 32);
             bool mem_ok = true;
-            if (want > held && have_mem) mem_ok = (want - held) * 230ull < (unsigned long long)(0.45 * (double)free_b);
+            if (want > held && have_mem) mem_ok = (want - held) * 238ull < (unsigned long long)(0.45 * (double)free_b);
             // (and never beyond ~150 GB of path state: a 177 GB configuration -- 6 x 64 spp at 1080p -- rendered three times SLOWER than the
             // 118 GB one on the 288 GB card, profiles/r03_shard_efficiency.log)
-            if (want * 230ull > 150ull * 1000 * 1000 * 1000) mem_ok = false;
+            if (want * 238ull > 150ull * 1000 * 1000 * 1000) mem_ok = false;
             if (idx_ok && mem_ok) break;
         }
     }
@@ -764,12 +764,17 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
         }
     }
 #define AL(f) if ((rc = s->f.alloc(cap)) != GNXR_OK) return rc;
-    AL(ray_o) AL(ray_d) AL(beta) AL(L) AL(sh_o) AL(sh_d) AL(sh_X) AL(mis_o) AL(mis_d) AL(mis_Y) AL(nbeta) AL(meta) AL(hit) AL(queue_a) AL(queue_b) AL(queue_nee) AL(queue_c0) AL(queue_c1) AL(queue_c2) AL(queue_c3) AL(pflags) AL(pclass) AL(nee_vis)
+    const size_t nrec = whitted ? (size_t)std::max(1, n_records) : 1;   // Whitted / DirectLighting keep one NEE record per light sample of a vertex
+    for (int i = 0; i < kRecGroups; ++i) {
+        const size_t per_slot = i < 2 ? 1 : (i < 4 ? nrec : (direct ? nrec : 1));
+        if ((rc = s->rec[i].alloc(cap * per_slot * kRS)) != GNXR_OK) return rc;
+    }
+    if ((rc = s->mis_Y.alloc(cap * (direct ? nrec : 1))) != GNXR_OK) return rc;
+    AL(L) AL(hit) AL(queue_a) AL(queue_b) AL(queue_nee) AL(queue_c0) AL(queue_c1) AL(queue_c2) AL(queue_c3) AL(pflags) AL(pclass) AL(nee_vis)
 #undef AL
     if (whitted) {
         const size_t nl = (size_t)std::max(1, n_records), md = (size_t)std::max(1, p.max_depth);
-        if (direct && ((rc = s->mis_o.alloc(cap * nl)) || (rc = s->mis_d.alloc(cap * nl)) || (rc = s->mis_Y.alloc(cap * nl)))) return rc;
-        if ((rc = s->sh_o.alloc(cap * nl)) || (rc = s->sh_d.alloc(cap * nl)) || (rc = s->sh_X.alloc(cap * nl)) || (rc = s->wh_rec.alloc(cap * nl)) ||
+        if ((rc = s->wh_rec.alloc(cap * nl)) ||
             (rc = s->wh_o.alloc(cap * md)) || (rc = s->wh_d.alloc(cap * md)) || (rc = s->wh_L.alloc(cap * md)) || (rc = s->wh_w.alloc(cap * md)) ||
             (rc = s->wh_pdf.alloc(cap * md)) || (rc = s->vol_vs.alloc(cap)))
             return rc;
@@ -779,8 +784,9 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
     if (volpath) {
 #define AL(f) if ((rc = s->f.alloc(cap)) != GNXR_OK) return rc;
         AL(vol_n1) AL(vol_f) AL(vol_Li) AL(vol_Tr) AL(vol_Ld) AL(vol_mres) AL(vol_vs) AL(vol_state)
-        AL(vol_Lout) AL(vol_alt_meta) AL(vol_alt_state) AL(vol_orig) AL(vol_alt_orig) AL(vol_newslot)
+        AL(vol_Lout) AL(vol_alt_state) AL(vol_orig) AL(vol_alt_orig) AL(vol_newslot)
         for (int i = 0; i < kVolPackF4; ++i) AL(vol_alt[i])
+        for (int i = 0; i < kRecGroups; ++i) if ((rc = s->vol_alt_rec[i].alloc(cap * kRS)) != GNXR_OK) return rc;
 #undef AL
     }
     {   // global part of k_trace's traversal stacks (the deepest walk either BVH layout can need), sized for a full grid
@@ -791,11 +797,16 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
     const int max_tiles = (int)((cap + kCompactTile - 1) / kCompactTile);
     if ((rc = s->tile_counts.alloc((size_t)5 * max_tiles)) != GNXR_OK) return rc;
     PathArrays pa;
-    pa.ray_o = s->ray_o.p; pa.ray_d = s->ray_d.p; pa.beta = s->beta.p; pa.L = s->L.p; pa.meta = s->meta.p; pa.hit = s->hit.p; pa.pflags = s->pflags.p; pa.pclass = s->pclass.p;
-    pa.sh_o = s->sh_o.p; pa.sh_d = s->sh_d.p; pa.sh_X = s->sh_X.p; pa.mis_o = s->mis_o.p; pa.mis_d = s->mis_d.p; pa.mis_Y = s->mis_Y.p; pa.nbeta = s->nbeta.p; pa.nee_vis = s->nee_vis.p;
+    float4 *rec_primary[kRecGroups];
+    gnxr_scene::record_ptrs(s->rec, rec_primary);
+    pa.bind_records(rec_primary);
+    pa.mis_Y = s->mis_Y.p;
+    pa.L = s->L.p; pa.hit = s->hit.p; pa.pflags = s->pflags.p; pa.pclass = s->pclass.p; pa.nee_vis = s->nee_vis.p;
     VolArrays va;
-    va.vs = s->vol_vs.p; va.sv_o = s->sh_o.p; va.sv_d = s->sh_d.p; va.p1 = s->sh_X.p; va.p1e = s->nbeta.p; va.n1 = s->vol_n1.p; va.f = s->vol_f.p;
-    va.Li = s->vol_Li.p; va.Tr = s->vol_Tr.p; va.Ld = s->vol_Ld.p; va.mis_o = s->mis_o.p; va.mis_d = s->mis_d.p; va.mis_Y = s->mis_Y.p; va.mres = s->vol_mres.p; va.state = s->vol_state.p;
+    va.bind_records(rec_primary);
+    va.mis_Y = s->mis_Y.p;
+    va.vs = s->vol_vs.p; va.n1 = s->vol_n1.p; va.f = s->vol_f.p;
+    va.Li = s->vol_Li.p; va.Tr = s->vol_Tr.p; va.Ld = s->vol_Ld.p; va.mres = s->vol_mres.p; va.state = s->vol_state.p;
     va.orig = s->vol_orig.p; va.Lout = s->vol_Lout.p;
     DMediaTables mt = s->media_tables();
     WhittedArrays wa;
@@ -806,7 +817,6 @@ static int render_one(gnxr_scene *s, const gnxr_render_params *pin, void *d_rgba
     wa.start_dim = wmode == WM_DIRECT_ALL ? 5 + 2 * (p.max_depth * nL * 2) : 5;
     if (whitted) {
         sc.materials = s->materials_single.p + 1;
-        pa.sh_o = s->sh_o.p; pa.sh_d = s->sh_d.p; pa.sh_X = s->sh_X.p; pa.mis_o = s->mis_o.p; pa.mis_d = s->mis_d.p; pa.mis_Y = s->mis_Y.p;
     }
 
     if (g_reserve_only) { if (stats) memset(stats, 0, sizeof(*stats)); return GNXR_OK; }
@@ -1041,12 +1051,7 @@ else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, slds, cst[3],
         const int lag = std::max(1, std::min(gnxr_scene::kRing - 2, lag_env >= 0 ? lag_env : 2));
         // a sub-pass lives max_depth + 2 iterations (+ the lag until the host sees that it has ended): spread the starts over that time
         const int stagger = cut_env >= 0 ? cut_env : std::max(1, (p.max_depth + 2 + lag + R - 1) / R);
-        auto pa_at = [&](size_t base) {
-            PathArrays q = pa;
-            q.ray_o += base; q.ray_d += base; q.beta += base; q.L += base; q.meta += base; q.hit += base; q.pflags += base; q.pclass += base;
-            q.sh_o += base; q.sh_d += base; q.sh_X += base; q.mis_o += base; q.mis_d += base; q.mis_Y += base; q.nbeta += base; q.nee_vis += base;
-            return q;
-        };
+        auto pa_at = [&](size_t base) { return pa.at(base); };
         int *qbuf[2] = {s->queue_a.p, s->queue_b.p};
         int in_idx = 0;
         const unsigned *cnt_ptr = &dctr->n_queue;  // where the count of the queue in flight lives on the device (k_loop_tail / k_queue_merge write it)
@@ -1205,21 +1210,21 @@ else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, slds, cst[3],
             auto pack_set = [&](bool alt) {
                 VolPackSet ps;
                 if (!alt) {
-                    float4 *a[kVolPackF4] = {s->ray_o.p, s->ray_d.p, s->beta.p, s->L.p, reinterpret_cast<float4 *>(s->vol_vs.p), s->sh_o.p, s->sh_d.p, s->sh_X.p, s->nbeta.p, s->vol_n1.p, s->vol_f.p,
-                                             s->vol_Li.p, s->vol_Tr.p, s->vol_Ld.p, s->mis_o.p, s->mis_d.p, s->mis_Y.p};
+                    float4 *a[kVolPackF4] = {s->L.p, reinterpret_cast<float4 *>(s->vol_vs.p), s->vol_n1.p, s->vol_f.p, s->vol_Li.p, s->vol_Tr.p, s->vol_Ld.p, s->mis_Y.p};
                     for (int i = 0; i < kVolPackF4; ++i) ps.f4[i] = a[i];
-                    ps.meta = s->meta.p; ps.state = s->vol_state.p; ps.orig = s->vol_orig.p;
+                    gnxr_scene::record_ptrs(s->rec, ps.rec);
+                    ps.state = s->vol_state.p; ps.orig = s->vol_orig.p;
                 } else {
                     for (int i = 0; i < kVolPackF4; ++i) ps.f4[i] = s->vol_alt[i].p;
-                    ps.meta = s->vol_alt_meta.p; ps.state = s->vol_alt_state.p; ps.orig = s->vol_alt_orig.p;
+                    gnxr_scene::record_ptrs(s->vol_alt_rec, ps.rec);
+                    ps.state = s->vol_alt_state.p; ps.orig = s->vol_alt_orig.p;
                 }
                 return ps;
             };
             auto bind_set = [&](const VolPackSet &ps) {   // point the kernels' views at a set
-                pa.ray_o = ps.f4[0]; pa.ray_d = ps.f4[1]; pa.beta = ps.f4[2]; pa.L = ps.f4[3]; va.vs = reinterpret_cast<int4 *>(ps.f4[4]); va.sv_o = ps.f4[5]; va.sv_d = ps.f4[6];
-                va.p1 = ps.f4[7]; va.p1e = ps.f4[8]; va.n1 = ps.f4[9]; va.f = ps.f4[10]; va.Li = ps.f4[11]; va.Tr = ps.f4[12]; va.Ld = ps.f4[13];
-                va.mis_o = ps.f4[14]; va.mis_d = ps.f4[15]; va.mis_Y = ps.f4[16];
-                pa.meta = ps.meta; va.state = ps.state; va.orig = ps.orig;
+                pa.bind_records(ps.rec); va.bind_records(ps.rec);
+                pa.L = ps.f4[0]; va.vs = reinterpret_cast<int4 *>(ps.f4[1]); va.n1 = ps.f4[2]; va.f = ps.f4[3]; va.Li = ps.f4[4]; va.Tr = ps.f4[5]; va.Ld = ps.f4[6]; pa.mis_Y = va.mis_Y = ps.f4[7];
+                va.state = ps.state; va.orig = ps.orig;
             };
             bool in_alt = false;
             long long span = n_paths;     // the live paths lie in slots [0, span)
@@ -1322,7 +1327,7 @@ else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, slds, cst[3],
         stats->passes_in_flight = (uint32_t)in_flight;
         stats->loop_iterations = loop_iterations;
         {   // what this render keeps resident per path slot: the float4 / uint2 / int state arrays, the queues and the per-path bytes
-            const unsigned long long per_slot = 11ull * sizeof(float4) + sizeof(uint2) + 8ull * sizeof(int) + 2 + sizeof(unsigned int);
+            const unsigned long long per_slot = (2ull * kRecGroups + 2) * sizeof(float4) + 8ull * sizeof(int) + 2 + sizeof(unsigned int);   // five record groups + mis_Y + L, hit + seven queues, pflags + pclass, nee_vis
             stats->state_bytes = (unsigned long long)cap * per_slot + (volpath ? (unsigned long long)cap * (6ull * sizeof(float4) + sizeof(int4) + 1) : 0ull);
         }
         stats->seconds_closest = timer.seconds[0]; stats->seconds_nee = timer.seconds[1]; stats->seconds_shade = timer.seconds[2];

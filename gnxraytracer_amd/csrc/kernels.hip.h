@@ -23,24 +23,53 @@ namespace gnxr {
 
 constexpr int kBlock = 256;
 
+// Per-path state lives in 32-byte RECORDS, not in one array per field: late in a pass the live paths are a sparse subset of the slots, every
+// access is then one 16-byte element per lane, and a kernel that needs four fields of a path pays four memory transactions where two
+// records cost two.  Five groups of two float4, by who reads them together, so that nobody drags bytes it does not want through the
+// memory system (k_trace reads exactly the ray, k_nee_combine exactly the weights, k_shade two records where it read four arrays):
+//   0 ray {ray_o, ray_d}   1 throughput {beta, meta}   2 shadow ray {sh_o, sh_d}   3 NEE weights {sh_X, nbeta}   4 MIS ray {mis_o, mis_d}
+// (64-byte records -- groups 0+1 and 2+3 in one -- make k_shade another 4 % faster and k_trace 3 % slower, a net loss:
+// profiles/r03_ab_records.log.)  The pointers below address the first element of their field and element i sits at [i * kRS]
+// (meta: [i * kRSm]).  What is streamed densely (L by k_resolve, hit by the compaction), is a byte (pflags, pclass) or has no partner
+// (mis_Y) stays an array of its own.
+constexpr int kRS = 2;          // float4 stride of the record fields
+constexpr int kRSm = 2 * kRS;   // the same stride in uint2 units (meta)
+constexpr int kRecGroups = 5;
 struct PathArrays {
-    float4 *ray_o;    // origin.xyz, tMax
-    float4 *ray_d;    // direction.xyz, medium (int bits)
-    float4 *beta;     // beta.rgb, etaScale
+    float4 *ray_o;    // [0] origin.xyz, tMax
+    float4 *ray_d;    // [0] direction.xyz, medium (int bits)
+    float4 *beta;     // [1] beta.rgb, etaScale
+    uint2 *meta;      // [1] x: Halton sample index, y: dim | bounces << 16 | specularBounce << 31   (8 of 16 bytes)
     float4 *L;        // L.rgb
-    uint2 *meta;      // x: Halton sample index, y: dim | bounces << 16 | specularBounce << 31
     int *hit;         // leaf-order triangle of the closest hit, -1 == miss
     unsigned char *pflags;  // written by k_shade: bit0 continues, bit1 NEE record, bit2 shadow ray, bit3 MIS ray
     unsigned char *pclass;  // written by k_trace: shade-kernel class of the hit material (DMaterial::shade_class)
     // next-event-estimation records written by k_shade, consumed by k_nee
-    float4 *sh_o;     // shadow ray origin, tMax
-    float4 *sh_d;     // shadow ray direction, flags (bit0 shadow ray valid, bit1 MIS ray valid)
-    float4 *sh_X;     // f*Li*w/lightPdf, w: light-selection pdf
-    float4 *mis_o;    // MIS ray origin, w: expected leaf triangle (int bits; -1 == expects a miss)
-    float4 *mis_d;    // MIS ray direction
-    float4 *mis_Y;    // f*Li*w/scatteringPdf if the expectation holds
-    float4 *nbeta;    // beta at the vertex
+    float4 *sh_o;     // [2] shadow ray origin, tMax
+    float4 *sh_d;     // [2] shadow ray direction, flags (bit0 shadow ray valid, bit1 MIS ray valid)
+    float4 *sh_X;     // [3] f*Li*w/lightPdf, w: light-selection pdf
+    float4 *nbeta;    // [3] beta at the vertex
+    float4 *mis_o;    // [4] MIS ray origin, w: expected leaf triangle (int bits; -1 == expects a miss)
+    float4 *mis_d;    // [4] MIS ray direction
+    float4 *mis_Y;    // f*Li*w/scatteringPdf if the expectation holds (plain array)
     unsigned int *nee_vis;   // PathIntegrator: per path [0] shadow ray unoccluded, [1] MIS ray found what it expects (bytes written by k_trace), [2] record flags (k_shade)
+    // bind the record fields to the five groups
+    __host__ __device__ void bind_records(float4 *const g[kRecGroups]) {
+        ray_o = g[0]; ray_d = g[0] + 1; beta = g[1]; meta = reinterpret_cast<uint2 *>(g[1] + 1);
+        sh_o = g[2]; sh_d = g[2] + 1; sh_X = g[3]; nbeta = g[3] + 1;
+        mis_o = g[4]; mis_d = g[4] + 1;
+    }
+    // meta is stored with its 8 bytes of padding, so that a record is always written whole (no partial-sector write)
+    __device__ void store_meta(size_t i, uint32_t x, uint32_t y) const { *reinterpret_cast<uint4 *>(&meta[i * kRSm]) = make_uint4(x, y, 0u, 0u); }
+    // the same arrays seen from slot `base` on (a region of the state arrays)
+    __host__ __device__ PathArrays at(size_t base) const {
+        PathArrays q = *this;
+        q.ray_o += base * kRS; q.ray_d += base * kRS; q.beta += base * kRS; q.meta += base * kRSm;
+        q.sh_o += base * kRS; q.sh_d += base * kRS; q.sh_X += base * kRS; q.nbeta += base * kRS;
+        q.mis_o += base * kRS; q.mis_d += base * kRS;
+        q.mis_Y += base; q.L += base; q.hit += base; q.pflags += base; q.pclass += base; q.nee_vis += base;
+        return q;
+    }
 };
 
 constexpr int kMaxRegions = 8;   // sub-passes in flight at most (each in its own region of the state arrays)
@@ -232,11 +261,11 @@ static __global__ void __launch_bounds__(kBlock) k_raygen(DScene sc, DRender r, 
         float tMax;
         int dim;
         camera_ray(r.cam, sc.st, px, py, index, &o, &d, &tMax, &dim);
-        pa.ray_o[slot] = make_float4(o.x, o.y, o.z, tMax);
-        pa.ray_d[slot] = make_float4(d.x, d.y, d.z, __int_as_float(r.cam.medium));
-        pa.beta[slot] = make_float4(1.f, 1.f, 1.f, 1.f);
+        pa.ray_o[(size_t)slot * kRS] = make_float4(o.x, o.y, o.z, tMax);
+        pa.ray_d[(size_t)slot * kRS] = make_float4(d.x, d.y, d.z, __int_as_float(r.cam.medium));
+        pa.beta[(size_t)slot * kRS] = make_float4(1.f, 1.f, 1.f, 1.f);
         pa.L[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
-        pa.meta[slot] = make_uint2(index, (uint32_t)dim);
+        pa.store_meta(slot, index, (uint32_t)dim);
     }
 }
 
@@ -300,12 +329,12 @@ GX_DEV int estimate_direct_record(const DScene &sc, const Bsdf<LM> &bsdf, const 
         }
     }
     if (nflags) {
-        pa.sh_o[rec] = make_float4(so.x, so.y, so.z, 1 - GX_SHADOW_EPS);
-        pa.sh_d[rec] = make_float4(sd.x, sd.y, sd.z, __int_as_float(nflags));
-        pa.sh_X[rec] = make_float4(X.r, X.g, X.b, xw);
+        pa.sh_o[(size_t)rec * kRS] = make_float4(so.x, so.y, so.z, 1 - GX_SHADOW_EPS);
+        pa.sh_d[(size_t)rec * kRS] = make_float4(sd.x, sd.y, sd.z, __int_as_float(nflags));
+        pa.sh_X[(size_t)rec * kRS] = make_float4(X.r, X.g, X.b, xw);
         if (nflags & 2) {
-            pa.mis_o[rec] = make_float4(mo.x, mo.y, mo.z, __int_as_float(expect));
-            pa.mis_d[rec] = make_float4(wi2.x, wi2.y, wi2.z, 0.f);
+            pa.mis_o[(size_t)rec * kRS] = make_float4(mo.x, mo.y, mo.z, __int_as_float(expect));
+            pa.mis_d[(size_t)rec * kRS] = make_float4(wi2.x, wi2.y, wi2.z, 0.f);
             pa.mis_Y[rec] = make_float4(Y.r, Y.g, Y.b, 0.f);
         }
     }
@@ -314,14 +343,14 @@ GX_DEV int estimate_direct_record(const DScene &sc, const Bsdf<LM> &bsdf, const 
 // Ld of one NEE record once both visibility rays are traced: `Ld += f * Li * weight / lightPdf` (:160) if unoccluded, then
 // `Ld += f * Li * Tr * weight / scatteringPdf` (:204) if the MIS ray found the light
 GX_DEV Spec nee_record_Ld(const PathArrays &pa, size_t rec, float *xw) {
-    float4 sd4 = pa.sh_d[rec], X4 = pa.sh_X[rec];
+    float4 sd4 = pa.sh_d[(size_t)rec * kRS], X4 = pa.sh_X[(size_t)rec * kRS];
     int flags = __float_as_int(sd4.w);
     Spec Ld(0.f);
-    if ((flags & 1) && pa.sh_o[rec].w == 1.f) Ld = Ld + Spec(X4.x, X4.y, X4.z);
+    if ((flags & 1) && pa.sh_o[(size_t)rec * kRS].w == 1.f) Ld = Ld + Spec(X4.x, X4.y, X4.z);
     if (flags & 2) {
         float4 Y4 = pa.mis_Y[rec];
         Spec Y(Y4.x, Y4.y, Y4.z);
-        if (pa.mis_o[rec].w == 1.f && !Y.is_black()) Ld = Ld + Y;
+        if (pa.mis_o[(size_t)rec * kRS].w == 1.f && !Y.is_black()) Ld = Ld + Y;
     }
     *xw = X4.w;
     return Ld;
@@ -411,11 +440,11 @@ __global__ void __launch_bounds__(kBlock, shade_min_waves<LM>()) k_shade(DScene 
         const int pathNext2_ = (long long)i + 2ll * stride_ < n ? queue[i + 2 * stride_] : -1;
         {
             path = pathCur_;
-            uint2 m = pa.meta[path];
+            uint2 m = pa.meta[(size_t)path * kRSm];
             uint32_t index = m.x;
             int dim = (int)(m.y & 0xffffu), bounces = (int)((m.y >> 16) & 0xffu);
             bool specularBounce = (m.y >> 31) != 0;
-            float4 o4 = pa.ray_o[path], d4 = pa.ray_d[path], b4 = pa.beta[path];
+            float4 o4 = pa.ray_o[(size_t)path * kRS], d4 = pa.ray_d[(size_t)path * kRS], b4 = pa.beta[(size_t)path * kRS];
             V3 ro(o4.x, o4.y, o4.z), rd(d4.x, d4.y, d4.z);
             Spec beta(b4.x, b4.y, b4.z);
             float etaScale = b4.w;
@@ -463,7 +492,7 @@ __global__ void __launch_bounds__(kBlock, shade_min_waves<LM>()) k_shade(DScene 
                 if (triMat < 0) {
                     // null material: skip the boundary, PathIntegrator.cpp:121-126 (bounces-- ; continue)
                     V3 o2 = offset_ray_origin(sp.p, sp.pError, sp.n, rd);
-                    pa.ray_o[path] = make_float4(o2.x, o2.y, o2.z, GX_INF);
+                    pa.ray_o[(size_t)path * kRS] = make_float4(o2.x, o2.y, o2.z, GX_INF);
                     survive = true;
                 } else {
                     const DMaterial *mat = mats + triMat;
@@ -550,15 +579,15 @@ __global__ void __launch_bounds__(kBlock, shade_min_waves<LM>()) k_shade(DScene 
                             }
                             GX_STICK(7);   // light_pdf + MIS record
                             if (nflags) {
-                                pa.sh_o[path] = make_float4(so.x, so.y, so.z, 1 - GX_SHADOW_EPS);
-                                pa.sh_d[path] = make_float4(sd.x, sd.y, sd.z, __int_as_float(nflags));
-                                pa.sh_X[path] = make_float4(X.r, X.g, X.b, lightPdfSel);
+                                pa.sh_o[(size_t)path * kRS] = make_float4(so.x, so.y, so.z, 1 - GX_SHADOW_EPS);
+                                pa.sh_d[(size_t)path * kRS] = make_float4(sd.x, sd.y, sd.z, __int_as_float(nflags));
+                                pa.sh_X[(size_t)path * kRS] = make_float4(X.r, X.g, X.b, lightPdfSel);
                                 if (nflags & 2) {
-                                    pa.mis_o[path] = make_float4(mo.x, mo.y, mo.z, __int_as_float(expect));
-                                    pa.mis_d[path] = make_float4(wi2.x, wi2.y, wi2.z, 0.f);
+                                    pa.mis_o[(size_t)path * kRS] = make_float4(mo.x, mo.y, mo.z, __int_as_float(expect));
+                                    pa.mis_d[(size_t)path * kRS] = make_float4(wi2.x, wi2.y, wi2.z, 0.f);
                                     pa.mis_Y[path] = make_float4(Y.r, Y.g, Y.b, 0.f);
                                 }
-                                pa.nbeta[path] = make_float4(beta.r, beta.g, beta.b, 0.f);
+                                pa.nbeta[(size_t)path * kRS] = make_float4(beta.r, beta.g, beta.b, 0.f);
                                 // byte 2: the record's flags; bit 7 of it: beta is not finite (k_nee_combine may then not skip a vertex whose rays both failed:
                                 // the reference's L += beta * 0 would poison the pixel, and so must this)
                                 const bool betaFinite = __builtin_isfinite(beta.r) && __builtin_isfinite(beta.g) && __builtin_isfinite(beta.b);
@@ -593,10 +622,10 @@ __global__ void __launch_bounds__(kBlock, shade_min_waves<LM>()) k_shade(DScene 
                             else beta = beta / (1 - q);
                         }
                         if (survive) {
-                            pa.ray_o[path] = make_float4(o2.x, o2.y, o2.z, GX_INF);
-                            pa.ray_d[path] = make_float4(wi.x, wi.y, wi.z, d4.w);
-                            pa.beta[path] = make_float4(beta.r, beta.g, beta.b, etaScale);
-                            pa.meta[path] = make_uint2(index, (uint32_t)ss.dim | ((uint32_t)(bounces + 1) << 16) | (specularBounce ? 0x80000000u : 0u));
+                            pa.ray_o[(size_t)path * kRS] = make_float4(o2.x, o2.y, o2.z, GX_INF);
+                            pa.ray_d[(size_t)path * kRS] = make_float4(wi.x, wi.y, wi.z, d4.w);
+                            pa.beta[(size_t)path * kRS] = make_float4(beta.r, beta.g, beta.b, etaScale);
+                            pa.store_meta(path, index, (uint32_t)ss.dim | ((uint32_t)(bounces + 1) << 16) | (specularBounce ? 0x80000000u : 0u));
                         }
                     }
                 }
@@ -620,11 +649,11 @@ __global__ void __launch_bounds__(kBlock) k_shade_escape(DScene sc, PathArrays p
     const int n = (int)*n_dev;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int path = queue[i];
-        const uint2 m = pa.meta[path];
+        const uint2 m = pa.meta[(size_t)path * kRSm];
         const int bounces = (int)((m.y >> 16) & 0xffu);
         const bool specularBounce = (m.y >> 31) != 0;
         if (bounces == 0 || specularBounce) {
-            const float4 o4 = pa.ray_o[path], d4 = pa.ray_d[path], b4 = pa.beta[path], L4 = pa.L[path];
+            const float4 o4 = pa.ray_o[(size_t)path * kRS], d4 = pa.ray_d[(size_t)path * kRS], b4 = pa.beta[(size_t)path * kRS], L4 = pa.L[path];
             const V3 ro(o4.x, o4.y, o4.z), rd(d4.x, d4.y, d4.z);
             const Spec beta(b4.x, b4.y, b4.z);
             Spec L(L4.x, L4.y, L4.z);

@@ -158,12 +158,12 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
         }
         else if (kind == 1) {
             if (w.vis) w.vis[4 * (size_t)path] = hitLeaf == -1 ? 1 : 0;
-            else reinterpret_cast<float *>(&pa.sh_o[path])[3] = hitLeaf == -1 ? 1.f : 0.f;
+            else reinterpret_cast<float *>(&pa.sh_o[(size_t)path * kRS])[3] = hitLeaf == -1 ? 1.f : 0.f;
         } else {
-            const int expect = __float_as_int(pa.mis_o[path].w);   // the leaf triangle the light sample expects (-1: nothing), written by k_shade
+            const int expect = __float_as_int(pa.mis_o[(size_t)path * kRS].w);   // the leaf triangle the light sample expects (-1: nothing), written by k_shade
             bool ok = (expect >= 0) ? (hitLeaf == expect) : (hitLeaf == -1);
             if (w.vis) w.vis[4 * (size_t)path + 1] = ok ? 1 : 0;
-            else reinterpret_cast<float *>(&pa.mis_o[path])[3] = ok ? 1.f : 0.f;
+            else reinterpret_cast<float *>(&pa.mis_o[(size_t)path * kRS])[3] = ok ? 1.f : 0.f;
         }
         live = false;
     };
@@ -207,7 +207,7 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
                         valid = true;
                         if (i < (unsigned)w.n_closest) {
                             path_ = w.q_closest ? w.q_closest[i] : (int)i;
-                            o4 = pa.ray_o[path_]; d4 = pa.ray_d[path_];
+                            o4 = pa.ray_o[(size_t)path_ * kRS]; d4 = pa.ray_d[(size_t)path_ * kRS];
                             tMax_ = o4.w;
                         } else {
                             // NEE work items: first all shadow rays, then all MIS rays
@@ -220,13 +220,13 @@ __global__ void GX_T4_BOUNDS k_trace4(DScene sc, PathArrays pa, TraceWork w, uns
                             const bool together = w.vis != nullptr;
                             if (isShadow) {
                                 kind_ = 1; any_ = 1;
-                                o4 = pa.sh_o[path_]; d4 = pa.sh_d[path_]; tMax_ = o4.w;
+                                o4 = pa.sh_o[(size_t)path_ * kRS]; d4 = pa.sh_d[(size_t)path_ * kRS]; tMax_ = o4.w;
                                 valid = (__float_as_int(d4.w) & 1) != 0;     // else: this vertex spawned no shadow ray
                             } else {
                                 kind_ = 2;
-                                const int nflags = __float_as_int(pa.sh_d[path_].w);
+                                const int nflags = __float_as_int(pa.sh_d[(size_t)path_ * kRS].w);
                                 valid = (nflags & 2) != 0;
-                                if (together || valid) { o4 = pa.mis_o[path_]; d4 = pa.mis_d[path_]; }
+                                if (together || valid) { o4 = pa.mis_o[(size_t)path_ * kRS]; d4 = pa.mis_d[(size_t)path_ * kRS]; }
                                 else { o4 = make_float4(0, 0, 0, 0); d4 = o4; }
                                 tMax_ = GX_INF;
                                 // a MIS ray that expects to escape (an infinite light was sampled) asks "is there any hit at all": with tMax = inf

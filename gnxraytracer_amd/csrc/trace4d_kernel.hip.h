@@ -122,12 +122,12 @@ __global__ void __launch_bounds__(kBlock, GX_T4D_WAVES) k_trace4d(DScene sc, Pat
             }
         } else if (kind == 1) {
             if (w.vis) w.vis[4 * (size_t)path] = hitLeaf == -1 ? 1 : 0;
-            else reinterpret_cast<float *>(&pa.sh_o[path])[3] = hitLeaf == -1 ? 1.f : 0.f;
+            else reinterpret_cast<float *>(&pa.sh_o[(size_t)path * kRS])[3] = hitLeaf == -1 ? 1.f : 0.f;
         } else {
-            const int expect = __float_as_int(pa.mis_o[path].w);
+            const int expect = __float_as_int(pa.mis_o[(size_t)path * kRS].w);
             const bool ok = (expect >= 0) ? (hitLeaf == expect) : (hitLeaf == -1);
             if (w.vis) w.vis[4 * (size_t)path + 1] = ok ? 1 : 0;
-            else reinterpret_cast<float *>(&pa.mis_o[path])[3] = ok ? 1.f : 0.f;
+            else reinterpret_cast<float *>(&pa.mis_o[(size_t)path * kRS])[3] = ok ? 1.f : 0.f;
         }
         r.path = -1;
     };
@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(kBlock, GX_T4D_WAVES) k_trace4d(DScene sc, Pat
                         valid = true;
                         if (i < (unsigned)w.n_closest) {
                             path_ = w.q_closest ? w.q_closest[i] : (int)i;
-                            o4 = pa.ray_o[path_]; d4 = pa.ray_d[path_];
+                            o4 = pa.ray_o[(size_t)path_ * kRS]; d4 = pa.ray_d[(size_t)path_ * kRS];
                             tMax_ = o4.w;
                         } else {
                             const unsigned e = i - (unsigned)w.n_closest;
@@ -172,13 +172,13 @@ __global__ void __launch_bounds__(kBlock, GX_T4D_WAVES) k_trace4d(DScene sc, Pat
                             const bool together = w.vis != nullptr;
                             if (isShadow) {
                                 kind_ = 1; any_ = 1;
-                                o4 = pa.sh_o[path_]; d4 = pa.sh_d[path_]; tMax_ = o4.w;
+                                o4 = pa.sh_o[(size_t)path_ * kRS]; d4 = pa.sh_d[(size_t)path_ * kRS]; tMax_ = o4.w;
                                 valid = (__float_as_int(d4.w) & 1) != 0;
                             } else {
                                 kind_ = 2;
-                                const int nflags = __float_as_int(pa.sh_d[path_].w);
+                                const int nflags = __float_as_int(pa.sh_d[(size_t)path_ * kRS].w);
                                 valid = (nflags & 2) != 0;
-                                if (together || valid) { o4 = pa.mis_o[path_]; d4 = pa.mis_d[path_]; }
+                                if (together || valid) { o4 = pa.mis_o[(size_t)path_ * kRS]; d4 = pa.mis_d[(size_t)path_ * kRS]; }
                                 else { o4 = make_float4(0, 0, 0, 0); d4 = o4; }
                                 tMax_ = GX_INF;
                                 any_ = __float_as_int(o4.w) < 0 ? 1 : 0;

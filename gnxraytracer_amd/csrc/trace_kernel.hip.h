@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
                     if (i < (unsigned)w.n_closest) {
                         kind = 0;
                         path = w.q_closest ? w.q_closest[i] : (int)i;
-                        o4 = pa.ray_o[path]; d4 = pa.ray_d[path];
+                        o4 = pa.ray_o[(size_t)path * kRS]; d4 = pa.ray_d[(size_t)path * kRS];
                         tMax = o4.w;
                     } else {
                         // NEE work items: first all shadow rays, then all MIS rays (a wave then holds rays of one kind that
@@ -255,14 +255,14 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
                         unsigned e = i - (unsigned)w.n_closest;
                         const bool isShadow = GX_NEE_INTERLEAVED ? (e & 1u) == 0 : e < (unsigned)w.n_nee;
                         path = w.q_nee[GX_NEE_INTERLEAVED ? (e >> 1) : (isShadow ? e : e - (unsigned)w.n_nee)];
-                        int nflags = __float_as_int(pa.sh_d[path].w);
+                        int nflags = __float_as_int(pa.sh_d[(size_t)path * kRS].w);
                         if (isShadow) {
                             kind = 1;
-                            if (nflags & 1) { o4 = pa.sh_o[path]; d4 = pa.sh_d[path]; tMax = o4.w; }
+                            if (nflags & 1) { o4 = pa.sh_o[(size_t)path * kRS]; d4 = pa.sh_d[(size_t)path * kRS]; tMax = o4.w; }
                             else item = -1;     // this vertex spawned no shadow ray
                         } else {
                             kind = 2;
-                            if (nflags & 2) { o4 = pa.mis_o[path]; d4 = pa.mis_d[path]; expect = __float_as_int(o4.w); tMax = GX_INF; }
+                            if (nflags & 2) { o4 = pa.mis_o[(size_t)path * kRS]; d4 = pa.mis_d[(size_t)path * kRS]; expect = __float_as_int(o4.w); tMax = GX_INF; }
                             else item = -1;
                         }
                     }
@@ -400,11 +400,11 @@ __global__ void __launch_bounds__(kBlock) k_trace(DScene sc, PathArrays pa, Trac
             }
             else if (kind == 1) {
                 if (w.vis) w.vis[4 * (size_t)path] = hitLeaf == -1 ? 1 : 0;
-                else reinterpret_cast<float *>(&pa.sh_o[path])[3] = hitLeaf == -1 ? 1.f : 0.f;
+                else reinterpret_cast<float *>(&pa.sh_o[(size_t)path * kRS])[3] = hitLeaf == -1 ? 1.f : 0.f;
             } else {
                 bool ok = (expect >= 0) ? (hitLeaf == expect) : (hitLeaf == -1);
                 if (w.vis) w.vis[4 * (size_t)path + 1] = ok ? 1 : 0;
-                else reinterpret_cast<float *>(&pa.mis_o[path])[3] = ok ? 1.f : 0.f;
+                else reinterpret_cast<float *>(&pa.mis_o[(size_t)path * kRS])[3] = ok ? 1.f : 0.f;
             }
             item = -1;
         }
@@ -433,7 +433,7 @@ static __global__ void __launch_bounds__(kBlock) k_nee_combine(PathArrays pa, co
         // for bit when beta is finite (k_shade says so in bit 7 of the flags; pdf > 0) -- a third to a half of the vertices; their three
         // records and L are not touched
         if (!(flags & 0x80) && !(((flags & 1) && (v & 0xffu)) || ((flags & 2) && ((v >> 8) & 0xffu)))) continue;
-        float4 X4 = pa.sh_X[path];
+        float4 X4 = pa.sh_X[(size_t)path * kRS];
         Spec Ld(0.f);
         if ((flags & 1) && (v & 0xffu)) Ld = Ld + Spec(X4.x, X4.y, X4.z);
         if ((flags & 2) && ((v >> 8) & 0xffu)) {
@@ -441,7 +441,7 @@ static __global__ void __launch_bounds__(kBlock) k_nee_combine(PathArrays pa, co
             Spec Y(Y4.x, Y4.y, Y4.z);
             if (!Y.is_black()) Ld = Ld + Y;
         }
-        float4 nb = pa.nbeta[path], L4 = pa.L[path];
+        float4 nb = pa.nbeta[(size_t)path * kRS], L4 = pa.L[path];
         Spec add = Spec(nb.x, nb.y, nb.z) * (Ld / X4.w);
         pa.L[path] = make_float4(L4.x + add.r, L4.y + add.g, L4.z + add.b, 0.f);
     }

@@ -48,15 +48,17 @@ struct VolArrays {
     float4 *mres;    // k_vol_media result for the ray in flight: Medium::Sample weight / Medium::Tr (rgb), w: t of the sampled interaction or -1
     int *orig;       // the slot (sample j * npix + pixel) a path started in: packing (k_vol_pack) moves the live paths to the front of the state arrays
     float4 *Lout;    // final radiance of a path, written once when it ends, at its ORIGINAL slot: what k_resolve sums in sample order
+    // sv_o sv_d | p1 p1e | mis_o mis_d are the fields of the slot's record groups 2 - 4 (PathArrays, kernels.hip.h): element i at [i * kRS]
+    __host__ __device__ void bind_records(float4 *const g[kRecGroups]) { sv_o = g[2]; sv_d = g[2] + 1; p1 = g[3]; p1e = g[3] + 1; mis_o = g[4]; mis_d = g[4] + 1; }
 };
 
 static __global__ void __launch_bounds__(kBlock) k_vol_init(PathArrays pa, VolArrays va, int n_paths) {
     for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_paths; slot += gridDim.x * blockDim.x) {
-        uint2 m = pa.meta[slot];
+        uint2 m = pa.meta[(size_t)slot * kRSm];
         va.vs[slot] = make_int4(VS_MAIN, (int)m.y, -1, 1);
         va.state[slot] = (unsigned char)VS_MAIN;
         va.orig[slot] = slot;
-        pa.meta[slot] = make_uint2(m.x, 0u);   // y: bounces << 16 | specularBounce << 31
+        pa.store_meta(slot, m.x, 0u);   // y: bounces << 16 | specularBounce << 31
     }
 }
 
@@ -134,7 +136,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt
                     if ((unsigned)lane < take) {
                         const int p = queue ? queue[poolBase + lane] : (int)(poolBase + lane);
                         int4 vs = va.vs[p];
-                        float4 o4 = pa.ray_o[p], d4 = pa.ray_d[p];
+                        float4 o4 = pa.ray_o[(size_t)p * kRS], d4 = pa.ray_d[(size_t)p * kRS];
                         V3 ro(o4.x, o4.y, o4.z), rd(d4.x, d4.y, d4.z);
                         const int med = __float_as_int(d4.w);
                         const int leaf = pa.hit[p];
@@ -156,7 +158,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt
                         if (!skip) {
                             const float tSeg = found ? h.t : o4.w;
                             const DMedium &m = mt.media[med];
-                            SampleStream ss(sc.st, pa.meta[p].x, vs.y);
+                            SampleStream ss(sc.st, pa.meta[(size_t)p * kRSm].x, vs.y);
                             if (m.type == GNXR_MEDIUM_HOMOGENEOUS) {
                                 float4 res;
                                 if (vs.x == VS_MAIN) {
@@ -319,12 +321,12 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_vol_step(DScene sc, DM
         const int path = queue[i];
         int4 vs = va.vs[path];
         vs.x = ST;   // == the stored state
-        uint2 meta = pa.meta[path];
+        uint2 meta = pa.meta[(size_t)path * kRSm];
         const uint32_t index = meta.x;
         int bounces = (int)((meta.y >> 16) & 0xffu);
         bool specularBounce = (meta.y >> 31) != 0;
         SampleStream ss(sc.st, index, vs.y);
-        float4 o4 = pa.ray_o[path], d4 = pa.ray_d[path];
+        float4 o4 = pa.ray_o[(size_t)path * kRS], d4 = pa.ray_d[(size_t)path * kRS];
         V3 ro(o4.x, o4.y, o4.z), rd(d4.x, d4.y, d4.z);
         int rayMedium = __float_as_int(d4.w);
         const int leaf = pa.hit[path];
@@ -377,20 +379,20 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_vol_step(DScene sc, DM
                         segDone = true;
                         float4 Li4 = va.Li[path];
                         Spec Li = Spec(Li4.x, Li4.y, Li4.z) * Tr;
-                        if (!Li.is_black()) Ld = Ld + Spec(f4.x, f4.y, f4.z) * Li * va.n1[path].w / va.p1e[path].w;
+                        if (!Li.is_black()) Ld = Ld + Spec(f4.x, f4.y, f4.z) * Li * va.n1[path].w / va.p1e[(size_t)path * kRS].w;
                     } else {           // ray = isect.SpawnRayTo(p1)
-                        float4 q1 = va.p1[path], q1e = va.p1e[path], qn1 = va.n1[path];
+                        float4 q1 = va.p1[(size_t)path * kRS], q1e = va.p1e[(size_t)path * kRS], qn1 = va.n1[path];
                         V3 so, sd;
                         spawn_ray_to(sp.p, sp.pError, sp.n, V3(q1.x, q1.y, q1.z), V3(q1e.x, q1e.y, q1e.z), V3(qn1.x, qn1.y, qn1.z), &so, &sd);
                         segMedium = hit_medium(sc, mt, leaf, rayMedium, sp.n, sd);
-                        pa.ray_o[path] = make_float4(so.x, so.y, so.z, 1 - GX_SHADOW_EPS);
-                        pa.ray_d[path] = make_float4(sd.x, sd.y, sd.z, __int_as_float(segMedium));
+                        pa.ray_o[(size_t)path * kRS] = make_float4(so.x, so.y, so.z, 1 - GX_SHADOW_EPS);
+                        pa.ray_d[(size_t)path * kRS] = make_float4(sd.x, sd.y, sd.z, __int_as_float(segMedium));
                     }
                 }
                 if (segDone && (nflags & 2)) {   // go on with the scattering ray: it.SpawnRay(wi), Integrator.cpp:193
-                    float4 mo = va.mis_o[path], md = va.mis_d[path];
-                    pa.ray_o[path] = make_float4(mo.x, mo.y, mo.z, GX_INF);
-                    pa.ray_d[path] = make_float4(md.x, md.y, md.z, mo.w);
+                    float4 mo = va.mis_o[(size_t)path * kRS], md = va.mis_d[(size_t)path * kRS];
+                    pa.ray_o[(size_t)path * kRS] = make_float4(mo.x, mo.y, mo.z, GX_INF);
+                    pa.ray_d[(size_t)path * kRS] = make_float4(md.x, md.y, md.z, mo.w);
                     segMedium = __float_as_int(mo.w);
                     Tr = Spec(1.f);
                     vs.x = VS_MIS;
@@ -401,15 +403,15 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_vol_step(DScene sc, DM
                 if (found && triMat < 0) {   // ray = isect->SpawnRay(ray.d)
                     V3 o2 = offset_ray_origin(sp.p, sp.pError, sp.n, rd);
                     segMedium = hit_medium(sc, mt, leaf, rayMedium, sp.n, rd);
-                    pa.ray_o[path] = make_float4(o2.x, o2.y, o2.z, GX_INF);
-                    pa.ray_d[path] = make_float4(rd.x, rd.y, rd.z, __int_as_float(segMedium));
+                    pa.ray_o[(size_t)path * kRS] = make_float4(o2.x, o2.y, o2.z, GX_INF);
+                    pa.ray_d[(size_t)path * kRS] = make_float4(rd.x, rd.y, rd.z, __int_as_float(segMedium));
                 } else {
                     segDone = true;
                     const int expect = __float_as_int(va.Li[path].w);
                     bool ok = found ? (leaf == expect) : (expect < 0);
                     if (ok && (nflags & 4)) {
                         float4 Y4 = va.mis_Y[path];
-                        Ld = Ld + Spec(Y4.x, Y4.y, Y4.z) * Tr * Ld4.w / va.mis_d[path].w;
+                        Ld = Ld + Spec(Y4.x, Y4.y, Y4.z) * Tr * Ld4.w / va.mis_d[(size_t)path * kRS].w;
                     }
                 }
             }
@@ -422,18 +424,18 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_vol_step(DScene sc, DM
                 continue;
             }
             // light estimate complete: L += beta * (Ld / lightPdf), Integrator.cpp:78 + VolPathIntegrator.cpp:55/99
-            float4 b4 = pa.beta[path], L4 = pa.L[path];
+            float4 b4 = pa.beta[(size_t)path * kRS], L4 = pa.L[path];
             beta = Spec(b4.x, b4.y, b4.z); etaScale = b4.w;
-            L = Spec(L4.x, L4.y, L4.z) + beta * (Ld / va.p1[path].w);
+            L = Spec(L4.x, L4.y, L4.z) + beta * (Ld / va.p1[(size_t)path * kRS].w);
             vertexDone = true;
             // re-establish the vertex from its saved main ray
-            o4 = va.sv_o[path]; d4 = va.sv_d[path];
+            o4 = va.sv_o[(size_t)path * kRS]; d4 = va.sv_d[(size_t)path * kRS];
             ro = V3(o4.x, o4.y, o4.z); rd = V3(d4.x, d4.y, d4.z);
             rayMedium = __float_as_int(d4.w);
             miT = T4.w;
         } else {
             // ---------------- phase 2: the main ray, VolPathIntegrator.cpp:36-80 ----------------
-            float4 b4 = pa.beta[path], L4 = pa.L[path];
+            float4 b4 = pa.beta[(size_t)path * kRS], L4 = pa.L[path];
             beta = Spec(b4.x, b4.y, b4.z); etaScale = b4.w;
             L = Spec(L4.x, L4.y, L4.z);
             SurfacePoint sp0;
@@ -464,9 +466,9 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_vol_step(DScene sc, DM
                     // no BSDF: ray = isect.SpawnRay(ray.d); bounces--; continue  (VolPathIntegrator.cpp:88-92)
                     V3 o2 = offset_ray_origin(sp0.p, sp0.pError, sp0.n, rd);
                     const int nm = hit_medium(sc, mt, leaf, rayMedium, sp0.n, rd);
-                    pa.ray_o[path] = make_float4(o2.x, o2.y, o2.z, GX_INF);
-                    pa.ray_d[path] = make_float4(rd.x, rd.y, rd.z, __int_as_float(nm));
-                    pa.beta[path] = make_float4(beta.r, beta.g, beta.b, etaScale);
+                    pa.ray_o[(size_t)path * kRS] = make_float4(o2.x, o2.y, o2.z, GX_INF);
+                    pa.ray_d[(size_t)path * kRS] = make_float4(rd.x, rd.y, rd.z, __int_as_float(nm));
+                    pa.beta[(size_t)path * kRS] = make_float4(beta.r, beta.g, beta.b, etaScale);
                     pa.L[path] = make_float4(L.r, L.g, L.b, 0.f);
                     vs.y = ss.dim;
                     vs.w = 0;   // isect.SpawnRay(ray.d): a plain Ray
@@ -521,7 +523,7 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_vol_step(DScene sc, DM
                     if (vs.w & 1) {
                         int px, py;
                         local_pixel(r, va.orig[path] % r.npix, &px, &py);
-                        rdf = camera_ray_diff(r.cam, sc.st, px, py, pa.meta[path].x, r.spp);
+                        rdf = camera_ray_diff(r.cam, sc.st, px, py, pa.meta[(size_t)path * kRSm].x, r.spp);
                     }
                     textured_material(tex_tables(sc.materials), *mat, tu, tv, compute_differentials(rdf, sp.p, sp.n, dpdu, dpdv), &tm);
                     mat = &tm;
@@ -605,33 +607,33 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_vol_step(DScene sc, DM
                     }
                 }
                 if (nflags & 3) {
-                    va.sv_o[path] = o4;
-                    va.sv_d[path] = d4;
-                    va.p1[path] = make_float4(ls.p1.x, ls.p1.y, ls.p1.z, lightPdfSel);
-                    va.p1e[path] = make_float4(ls.p1Error.x, ls.p1Error.y, ls.p1Error.z, ls.pdf);
+                    va.sv_o[(size_t)path * kRS] = o4;
+                    va.sv_d[(size_t)path * kRS] = d4;
+                    va.p1[(size_t)path * kRS] = make_float4(ls.p1.x, ls.p1.y, ls.p1.z, lightPdfSel);
+                    va.p1e[(size_t)path * kRS] = make_float4(ls.p1Error.x, ls.p1Error.y, ls.p1Error.z, ls.pdf);
                     va.n1[path] = make_float4(ls.n1.x, ls.n1.y, ls.n1.z, weightX);
                     va.f[path] = make_float4(fX.r, fX.g, fX.b, __int_as_float(nflags));
                     va.Li[path] = make_float4(ls.Li.r, ls.Li.g, ls.Li.b, __int_as_float(expect));
                     va.Tr[path] = make_float4(1.f, 1.f, 1.f, miT);
                     va.Ld[path] = make_float4(0.f, 0.f, 0.f, weightY);
                     if (nflags & 2) {
-                        va.mis_o[path] = make_float4(mo.x, mo.y, mo.z, __int_as_float(misMedium));
-                        va.mis_d[path] = make_float4(wi2.x, wi2.y, wi2.z, scatPdf2);
+                        va.mis_o[(size_t)path * kRS] = make_float4(mo.x, mo.y, mo.z, __int_as_float(misMedium));
+                        va.mis_d[(size_t)path * kRS] = make_float4(wi2.x, wi2.y, wi2.z, scatPdf2);
                         va.mis_Y[path] = make_float4(Y.r, Y.g, Y.b, 0.f);
                     }
                     if (nflags & 1) {
-                        pa.ray_o[path] = make_float4(so.x, so.y, so.z, 1 - GX_SHADOW_EPS);
-                        pa.ray_d[path] = make_float4(sd.x, sd.y, sd.z, __int_as_float(shMedium));
+                        pa.ray_o[(size_t)path * kRS] = make_float4(so.x, so.y, so.z, 1 - GX_SHADOW_EPS);
+                        pa.ray_d[(size_t)path * kRS] = make_float4(sd.x, sd.y, sd.z, __int_as_float(shMedium));
                         vs.x = VS_SHADOW;
                     } else {
-                        pa.ray_o[path] = make_float4(mo.x, mo.y, mo.z, GX_INF);
-                        pa.ray_d[path] = make_float4(wi2.x, wi2.y, wi2.z, __int_as_float(misMedium));
+                        pa.ray_o[(size_t)path * kRS] = make_float4(mo.x, mo.y, mo.z, GX_INF);
+                        pa.ray_d[(size_t)path * kRS] = make_float4(wi2.x, wi2.y, wi2.z, __int_as_float(misMedium));
                         vs.x = VS_MIS;
                     }
                     vs.y = ss.dim;
                     vs.z = leaf;
                     va.vs[path] = vs; va.state[path] = (unsigned char)vs.x;
-                    pa.beta[path] = make_float4(beta.r, beta.g, beta.b, etaScale);
+                    pa.beta[(size_t)path * kRS] = make_float4(beta.r, beta.g, beta.b, etaScale);
                     pa.L[path] = make_float4(L.r, L.g, L.b, 0.f);
                     pa.pflags[path] = (unsigned char)(1 | (((nflags & 1) ? shMedium : misMedium) >= 0 ? 2 : 0));
                     continue;
@@ -676,10 +678,10 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_vol_step(DScene sc, DM
                     else beta = beta / (1 - q);
                 }
                 if (survive) {
-                    pa.ray_o[path] = make_float4(o2.x, o2.y, o2.z, GX_INF);
-                    pa.ray_d[path] = make_float4(wi.x, wi.y, wi.z, __int_as_float(nextMedium));
-                    pa.beta[path] = make_float4(beta.r, beta.g, beta.b, etaScale);
-                    pa.meta[path] = make_uint2(index, ((uint32_t)(bounces + 1) << 16) | (specularBounce ? 0x80000000u : 0u));
+                    pa.ray_o[(size_t)path * kRS] = make_float4(o2.x, o2.y, o2.z, GX_INF);
+                    pa.ray_d[(size_t)path * kRS] = make_float4(wi.x, wi.y, wi.z, __int_as_float(nextMedium));
+                    pa.beta[(size_t)path * kRS] = make_float4(beta.r, beta.g, beta.b, etaScale);
+                    pa.store_meta(path, index, ((uint32_t)(bounces + 1) << 16) | (specularBounce ? 0x80000000u : 0u));
                     vs.x = VS_MAIN;
                     vs.y = ss.dim;
                     vs.w = 0;   // mi.SpawnRay(wi) / isect.SpawnRay(wi): a plain Ray
@@ -698,10 +700,10 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_vol_step(DScene sc, DM
 // against ~210 B of state (profiles/traffic_latest_cfg5.json, round 2).  When the survivors have dropped to half the span they are spread
 // over, their state is copied to the front of a second set of arrays (queue order == slot order is kept, so everything stays sorted and
 // coalesced), the queues are renumbered, and the rounds go on densely.  A path's results go to its ORIGINAL slot (`orig`, `Lout`).
-constexpr int kVolPackF4 = 17;   // float4-sized per-path arrays that carry state from round to round
+constexpr int kVolPackF4 = 8;    // float4-sized per-path arrays that carry state from round to round
 struct VolPackSet {
-    float4 *f4[kVolPackF4];      // ray_o ray_d beta L | vs sv_o sv_d p1 p1e n1 f Li Tr Ld mis_o mis_d mis_Y
-    uint2 *meta;
+    float4 *f4[kVolPackF4];      // L | vs n1 f Li Tr Ld mis_Y
+    float4 *rec[kRecGroups];     // the record groups of a slot (PathArrays): {ray_o ray_d} {beta meta} {sv_o sv_d} {p1 p1e} {mis_o mis_d}
     unsigned char *state;
     int *orig;
 };
@@ -710,7 +712,10 @@ static __global__ void __launch_bounds__(kBlock) k_vol_pack(const int *__restric
         const int p = queue ? queue[i] : i;
 #pragma unroll
         for (int k = 0; k < kVolPackF4; ++k) dst.f4[k][i] = src.f4[k][p];
-        dst.meta[i] = src.meta[p];
+#pragma unroll
+        for (int k = 0; k < kRecGroups; ++k)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) dst.rec[k][(size_t)i * kRS + e] = src.rec[k][(size_t)p * kRS + e];
         dst.state[i] = src.state[p];
         dst.orig[i] = src.orig[p];
         newslot[p] = i;

@@ -47,7 +47,7 @@ struct WhittedArrays {
 
 static __global__ void __launch_bounds__(kBlock) k_whitted_init(PathArrays pa, WhittedArrays wa, int n_paths) {
     for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_paths; slot += gridDim.x * blockDim.x) {
-        uint2 m = pa.meta[slot];
+        uint2 m = pa.meta[(size_t)slot * kRSm];
         // GlobalSampler::Get1D / Get2D jump over [arrayStartDim, arrayEndDim) (core/Sampler.cpp:165-166, 173-174); the camera
         // sample ends exactly at arrayStartDim = 5
         wa.ws[slot] = make_int4(0, max((int)m.y, wa.start_dim), -1, 0);
@@ -76,7 +76,7 @@ static __global__ void __launch_bounds__(kBlock) k_whitted_init_diff(DScene sc, 
     for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n_paths; slot += gridDim.x * blockDim.x) {
         int px, py;
         local_pixel(r, slot % r.npix, &px, &py);
-        store_ray_diff(wa, (size_t)slot, camera_ray_diff(r.cam, sc.st, px, py, pa.meta[slot].x, r.spp));
+        store_ray_diff(wa, (size_t)slot, camera_ray_diff(r.cam, sc.st, px, py, pa.meta[(size_t)slot * kRSm].x, r.spp));
     }
 }
 
@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_whitted_step(DScene sc
         int top = ws.x, pend = ws.z;
         bool pendArrays = (ws.w & 2) != 0;
         int nArrayVertices = ws.w >> 2;
-        const uint32_t index = pa.meta[path].x;
+        const uint32_t index = pa.meta[(size_t)path * kRSm].x;
         SampleStream ss(sc.st, index, ws.y);
         // ---- (a) the shadow rays of the most recent vertex have been traced: lightL, then L += lightL
         if (pend >= 0) {
@@ -111,8 +111,8 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_whitted_step(DScene sc
             if (MODE == WM_WHITTED) {
                 for (int l = 0; l < wa.n_lights; ++l) {
                     const size_t rec = (size_t)l * cap + path;
-                    if ((__float_as_int(pa.sh_d[rec].w) & 1) && pa.sh_o[rec].w == 1.f) {
-                        float4 X = pa.sh_X[rec];
+                    if ((__float_as_int(pa.sh_d[(size_t)rec * kRS].w) & 1) && pa.sh_o[(size_t)rec * kRS].w == 1.f) {
+                        float4 X = pa.sh_X[(size_t)rec * kRS];
                         lightL = lightL + Spec(X.x, X.y, X.z);
                     }
                 }
@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_whitted_step(DScene sc
         Spec result(0.f);
         if ((ws.w & 1) == 0) {
             // ---- (b) the ray in flight (recursion depth `top`) has been traced
-            float4 o4 = pa.ray_o[path], d4 = pa.ray_d[path];
+            float4 o4 = pa.ray_o[(size_t)path * kRS], d4 = pa.ray_d[(size_t)path * kRS];
             V3 ro(o4.x, o4.y, o4.z), rd(d4.x, d4.y, d4.z);
             const int leaf = pa.hit[path];
             bool found = leaf != -1;
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_whitted_step(DScene sc
                 haveResult = true;
             } else if (triMat < 0) { // no BSDF: Li(isect.SpawnRay(ray.d), ..., depth)
                 V3 o2 = offset_ray_origin(sp.p, sp.pError, sp.n, rd);
-                pa.ray_o[path] = make_float4(o2.x, o2.y, o2.z, GX_INF);
+                pa.ray_o[(size_t)path * kRS] = make_float4(o2.x, o2.y, o2.z, GX_INF);
                 if (TEX) wa.fr_rxo[(size_t)top * cap + path] = make_float4(0.f, 0.f, 0.f, 0.f);   // isect.SpawnRay(ray.d): a plain Ray
                 traceClosest = true;
             } else {
@@ -205,20 +205,20 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_whitted_step(DScene sc
                                 V3 so, sd;
                                 spawn_ray_to(sp.p, sp.pError, sp.n, ls.p1, ls.p1Error, ls.n1, &so, &sd);
                                 Spec X = f * ls.Li * absdot(ls.wi, sp.ns) / ls.pdf;
-                                pa.sh_o[rec] = make_float4(so.x, so.y, so.z, 1 - GX_SHADOW_EPS);
-                                pa.sh_X[rec] = make_float4(X.r, X.g, X.b, 0.f);
-                                pa.sh_d[rec] = make_float4(sd.x, sd.y, sd.z, __int_as_float(1));
+                                pa.sh_o[(size_t)rec * kRS] = make_float4(so.x, so.y, so.z, 1 - GX_SHADOW_EPS);
+                                pa.sh_X[(size_t)rec * kRS] = make_float4(X.r, X.g, X.b, 0.f);
+                                pa.sh_d[(size_t)rec * kRS] = make_float4(sd.x, sd.y, sd.z, __int_as_float(1));
                                 flag = 1;
                                 ++nShadow;
                             }
                         }
-                        if (!flag) pa.sh_d[rec] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
+                        if (!flag) pa.sh_d[(size_t)rec * kRS] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
                     }
                 } else if (sc.lt.n_lights > 0) {
                     auto record = [&](int slot, int lightNum, float ul0, float ul1, float us0, float us1, float xw) {
                         const size_t rec = (size_t)slot * cap + path;
                         const int nflags = estimate_direct_record<LM_ALL, LT>(sc, bsdf, sp, woN, lightNum, ul0, ul1, us0, us1, pa, rec, xw);
-                        if (!nflags) { pa.sh_d[rec] = make_float4(0.f, 0.f, 0.f, __int_as_float(0)); pa.sh_X[rec] = make_float4(0.f, 0.f, 0.f, xw); }
+                        if (!nflags) { pa.sh_d[(size_t)rec * kRS] = make_float4(0.f, 0.f, 0.f, __int_as_float(0)); pa.sh_X[(size_t)rec * kRS] = make_float4(0.f, 0.f, 0.f, xw); }
                         nShadow += nflags & 1;
                         nMis += (nflags >> 1) & 1;
                     };
@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_whitted_step(DScene sc
                                 ss.get2d(&ul0, &ul1);
                                 ss.get2d(&us0, &us1);
                                 record(base, l, ul0, ul1, us0, us1, 1.f);
-                                for (int k = 1; k < nSamples; ++k) pa.sh_d[(size_t)(base + k) * cap + path] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
+                                for (int k = 1; k < nSamples; ++k) pa.sh_d[(size_t)((size_t)(base + k) * cap + path) * kRS] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
                             }
                             base += nSamples;
                         }
@@ -260,8 +260,8 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_whitted_step(DScene sc
                 } else {
                     // `if (scene.lights.size() > 0)` (DirectLightingIntegrator.cpp:53): no direct term and no sample draws
                     for (int k = 0; k < wa.n_records; ++k) {
-                        pa.sh_d[(size_t)k * cap + path] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
-                        pa.sh_X[(size_t)k * cap + path] = make_float4(0.f, 0.f, 0.f, 1.f);
+                        pa.sh_d[(size_t)((size_t)k * cap + path) * kRS] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
+                        pa.sh_X[(size_t)((size_t)k * cap + path) * kRS] = make_float4(0.f, 0.f, 0.f, 1.f);
                     }
                 }
                 const size_t fi = (size_t)top * cap + path;
@@ -338,8 +338,8 @@ __global__ void __launch_bounds__(kBlock) GX_SHADE_ATTR k_whitted_step(DScene sc
                     Spec fs = bsdf.sample_f(woN, &wi, u0, u1, &pdf, type, &sampledType);
                     if (pdf > 0.f && !fs.is_black() && absdot(wi, sp.ns) != 0.f) {
                         V3 o2 = offset_ray_origin(sp.p, sp.pError, sp.n, wi);
-                        pa.ray_o[path] = make_float4(o2.x, o2.y, o2.z, GX_INF);
-                        pa.ray_d[path] = make_float4(wi.x, wi.y, wi.z, __int_as_float(-1));
+                        pa.ray_o[(size_t)path * kRS] = make_float4(o2.x, o2.y, o2.z, GX_INF);
+                        pa.ray_d[(size_t)path * kRS] = make_float4(wi.x, wi.y, wi.z, __int_as_float(-1));
                         wa.fr_w[fi] = make_float4(fs.r, fs.g, fs.b, absdot(wi, sp.ns));
                         wa.fr_pdf[fi] = pdf;
                         if (TEX) {   // the child's offset rays, Integrator.cpp:335-354 / 376-436
