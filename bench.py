@@ -241,20 +241,16 @@ def git_head():
 
 
 def kernel_source_id():
-    """Identifies the KERNELS a counter file was measured on: a hash over csrc/ and the compile flags (a commit that only touches documents
-    or tests leaves it alone, so committed counter files do not go stale with every commit)."""
-    import hashlib
-    h = hashlib.sha1()
-    d = os.path.join(ROOT, "gnxraytracer_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".h", ".hip", ".cpp")):
-            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
-    try:
-        import __graft_entry__ as ge
-        h.update(" ".join(ge.HIPCC_FLAGS).encode())
-    except Exception:
-        pass
-    return h.hexdigest()[:12]
+    """Identifies the KERNELS a counter file was measured on (__graft_entry__.source_id: a hash over csrc/ and the compile flags)."""
+    import __graft_entry__ as ge
+    return ge.source_id()
+
+
+def library_matches_source():
+    """False when the libgnxr.so in the tree was not built from the csrc/ in the tree (None: no id file beside the library)."""
+    import __graft_entry__ as ge
+    lid = ge.library_source_id()
+    return None if lid is None else lid == ge.source_id()
 
 
 def counters_stale(tj):
@@ -576,7 +572,9 @@ def main():
                    "sharding": f"rows y % {world} == rank" if world > 1 else "none",
                    "gather": "RCCL gather of row shards to rank 0 (in timed region)" if world > 1 else "n/a",
                    "world_size": dist.get_world_size() if world > 1 else 1, "backend": (backend if world > 1 else "none"),
-                   "devices_visible": n_visible, "commit": git_head(), "per_rank": per_rank},
+                   "devices_visible": n_visible, "commit": git_head(), "kernel_source_id": kernel_source_id(),
+                   # False: the libgnxr.so that ran was not built from the csrc/ in this tree (a stale or experiment library)
+                   "library_matches_source": library_matches_source(), "per_rank": per_rank},
         "wall_to_1024spp_s": dt_max * (1024.0 / spp_timed),
         "wall_to_full_spp_s": dt_max * (float(args.spp) / spp_timed),
         "wall_measured_s": dt_max,

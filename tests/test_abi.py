@@ -86,3 +86,11 @@ def test_kernel_register_budgets(gx):
     assert t4 and all(k["waves_per_simd"] >= 5 and k["vgpr_spill"] == 0 for k in t4), t4
     head = [k for k in ks if ("k_shade<458879u, 1, false, false>" in k["name"] or "k_shade<3u, 1, false, false>" in k["name"])]
     assert len(head) == 2 and all(k["scratch"] <= 256 and k["waves_per_simd"] >= 3 for k in head), head
+
+
+def test_library_was_built_from_the_sources_in_the_tree():
+    """build() writes the hash of csrc/ + flags it compiled beside libgnxr.so; a library left behind by an experiment build or by a checkout of
+    other sources (what ships to the GPU box is the file in the tree, not the sources) must not pass for the product."""
+    import __graft_entry__ as ge
+    ge.build_lib()
+    assert ge.library_source_id() == ge.source_id()
