@@ -1233,6 +1233,7 @@ else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, slds, cst[3],
                 launch_trace(TraceWork{q_in, n, nullptr, 0}, 0, 0);
                 if (n_media > 0) {
                     (void)hipMemsetAsync(&dctr->cursor, 0, sizeof(unsigned int), stream);
+                    // (4 / 5 / 8 / 16 / 32 blocks per CU: k_vol_media 0.357 s per 3 x 256 spp of cfg 5 each time -- its waves persist; profiles/r03_ab_vol_step_occupancy_cfg5.log)
                     int blocks = (int)std::min<long long>((long long)g_num_cus * 8, ((long long)n_media + kBlock - 1) / kBlock);
                     if (timing) timer.begin(1, stream);
                     const long long mwaves = (long long)blocks * (kBlock / 64);

@@ -11,7 +11,7 @@
 //                   (shadow ray + MIS ray records), BSDF sampling, Russian roulette, compaction  (A7-A21)
 //   k_resolve       colObj += Li in sample order, box average                                   (A1)
 //
-// State is SoA-of-float4 in HBM (one dwordx4 per lane per field, coalesced); queues hold path slots and
+// State lives in HBM as 32-byte records grouped by consumer plus a few plain arrays (PathArrays below); queues hold path slots and
 // are compacted order-preservingly with wave64 ballots + a tile scan (compact_kernel.hip.h: no atomics).
 // No MFMA: the work is BVH pointer chasing and divergent shading, bound by VALU issue and memory latency.
 #pragma once
