@@ -11,7 +11,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     spp = int(os.environ.get("GNXR_AB_SPP", spp)); passes = int(os.environ.get("GNXR_AB_PASSES", passes))   # per-variant overrides
     gx.init(0)
     b = scenes.dragon_cornell(100000, "glass+metal") if workload == "cfg3" else scenes.dragon_cornell(100000, "zoo", env=scenes.synthetic_env_path(1000, 500))
-    scene = gx.Scene(b); integ = gx.PathIntegrator(8, 1.0, "spatial")
+    scene = gx.Scene(b)
+    which = os.environ.get("GNXR_AB_INTEG", "path")   # per-variant: the integrator under test
+    integ = {"path": lambda: gx.PathIntegrator(8, 1.0, "spatial"), "whitted": lambda: gx.WhittedIntegrator(5), "direct": lambda: gx.DirectLightingIntegrator("all", 5),
+             "direct_one": lambda: gx.DirectLightingIntegrator("one", 5), "volpath": lambda: gx.VolPathIntegrator(8, 1.0, "spatial")}[which]()
     out = torch.zeros((1080, 1920, 4), device="cuda")
     gx.lib().gnxr_set_profiling(1)
     best = None
