@@ -1210,7 +1210,7 @@ else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, slds, cst[3],
             auto pack_set = [&](bool alt) {
                 VolPackSet ps;
                 if (!alt) {
-                    float4 *a[kVolPackF4] = {s->L.p, reinterpret_cast<float4 *>(s->vol_vs.p), s->vol_n1.p, s->vol_f.p, s->vol_Li.p, s->vol_Tr.p, s->vol_Ld.p, s->mis_Y.p};
+                    float4 *a[kVolPackF4] = {s->L.p, reinterpret_cast<float4 *>(s->vol_vs.p), s->vol_n1.p, s->vol_f.p, s->vol_Li.p, s->vol_Tr.p, s->vol_Ld.p, s->mis_Y.p, s->vol_mres.p};
                     for (int i = 0; i < kVolPackF4; ++i) ps.f4[i] = a[i];
                     gnxr_scene::record_ptrs(s->rec, ps.rec);
                     ps.state = s->vol_state.p; ps.orig = s->vol_orig.p;
@@ -1223,7 +1223,7 @@ else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, slds, cst[3],
             };
             auto bind_set = [&](const VolPackSet &ps) {   // point the kernels' views at a set
                 pa.bind_records(ps.rec); va.bind_records(ps.rec);
-                pa.L = ps.f4[0]; va.vs = reinterpret_cast<int4 *>(ps.f4[1]); va.n1 = ps.f4[2]; va.f = ps.f4[3]; va.Li = ps.f4[4]; va.Tr = ps.f4[5]; va.Ld = ps.f4[6]; pa.mis_Y = va.mis_Y = ps.f4[7];
+                pa.L = ps.f4[0]; va.vs = reinterpret_cast<int4 *>(ps.f4[1]); va.n1 = ps.f4[2]; va.f = ps.f4[3]; va.Li = ps.f4[4]; va.Tr = ps.f4[5]; va.Ld = ps.f4[6]; pa.mis_Y = va.mis_Y = ps.f4[7]; va.mres = ps.f4[8];
                 va.state = ps.state; va.orig = ps.orig;
             };
             bool in_alt = false;
@@ -1235,11 +1235,12 @@ else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, slds, cst[3],
                     (void)hipMemsetAsync(&dctr->cursor, 0, sizeof(unsigned int), stream);
                     // (4 / 5 / 8 / 16 / 32 blocks per CU: k_vol_media 0.357 s per 3 x 256 spp of cfg 5 each time -- its waves persist; profiles/r03_ab_vol_step_occupancy_cfg5.log)
                     int blocks = (int)std::min<long long>((long long)g_num_cus * 8, ((long long)n_media + kBlock - 1) / kBlock);
+                    const int vm_cap = getenv("GNXR_VOLMEDIA_STEP_CAP") ? std::max(0, atoi(getenv("GNXR_VOLMEDIA_STEP_CAP"))) : 64;   // tuning knob, read per launch so that a test can vary it (0: no cap)
                     if (timing) timer.begin(1, stream);
                     const long long mwaves = (long long)blocks * (kBlock / 64);
                     const int mchunk = (int)std::min<long long>(kMediaChunk, std::max<long long>(64, ((n_media + mwaves - 1) / mwaves + 63) / 64 * 64));
-                    if (count_wide) hipLaunchKernelGGL(k_vol_media<true>, dim3(blocks), dim3(kBlock), (size_t)kVmRecDwords * kVmStride * sizeof(int), stream, sc, mt, pa, va, q_media, n_media, &dctr->cursor, mchunk, dctr);
-                    else hipLaunchKernelGGL(k_vol_media<false>, dim3(blocks), dim3(kBlock), (size_t)kVmRecDwords * kVmStride * sizeof(int), stream, sc, mt, pa, va, q_media, n_media, &dctr->cursor, mchunk, dctr);
+                    if (count_wide) hipLaunchKernelGGL(k_vol_media<true>, dim3(blocks), dim3(kBlock), (size_t)kVmRecDwords * kVmStride * sizeof(int), stream, sc, mt, pa, va, q_media, n_media, &dctr->cursor, mchunk, dctr, vm_cap);
+                    else hipLaunchKernelGGL(k_vol_media<false>, dim3(blocks), dim3(kBlock), (size_t)kVmRecDwords * kVmStride * sizeof(int), stream, sc, mt, pa, va, q_media, n_media, &dctr->cursor, mchunk, dctr, vm_cap);
                     media_segments += (unsigned long long)n_media;
                     if (timing) timer.end(stream);
                     ++launches;
@@ -1315,6 +1316,10 @@ else hipLaunchKernelGGL((k_shade<LM_ALL, LTV, false, true>), g, b, slds, cst[3],
             rays_closest = new_paths + s->h_counters->rays_continue + s->h_counters->rays_mis;
             rays_any = s->h_counters->rays_shadow;
             rays_mis = s->h_counters->rays_mis;
+        }
+        if (volpath) {   // a segment k_vol_media left at its step cap was traced and handed over once more: the same ray, counted once
+            rays_closest -= s->h_counters->media_cont;
+            media_segments -= s->h_counters->media_cont;
         }
         stats->rays_closest = rays_closest + (whitted ? s->h_counters->whitted_mis : 0);
         stats->rays_any = whitted ? s->h_counters->whitted_shadow : rays_any;

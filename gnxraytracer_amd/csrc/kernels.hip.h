@@ -82,6 +82,7 @@ struct Counters {
     unsigned long long whitted_shadow;              // shadow rays queued by k_whitted_step
     unsigned long long whitted_mis;                 // MIS closest-hit rays queued by k_whitted_step (DirectLighting); follows whitted_shadow
     unsigned long long media_steps;                 // tracking-loop iterations of k_vol_media<COUNT>
+    unsigned long long media_cont;                  // segments k_vol_media left at its step cap (each is traced and handed to it once more)
     unsigned long long retests;                     // k_trace<COUNT, WIDE>: leaf boxes re-tested against a shrunken tMax (32 B each)
     unsigned long long nodes_global;                // k_trace4<COUNT>: node visits served from global memory (the others come from the LDS copy of the top of the tree)
     // ---- the device-driven PathIntegrator loop (api.hip): the host never waits for these, it reads lagging copies

@@ -28,10 +28,12 @@
 
 namespace gnxr {
 
-enum : int { VS_MAIN = 0, VS_SHADOW = 1, VS_MIS = 2 };
+enum : int { VS_MAIN = 0, VS_SHADOW = 1, VS_MIS = 2, VS_PARKED = 3 };   // VS_PARKED: only in VolArrays::state (k_vol_media's step cap)
 
 struct VolArrays {
-    int4 *vs;        // x: state, y: Halton dimension, z: hit leaf of the saved vertex, w: 1 while the main ray is still the camera ray (it has ray differentials)
+    int4 *vs;        // x: state, y: Halton dimension, z: hit leaf of the saved vertex, w: bit 0: the main ray is still the camera ray (it has ray differentials),
+                     //    bit 1 (kVsCont): k_vol_media left the segment in flight at its step cap -- the path sits this round out (its `state` is
+                     //    VS_PARKED, which no k_vol_step bin takes) and the tracking loop goes on from mres in the next one
     float4 *sv_o;    // saved main ray of the vertex: o.xyz, tMax
     float4 *sv_d;    // d.xyz, medium (int bits)
     float4 *p1;      // light sample point p1.xyz, w: light-selection pdf
@@ -45,7 +47,8 @@ struct VolArrays {
     float4 *mis_d;   // scattering ray direction, w: scattering pdf
     float4 *mis_Y;   // f * Li2
     unsigned char *state;   // copy of vs.x for the live paths: key of the per-state binning before k_vol_step
-    float4 *mres;    // k_vol_media result for the ray in flight: Medium::Sample weight / Medium::Tr (rgb), w: t of the sampled interaction or -1
+    float4 *mres;    // k_vol_media result for the ray in flight: Medium::Sample weight / Medium::Tr (rgb), w: t of the sampled interaction or -1;
+                     // while vs.w has kVsCont: x: Tr so far, y: t reached (same ray, same stream position next round: same result)
     int *orig;       // the slot (sample j * npix + pixel) a path started in: packing (k_vol_pack) moves the live paths to the front of the state arrays
     float4 *Lout;    // final radiance of a path, written once when it ends, at its ORIGINAL slot: what k_resolve sums in sample order
     // sv_o sv_d | p1 p1e | mis_o mis_d are the fields of the slot's record groups 2 - 4 (PathArrays, kernels.hip.h): element i at [i * kRS]
@@ -87,14 +90,18 @@ GX_DEV int hit_medium(const DScene &sc, const DMediaTables &mt, int leaf, int ra
 constexpr int kMediaChunk = 256;   // most paths a wave takes per global atomic (smaller for thin launches, chosen by the host)
 
 // COUNT: add the number of tracking-loop iterations to ctr->media_steps (profiling run; gnxr_set_profiling bit 2)
-constexpr int kVmRecDwords = 12;                 // LDS record of a set-up medium segment (k_vol_media)
+constexpr int kVmRecDwords = 13;                 // LDS record of a set-up medium segment (k_vol_media)
+constexpr int kVsCont = 2;                       // VolArrays::vs[].w bit: the segment is to be continued
 constexpr int kVmStride = (kBlock / 64) * 64;     // ints per record field per block
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt, PathArrays pa, VolArrays va, const int *__restrict__ queue, int n, unsigned int *cursor, int chunk, Counters *ctr) {
+__global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt, PathArrays pa, VolArrays va, const int *__restrict__ queue, int n, unsigned int *cursor, int chunk, Counters *ctr, int step_cap) {
     // LDS: kVmRecDwords x (4 waves x 64) ints -- the set-up segments a wave has parked (SoA: field * kVmStride + wave * 64 + slot)
     extern __shared__ int vm_smem[];
     lds_int *const rq = (lds_int *)&vm_smem[(threadIdx.x >> 6) * 64];
     unsigned long long cntSteps = 0;
+    unsigned cntCont = 0;   // segments this lane left unfinished at the step cap
+    int nsteps = 0;         // tracking steps of the lane's current segment in THIS launch
+    int camBit = 0, realState = 0, wasParked = 0;   // bit 0 of the path's vs.w, its state, and whether this launch continues a parked segment
     const int lane = __lane_id();
     const unsigned total = (unsigned)n;
     unsigned poolBase = 0, poolCount = 0;
@@ -132,7 +139,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt
                     int rPath = -1, rMed = 0, rDim = 0;
                     uint32_t rIndex = 0;
                     V3 rO, rD;
-                    float rT = 0, rTMax = 0;
+                    float rT = 0, rTMax = 0, rTr = 1.f;
                     if ((unsigned)lane < take) {
                         const int p = queue ? queue[poolBase + lane] : (int)(poolBase + lane);
                         int4 vs = va.vs[p];
@@ -183,6 +190,10 @@ __global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt
                                     rPath = p; rMed = med | (vs.x == VS_MAIN ? 0x10000 : 0);
                                     rIndex = ss.index; rDim = ss.dim;
                                     rO = oo; rD = dd; rT = tMin; rTMax = tEnd;
+                                    // a segment the last round left at the step cap goes on where it stopped (vs.y already is its stream position)
+                                    if (vs.w & kVsCont) { const float4 prev = va.mres[p]; rTr = prev.x; rT = prev.y; }
+                                    // the camera-ray flag, the state and whether this is a continuation travel with the record: vs.w / state are rewritten when the segment parks, and again when it ends
+                                    rMed |= ((vs.w & 1) << 17) | ((vs.x & 3) << 18) | ((vs.w & kVsCont) ? (1 << 20) : 0);
                                 }
                             }
                         }
@@ -193,7 +204,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt
                         q[0 * kVmStride] = rPath; q[1 * kVmStride] = rMed; q[2 * kVmStride] = (int)rIndex; q[3 * kVmStride] = rDim;
                         q[4 * kVmStride] = __float_as_int(rO.x); q[5 * kVmStride] = __float_as_int(rO.y); q[6 * kVmStride] = __float_as_int(rO.z);
                         q[7 * kVmStride] = __float_as_int(rD.x); q[8 * kVmStride] = __float_as_int(rD.y); q[9 * kVmStride] = __float_as_int(rD.z);
-                        q[10 * kVmStride] = __float_as_int(rT); q[11 * kVmStride] = __float_as_int(rTMax);
+                        q[10 * kVmStride] = __float_as_int(rT); q[11 * kVmStride] = __float_as_int(rTMax); q[12 * kVmStride] = __float_as_int(rTr);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // the records are read by other lanes of this wave
                     rqCount = (unsigned)__popcll(vmask); rqHead = 0;
@@ -206,11 +217,11 @@ __global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt
                     const lds_int *q = rq + rqHead + rank;
                     path = q[0 * kVmStride];
                     const int pm = q[1 * kVmStride];
-                    medium = pm & 0xffff; sampleMode = (pm & 0x10000) != 0;
+                    medium = pm & 0xffff; sampleMode = (pm & 0x10000) != 0; camBit = (pm >> 17) & 1; realState = (pm >> 18) & 3; wasParked = (pm >> 20) & 1;
                     index = (uint32_t)q[2 * kVmStride]; dim = q[3 * kVmStride]; cachedDim = -1;
                     o = V3(__int_as_float(q[4 * kVmStride]), __int_as_float(q[5 * kVmStride]), __int_as_float(q[6 * kVmStride]));
                     d = V3(__int_as_float(q[7 * kVmStride]), __int_as_float(q[8 * kVmStride]), __int_as_float(q[9 * kVmStride]));
-                    t = __int_as_float(q[10 * kVmStride]); tMax = __int_as_float(q[11 * kVmStride]); Tr = 1;
+                    t = __int_as_float(q[10 * kVmStride]); tMax = __int_as_float(q[11 * kVmStride]); Tr = __int_as_float(q[12 * kVmStride]); nsteps = 0;
                     const DMedium &m = mt.media[medium];
                     nx = m.nx; ny = m.ny; nz = m.nz;
                     invMaxDensity = m.inv_max_density;
@@ -278,11 +289,26 @@ __global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt
                 }
                 va.mres[path] = res;
                 reinterpret_cast<int *>(&va.vs[path])[1] = dim;
+                if (wasParked) { reinterpret_cast<int *>(&va.vs[path])[3] = camBit; va.state[path] = (unsigned char)realState; }   // back among the living
+                path = -1;
+            } else if (step_cap > 0 && ++nsteps >= step_cap) {
+                // Step cap: a launch ends with its longest segment (0 ... ~1000 steps of ~2.4 us each once the chip has drained: 0.6 ms per launch,
+                // a quarter of the kernel's time over the ~40 launches of a pass), so a segment that is still running after step_cap steps parks
+                // its state; k_vol_step leaves the path alone this round, the next round re-traces the same ray and comes back here.
+                va.mres[path] = make_float4(Tr, t, 0.f, 0.f);
+                reinterpret_cast<int *>(&va.vs[path])[1] = dim;   // (a pending second half of a pair is simply drawn again: same dimension, same value)
+                reinterpret_cast<int *>(&va.vs[path])[3] = camBit | kVsCont;
+                va.state[path] = (unsigned char)VS_PARKED;   // no k_vol_step bin takes it this round
+                pa.pflags[path] = (unsigned char)(1 | 2);    // alive, ray inside a medium: k_vol_step, which writes the flags of the paths it handles, will not see this one
+                                                             // (and k_trace4 clears the flags of a ray that leaves a scene without infinite lights)
+                ++cntCont;
                 path = -1;
             }
         }
     }
     if (COUNT && cntSteps) atomicAdd(&ctr->media_steps, cntSteps);
+    for (int o = 32; o > 0; o >>= 1) cntCont += __shfl_xor(cntCont, o);
+    if (cntCont && lane == 0) atomicAdd(&ctr->media_cont, (unsigned long long)cntCont);
 }
 
 // LM: the lobe set every material of the scene fits in (device_bsdf.h LM_*): a scene of Matte walls and media runs the
@@ -714,9 +740,9 @@ __global__ void __launch_bounds__(kBlock, (vol_min_waves<LM, ST, TEX>())) k_vol_
 // against ~210 B of state (profiles/traffic_latest_cfg5.json, round 2).  When the survivors have dropped to half the span they are spread
 // over, their state is copied to the front of a second set of arrays (queue order == slot order is kept, so everything stays sorted and
 // coalesced), the queues are renumbered, and the rounds go on densely.  A path's results go to its ORIGINAL slot (`orig`, `Lout`).
-constexpr int kVolPackF4 = 8;    // float4-sized per-path arrays that carry state from round to round
+constexpr int kVolPackF4 = 9;    // float4-sized per-path arrays that carry state from round to round
 struct VolPackSet {
-    float4 *f4[kVolPackF4];      // L | vs n1 f Li Tr Ld mis_Y
+    float4 *f4[kVolPackF4];      // L | vs n1 f Li Tr Ld mis_Y mres
     float4 *rec[kRecGroups];     // the record groups of a slot (PathArrays): {ray_o ray_d} {beta meta} {sv_o sv_d} {p1 p1e} {mis_o mis_d}
     unsigned char *state;
     int *orig;

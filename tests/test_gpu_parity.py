@@ -313,6 +313,27 @@ def test_volpath_cfg5_density_against_oracle(gpu):
     assert (acc.view(np.uint32) == img.view(np.uint32)).all()
 
 
+@pytest.mark.parametrize("cap", ["0", "5", None])
+def test_volpath_step_cap_and_packing_over_several_passes(gpu, monkeypatch, cap):
+    """k_vol_media parks a tracking loop that is still running after GNXR_VOLMEDIA_STEP_CAP steps (default 64) and goes on with it in the
+    next round; k_vol_pack moves the live paths between two sets of state arrays and leaves copies of such records behind.  Three passes
+    of 262 k paths (packing engages, slots are reused by other paths) must give the oracle's image and ray count with no cap, with a cap
+    that nearly every segment hits several times, and with the shipped one."""
+    if cap is None: monkeypatch.delenv("GNXR_VOLMEDIA_STEP_CAP", raising=False)
+    else: monkeypatch.setenv("GNXR_VOLMEDIA_STEP_CAP", cap)
+    b = scenes.volume_cornell_cfg5(1.0)
+    integ = gpu.VolPathIntegrator(8, 1.0, "spatial")
+    img, st = integ.Render(gpu.Scene(b), 256, 256, 256, spp_begin=0, spp_end=12, samples_per_pass=4)
+    oimg, ost = ol.OracleScene(b).render(integ, 256, 256, 256, spp_begin=0, spp_end=12)
+    assert st["rays_closest"] == ost["rays_closest"]
+    assert biteq(img[..., :3], oimg[..., :3])
+    # the same range again on the same scene object: the same paths land in the same slots, where the first render left its records
+    scene = gpu.Scene(b)
+    for _ in range(2):
+        img2, st2 = integ.Render(scene, 256, 256, 256, spp_begin=0, spp_end=12, samples_per_pass=4)
+        assert st2["rays_closest"] == ost["rays_closest"] and biteq(img2[..., :3], oimg[..., :3])
+
+
 def test_path_integrator_passes_through_medium_boundaries(gpu):
     """PathIntegrator on the volume scene: null-material boundaries are skipped (PathIntegrator.cpp:121-126)."""
     b = scenes.volume_cornell(sigma_a=(0.5,) * 3, sigma_s=(3.5,) * 3)
