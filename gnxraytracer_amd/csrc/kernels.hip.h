@@ -392,9 +392,13 @@ static __device__ unsigned long long g_shade_stats[16];
 #ifndef GX_SHADE_W_ALL
 #define GX_SHADE_W_ALL GX_SHADE_MINWAVES
 #endif
+// (the image-textured class: three waves as well -- PathIntegrator on the image-textured Cornell box +6 %, profiles/r03_ab_textured_occupancy.log)
+#ifndef GX_SHADE_W_TEX
+#define GX_SHADE_W_TEX 3
+#endif
 template <uint32_t LM> constexpr int shade_min_waves() { return LM == LM_DIFFUSE ? GX_SHADE_W_DIFFUSE : (LM == LM_GLOSSY ? GX_SHADE_W_GLOSSY : GX_SHADE_W_ALL); }
 template <uint32_t LM, int LT, bool SPH, bool TEX = false>
-__global__ void __launch_bounds__(kBlock, shade_min_waves<LM>()) k_shade(DScene sc, DRender r, PathArrays pa, const int *__restrict__ queue, const unsigned int *n_dev, int lds_dims, int lds_nperm, int lds_mats, int lds_lights) {
+__global__ void __launch_bounds__(kBlock, (TEX ? GX_SHADE_W_TEX : shade_min_waves<LM>())) k_shade(DScene sc, DRender r, PathArrays pa, const int *__restrict__ queue, const unsigned int *n_dev, int lds_dims, int lds_nperm, int lds_mats, int lds_lights) {
     extern __shared__ int shade_smem[];   // the Halton tables of dimensions [0, lds_dims): device_sampler.h LdsSampler | the scene's DMaterial[] | DLight[]
     const int n = (int)*n_dev;
     if (blockIdx.x * blockDim.x >= (unsigned)n) return;   // this block has no item: skip the table fill

@@ -321,7 +321,8 @@ __global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt
 // minimum waves per SIMD (tuning knobs, tools/build_variant.sh).  The kernel waits on dependent gathers for 62 % of its wave cycles, so a third wave
 // is worth the 22 dwords the MAIN state of the diffuse class then spills (198 -> 168 registers): k_vol_step + compaction -5 ... -9 %, cfg 5 -2 ... -4 %;
 // a fourth wave for the segment states (152 -> 128) changes nothing (profiles/r03_ab_vol_step_occupancy_cfg5.log).  The glossy / Disney instantiations
-// (235 - 256 registers at two waves) take three as well: VolPath on the cfg 3 / cfg 4 scenes +4.4 % / +5.5 %; the textured ones were not measured (two).
+// (235 - 256 registers at two waves) take three as well: VolPath on the cfg 3 / cfg 4 scenes +4.4 % / +5.5 %; the textured ones too (+2.5 % on the
+// image-textured Cornell box, profiles/r03_ab_textured_occupancy.log).
 #ifndef GX_VOL_W_MAIN
 #define GX_VOL_W_MAIN 3
 #endif
@@ -331,7 +332,7 @@ __global__ void __launch_bounds__(kBlock) k_vol_media(DScene sc, DMediaTables mt
 #ifndef GX_VOL_W_OTHER
 #define GX_VOL_W_OTHER 3
 #endif
-template <uint32_t LM, int ST, bool TEX> constexpr int vol_min_waves() { return (LM == LM_DIFFUSE && !TEX) ? (ST == VS_MAIN ? GX_VOL_W_MAIN : GX_VOL_W_SEG) : (TEX ? 2 : GX_VOL_W_OTHER); }
+template <uint32_t LM, int ST, bool TEX> constexpr int vol_min_waves() { return (LM == LM_DIFFUSE && !TEX) ? (ST == VS_MAIN ? GX_VOL_W_MAIN : GX_VOL_W_SEG) : GX_VOL_W_OTHER; }
 template <uint32_t LM, int LT, int ST, bool TEX = false>
 __global__ void __launch_bounds__(kBlock, (vol_min_waves<LM, ST, TEX>())) k_vol_step(DScene sc, DMediaTables mt, DRender r, PathArrays pa, VolArrays va, const int *__restrict__ queue, const unsigned int *n_dev, int lds_mats, int lds_lights) {
     extern __shared__ int vstep_smem[];   // the scene's DMaterial[] | DLight[] when they are small (as in k_shade: dependent gathers along the BSDF code become LDS reads)

@@ -94,11 +94,12 @@ static __global__ void __launch_bounds__(kBlock) k_whitted_expand(const int *__r
 // take the camera RayDifferential and SpecularReflect / SpecularTransmit derive the children's), textures are filtered with them.
 // Minimum waves per SIMD.  Every instantiation wants 256 registers; held to 168 (three waves, 120 - 260 dwords spilled) the Whitted and the
 // UniformSampleAll kernels are 5 % / 8 % faster (whole render -2.3 % / -4 %), the UniformSampleOne kernel 4 % slower
-// (profiles/r03_ab_whitted_occupancy.log); the textured instantiations were not measured and stay at two.
+// (profiles/r03_ab_whitted_occupancy.log); the textured instantiations likewise (image-textured Cornell box: Whitted +-0, UniformSampleAll +7 %,
+// profiles/r03_ab_textured_occupancy.log).
 #ifndef GX_WHITTED_W
 #define GX_WHITTED_W 3
 #endif
-template <int MODE, bool TEX> constexpr int whitted_min_waves() { return (MODE != WM_DIRECT_ONE && !TEX) ? GX_WHITTED_W : 2; }
+template <int MODE, bool TEX> constexpr int whitted_min_waves() { return MODE != WM_DIRECT_ONE ? GX_WHITTED_W : 2; }
 template <int MODE, int LT, bool SPH, bool TEX = false>
 __global__ void __launch_bounds__(kBlock, (whitted_min_waves<MODE, TEX>())) k_whitted_step(DScene sc, DRender r, PathArrays pa, WhittedArrays wa, const int *__restrict__ queue, int n,
                                                          unsigned long long *ray_counts) {

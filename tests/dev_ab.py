@@ -10,7 +10,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     spp, workload, passes = int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
     spp = int(os.environ.get("GNXR_AB_SPP", spp)); passes = int(os.environ.get("GNXR_AB_PASSES", passes))   # per-variant overrides
     gx.init(0)
-    b = scenes.dragon_cornell(100000, "glass+metal") if workload == "cfg3" else scenes.dragon_cornell(100000, "zoo", env=scenes.synthetic_env_path(1000, 500))
+    if workload == "tex":   # the image-textured Cornell box of the parity tests (smile-face plastic, tiled matte floor, mirror, glass sheet)
+        from conftest import GOLDEN
+        b = scenes.textured_cornell(os.path.join(GOLDEN, "tex_smile_96x80.hdr"))
+    else:
+        b = scenes.dragon_cornell(100000, "glass+metal") if workload == "cfg3" else scenes.dragon_cornell(100000, "zoo", env=scenes.synthetic_env_path(1000, 500))
     scene = gx.Scene(b)
     which = os.environ.get("GNXR_AB_INTEG", "path")   # per-variant: the integrator under test
     integ = {"path": lambda: gx.PathIntegrator(8, 1.0, "spatial"), "whitted": lambda: gx.WhittedIntegrator(5), "direct": lambda: gx.DirectLightingIntegrator("all", 5),
